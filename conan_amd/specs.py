@@ -1,0 +1,166 @@
+"""state_dict layouts (key -> shape) of the three hot-path models.
+
+The key names and shapes are the checkpoint contract of SURVEY.md §8(b): they
+are what `torch.load(...)['state_dict']` of a reference checkpoint contains,
+so reference checkpoints load unchanged into conan_amd.modules.* and into the
+C-ABI (`conan_ctx_load_tensor` takes these keys prefixed by the model name).
+
+  Conan      modules/Conan/Conan.py:46-113 + modules/tts/fs.py:49-79
+  HiFi-GAN   modules/vocoder/hifigan/hifigan_causal.py:273-312
+  Emformer   modules/Emformer/emformer.py:14-25 (torchaudio.models.Emformer)
+"""
+from collections import OrderedDict
+
+
+def _conv_blocks(spec, prefix, C, k, n_blocks, n_in_block, out_dims, post_k, causal):
+    """ConvBlocks / CausalConvBlocks (modules/commons/conv.py:84-125, :181-264).
+    Sequential indices: non-causal [norm=0, conv=1, scale=2, act=3, conv1x1=4];
+    causal [norm=0, pad=1, conv=2, scale=3, act=4, conv1x1=5]."""
+    ic, i1 = (2, 5) if causal else (1, 4)
+    for b in range(n_blocks):
+        for j in range(n_in_block):
+            p = f"{prefix}.res_blocks.{b}.blocks.{j}"
+            spec[f"{p}.0.weight"] = (C,)
+            spec[f"{p}.0.bias"] = (C,)
+            spec[f"{p}.{ic}.weight"] = (2 * C, C, k)
+            spec[f"{p}.{ic}.bias"] = (2 * C,)
+            spec[f"{p}.{i1}.weight"] = (C, 2 * C, 1)
+            spec[f"{p}.{i1}.bias"] = (C,)
+    spec[f"{prefix}.last_norm.weight"] = (C,)
+    spec[f"{prefix}.last_norm.bias"] = (C,)
+    pn = f"{prefix}.post_net1.1" if causal else f"{prefix}.post_net1"
+    spec[f"{pn}.weight"] = (out_dims, C, post_k)
+    spec[f"{pn}.bias"] = (out_dims,)
+
+
+def _pitch_predictor(spec, prefix, idim, n_chans, n_layers, k, odim=2):
+    """PitchPredictor (modules/commons/nar_tts_modules.py:103-146)."""
+    for i in range(n_layers):
+        cin = idim if i == 0 else n_chans
+        spec[f"{prefix}.conv.{i}.0.conv.weight"] = (n_chans, cin, k)
+        spec[f"{prefix}.conv.{i}.0.conv.bias"] = (n_chans,)
+    spec[f"{prefix}.post_ln.weight"] = (n_chans,)
+    spec[f"{prefix}.post_ln.bias"] = (n_chans,)
+    spec[f"{prefix}.linear.weight"] = (odim, n_chans)
+    spec[f"{prefix}.linear.bias"] = (odim,)
+
+
+CONAN_BUFFERS = ("prosody_extractor.vqvae.data_initialized", "prosody_extractor.vqvae.embedding",
+                 "prosody_extractor.vqvae.ema_count", "prosody_extractor.vqvae.ema_weight",
+                 "embed_positions._float_tensor")
+
+
+def conan_spec(hp):
+    H = hp["hidden_size"]
+    mel = hp["audio_num_mel_bins"]
+    s = OrderedDict()
+    # FastSpeech.__init__ (fs.py:56-76)
+    _conv_blocks(s, "decoder", H, hp["dec_kernel_size"], len(hp["dec_dilations"]),
+                 hp["layers_in_block"], H, hp.get("dec_post_net_kernel", 3), causal=True)
+    s["mel_out.weight"] = (mel, H)
+    s["mel_out.bias"] = (mel,)
+    s["pitch_embed.weight"] = (300, H)
+    ph = hp["predictor_hidden"] if hp["predictor_hidden"] > 0 else H
+    _pitch_predictor(s, "pitch_predictor", H, ph, 5, hp["predictor_kernel"])
+    # Conan.__init__ (Conan.py:51-113)
+    s["content_embedding.weight"] = (102, H)
+    s["content_proj.0.conv.weight"] = (H, H, hp["kernel_size"])
+    s["content_proj.0.conv.bias"] = (H,)
+    s["global_conv_in.weight"] = (H, 80, 1)
+    s["global_conv_in.bias"] = (H,)
+    _conv_blocks(s, "global_encoder", H, 31, 5, 2, H, 3, causal=False)
+    # LocalStyleAdaptor (prosody_util.py:173-181)
+    _conv_blocks(s, "prosody_extractor.encoder", 80, 5, 5, 2, H, 3, causal=False)
+    s["prosody_extractor.vqvae.data_initialized"] = (1,)
+    s["prosody_extractor.vqvae.embedding"] = (hp["nVQ"], H)
+    s["prosody_extractor.vqvae.ema_count"] = (hp["nVQ"],)
+    s["prosody_extractor.vqvae.ema_weight"] = (hp["nVQ"], H)
+    for name, n_out in (("in_layers", None), ("res_skip_layers", None)):
+        for i in range(4):
+            if name == "in_layers":
+                co, k = 160, 3
+            else:
+                co, k = (160 if i < 3 else 80), 1
+            p = f"prosody_extractor.wavenet.{name}.{i}"
+            s[f"{p}.bias"] = (co,)
+            s[f"{p}.weight_g"] = (co, 1, 1)
+            s[f"{p}.weight_v"] = (co, 80, k)
+    s["l1.weight"] = (H, 2 * H)
+    s["l1.bias"] = (H,)
+    for l in range(2):
+        p = f"align.layers.{l}"
+        s[f"{p}.multihead_attn.in_proj_weight"] = (3 * H, H)
+        s[f"{p}.multihead_attn.in_proj_bias"] = (3 * H,)
+        s[f"{p}.multihead_attn.out_proj.weight"] = (H, H)
+        s[f"{p}.multihead_attn.out_proj.bias"] = (H,)
+        s[f"{p}.linear1.weight"] = (2048, H)
+        s[f"{p}.linear1.bias"] = (2048,)
+        s[f"{p}.norm1.weight"] = (H,)
+        s[f"{p}.norm1.bias"] = (H,)
+        s[f"{p}.linear2.weight"] = (H, 2048)
+        s[f"{p}.linear2.bias"] = (H,)
+        s[f"{p}.norm2.weight"] = (H,)
+        s[f"{p}.norm2.bias"] = (H,)
+    s["embed_positions._float_tensor"] = (1,)
+    _pitch_predictor(s, "uv_predictor", H, 128, 5, hp["predictor_kernel"])
+    return s
+
+
+def hifigan_spec(hp):
+    """HifiGanGenerator (hifigan_causal.py:273-312), upsample == 'shuffle', resblock == '1'."""
+    s = OrderedDict()
+
+    def wn(prefix, co, ci, k):
+        s[f"{prefix}.bias"] = (co,)
+        s[f"{prefix}.weight_g"] = (co, 1, 1)
+        s[f"{prefix}.weight_v"] = (co, ci, k)
+
+    C = hp.get("upsample_initial_channel", 512)
+    wn("conv_pre.conv", C, hp.get("num_mels", 80), 7)
+    ch = C
+    ups, rbs = [], []
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        out = ch // 2
+        ups.append((f"ups.{i}.conv.conv", out * u, ch, k))
+        for j, (rk, rd) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            rbs.append((len(rbs), out, rk, rd))
+        ch = out
+    for (p, co, ci, k) in ups:
+        wn(p, co, ci, k)
+    for (idx, c, rk, rd) in rbs:
+        for name in ("convs1", "convs2"):
+            for d in range(len(rd)):
+                wn(f"resblocks.{idx}.{name}.{d}.conv", c, c, rk)
+    wn("conv_post.conv", 1, ch, 7)
+    return s
+
+
+def emformer_spec(hp, input_dim=80, output_dim=None, ffn_dim=2048):
+    """EmformerDistillModel (modules/Emformer/emformer.py:7-31) over
+    torchaudio.models.Emformer (torchaudio 2.5.1 models/emformer.py)."""
+    if output_dim is None:
+        output_dim = hp.get("emformer_output_dim", 768)
+    D = input_dim
+    s = OrderedDict()
+    for i in range(hp["emformer_layers"]):
+        p = f"emformer.emformer_layers.{i}"
+        s[f"{p}.attention.emb_to_key_value.weight"] = (2 * D, D)
+        s[f"{p}.attention.emb_to_key_value.bias"] = (2 * D,)
+        s[f"{p}.attention.emb_to_query.weight"] = (D, D)
+        s[f"{p}.attention.emb_to_query.bias"] = (D,)
+        s[f"{p}.attention.out_proj.weight"] = (D, D)
+        s[f"{p}.attention.out_proj.bias"] = (D,)
+        s[f"{p}.pos_ff.0.weight"] = (D,)
+        s[f"{p}.pos_ff.0.bias"] = (D,)
+        s[f"{p}.pos_ff.1.weight"] = (ffn_dim, D)
+        s[f"{p}.pos_ff.1.bias"] = (ffn_dim,)
+        s[f"{p}.pos_ff.4.weight"] = (D, ffn_dim)
+        s[f"{p}.pos_ff.4.bias"] = (D,)
+        s[f"{p}.layer_norm_input.weight"] = (D,)
+        s[f"{p}.layer_norm_input.bias"] = (D,)
+        s[f"{p}.layer_norm_output.weight"] = (D,)
+        s[f"{p}.layer_norm_output.bias"] = (D,)
+    if output_dim != input_dim:
+        s["proj.weight"] = (output_dim, D)
+        s["proj.bias"] = (output_dim,)
+    return s

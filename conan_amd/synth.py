@@ -1,0 +1,129 @@
+"""Synthetic ("random-init") weights and inputs, generated procedurally by
+state_dict key name so that the container that makes the golden fixtures, the
+CPU test-suite and the GPU box all regenerate bit-identical tensors without
+shipping ~340 MB of weights.
+
+numpy's PCG64 stream for a given seed sequence is platform independent, so
+`fill(key, shape, seed)` is a pure function of its arguments.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+from . import specs
+
+
+def _rng(seed, key):
+    return np.random.default_rng([int(seed) & 0x7FFFFFFF, zlib.crc32(key.encode("utf-8"))])
+
+
+def _is_norm_weight(key, shape):
+    if len(shape) != 1 or not key.endswith(".weight"):
+        return False
+    return True  # every 1-D '.weight' on this path is a LayerNorm gain
+
+
+# gain multipliers for the N(0, gain^2 / fan_in) fill of conv / linear weights, chosen so that
+# random-init activations stay O(1) through the residual stacks (checked in tests/test_synth.py).
+_GAINS = (
+    ("convs2.", 0.5),                 # HiFi-GAN ResBlock1 second conv (residual branch)
+    ("conv_post.", 0.5),
+    ("res_skip_layers", 0.7),
+    ("uv_predictor.linear", 1.0),
+    ("pos_ff.4", 0.5),
+    ("linear2", 0.5),
+)
+
+
+def fill(key, shape, seed=0):
+    """Deterministic value of state_dict entry `key` (float32 ndarray of `shape`)."""
+    shape = tuple(int(s) for s in shape)
+    r = _rng(seed, key)
+    if key.endswith("_float_tensor"):
+        return np.zeros(shape, np.float32)
+    if key.endswith("data_initialized"):
+        return np.ones(shape, np.float32)
+    if key.endswith("ema_count"):
+        return np.ones(shape, np.float32)
+    if key.endswith("vqvae.embedding") or key.endswith("vqvae.ema_weight"):
+        # both buffers hold the same codebook in a trained checkpoint's eval path
+        r = _rng(seed, key.rsplit(".", 1)[0] + ".embedding")
+        return (0.5 * r.standard_normal(shape)).astype(np.float32)
+    if key.endswith("weight_g"):
+        # positive per-channel gains; value = ||v|| * U(0.8, 1.2) needs v: handled in state_dict()
+        raise KeyError("weight_g is derived from weight_v; use synth.state_dict()")
+    if key.endswith(".bias") or key.endswith("in_proj_bias"):
+        b = (0.05 * r.standard_normal(shape)).astype(np.float32)
+        if key == "uv_predictor.linear.bias":
+            b = np.array([0.0, 7.5], np.float32)  # f0 = 2**x around 180 Hz (pitch/utils.py:71-82)
+        return b
+    if _is_norm_weight(key, shape):
+        return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
+    if key in ("content_embedding.weight", "pitch_embed.weight"):
+        w = (r.standard_normal(shape)).astype(np.float32)
+        if key == "pitch_embed.weight":
+            w[0] = 0.0  # padding_idx=0 (modules/tts/fs.py:72)
+        return w
+    # conv / linear weight
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+    gain = 1.0
+    for pat, g in _GAINS:
+        if pat in key:
+            gain = g
+            break
+    return (gain / np.sqrt(fan_in) * r.standard_normal(shape)).astype(np.float32)
+
+
+def state_dict(spec, seed=0):
+    """OrderedDict key -> float32 ndarray for a spec from conan_amd.specs."""
+    sd = OrderedDict()
+    for key, shape in spec.items():
+        if key.endswith("weight_g"):
+            continue
+        sd[key] = fill(key, shape, seed)
+    for key, shape in spec.items():
+        if key.endswith("weight_g"):
+            v = sd[key[:-1] + "v"]
+            nrm = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(1, v.ndim)), keepdims=True))
+            u = _rng(seed, key).uniform(0.8, 1.2, size=nrm.shape)
+            sd[key] = (nrm * u).astype(np.float32).reshape(shape)
+    return OrderedDict((k, sd[k]) for k in spec.keys())
+
+
+def conan_state_dict(hp, seed=0):
+    return state_dict(specs.conan_spec(hp), seed)
+
+
+def hifigan_state_dict(hp, seed=0):
+    return state_dict(specs.hifigan_spec(hp), seed)
+
+
+def emformer_state_dict(hp, seed=0, output_dim=100):
+    return state_dict(specs.emformer_spec(hp, 80, output_dim), seed)
+
+
+def mel(n_frames, seed, n_streams=1):
+    """Synthetic log-mel `[n_streams, n_frames, 80]`: clip(1.2*N(0,1) - 2.5, -6, 1.5)
+    (range of inference/Conan.py:70)."""
+    out = np.empty((n_streams, n_frames, 80), np.float32)
+    for s in range(n_streams):
+        r = np.random.default_rng(int(seed) + s)
+        out[s] = np.clip(1.2 * r.standard_normal((n_frames, 80)) - 2.5, -6.0, 1.5)
+    return out
+
+
+def src_mel(n_frames=151, n_streams=1):
+    return mel(n_frames, 1234, n_streams)
+
+
+def ref_mel(n_frames=151, n_streams=1):
+    return mel(n_frames, 4321, n_streams)
+
+
+def codes(n_frames, n_streams=1, seed=7, silent_token=57):
+    """Synthetic HuBERT-like content codes in [0, 100), with a few silent tokens."""
+    r = np.random.default_rng(seed)
+    c = r.integers(0, 100, size=(n_streams, n_frames), dtype=np.int64)
+    c[:, ::17] = silent_token
+    return c
