@@ -1,0 +1,223 @@
+// extern "C" surface of libconan_hip.so (include/conan_hip.h).
+#include "streams.h"
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guarded(F&& f) {
+  try {
+    f();
+    return CONAN_OK;
+  } catch (const ch::Error& e) {
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return CONAN_ERR_INVALID;
+  }
+}
+
+static void validate_cfg(const conan_cfg& c) {
+  if (c.abi_version != CONAN_HIP_ABI_VERSION) throw Error(CONAN_ERR_INVALID, "conan_cfg.abi_version mismatch");
+  if (c.models & CONAN_MODEL_HIFIGAN) {
+    if (c.voc_num_ups < 1 || c.voc_num_ups > CONAN_MAX_UPS) throw Error(CONAN_ERR_INVALID, "voc_num_ups");
+    if (c.voc_num_resblocks < 1 || c.voc_num_resblocks > 3) throw Error(CONAN_ERR_UNSUPPORTED, "1..3 resblock branches supported");
+    if (c.voc_rb_num_dil < 1 || c.voc_rb_num_dil > CONAN_MAX_DILATIONS) throw Error(CONAN_ERR_INVALID, "voc_rb_num_dil");
+    int ch_ = c.voc_initial_channel;
+    for (int i = 0; i < c.voc_num_ups; ++i) { ch_ /= 2; if (ch_ < 4 || ch_ % 4) throw Error(CONAN_ERR_UNSUPPORTED, "vocoder channel ladder must stay a multiple of 4"); }
+    if (c.num_mels % 4) throw Error(CONAN_ERR_UNSUPPORTED, "num_mels must be a multiple of 4");
+  }
+  if (c.models & CONAN_MODEL_EMFORMER) {
+    if (c.emf_input_dim % c.emf_heads || c.emf_input_dim / c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer head_dim must be <= 16");
+    if (c.emf_input_dim % 4 || c.emf_input_dim > 512) throw Error(CONAN_ERR_UNSUPPORTED, "emformer input_dim");
+    if (c.emf_segment < 1 || c.emf_right_context < 0) throw Error(CONAN_ERR_INVALID, "emformer segment/right context");
+  }
+  if (c.models & CONAN_MODEL_CONAN) {
+    if (c.hidden_size % 8 || c.hidden_size > 512) throw Error(CONAN_ERR_UNSUPPORTED, "hidden_size must be a multiple of 8 and <= 512");
+    if (c.dec_num_blocks < 1 || c.dec_num_blocks > CONAN_MAX_DEC_BLOCKS) throw Error(CONAN_ERR_INVALID, "dec_num_blocks");
+    if (c.nvq < 1) throw Error(CONAN_ERR_INVALID, "nvq");
+  }
+}
+
+extern "C" {
+
+const char* conan_last_error(void) { return g_err.c_str(); }
+int conan_abi_version(void) { return CONAN_HIP_ABI_VERSION; }
+
+int conan_ctx_create(int device, const conan_cfg* cfg, conan_ctx** out) {
+  return guarded([&] {
+    if (!cfg || !out) throw Error(CONAN_ERR_INVALID, "null argument");
+    validate_cfg(*cfg);
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) throw Error(CONAN_ERR_HIP, "no such HIP device (libconan_hip has no CPU fallback)");
+    HIP_CHECK(hipSetDevice(device));
+    conan_ctx* c = new conan_ctx();
+    c->device = device;
+    c->cfg = *cfg;
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int hop = 1;
+    for (int i = 0; i < cfg->voc_num_ups; ++i) hop *= cfg->voc_up_rates[i];
+    c->hop = hop;
+    *out = c;
+  });
+}
+
+int conan_ctx_destroy(conan_ctx* ctx) {
+  return guarded([&] { delete ctx; });
+}
+
+int conan_ctx_load_tensor(conan_ctx* ctx, const char* key, const float* host, const int64_t* shape, int ndim) {
+  int known = 1;
+  int rc = guarded([&] {
+    if (!ctx || !key || !host || ndim < 0 || ndim > 4) throw Error(CONAN_ERR_INVALID, "bad argument");
+    if (ctx->finalized) throw Error(CONAN_ERR_STATE, "context already finalized");
+    std::string k(key);
+    if (k.rfind("emformer.", 0) != 0 && k.rfind("conan.", 0) != 0 && k.rfind("hifigan.", 0) != 0) { known = 0; return; }
+    ch::HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    int64_t n = t.numel();
+    if (n < 0 || n > (int64_t)1 << 31) throw Error(CONAN_ERR_SHAPE, "tensor too large");
+    t.data.assign(host, host + n);
+    ctx->raw[k] = std::move(t);
+  });
+  if (rc != CONAN_OK) return rc;
+  return known ? 0 : 1;
+}
+
+int conan_ctx_finalize(conan_ctx* ctx) {
+  return guarded([&] {
+    if (!ctx) throw Error(CONAN_ERR_INVALID, "null ctx");
+    if (ctx->finalized) return;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->cfg.models & CONAN_MODEL_HIFIGAN) ctx->finalize_hifigan();
+    if (ctx->cfg.models & CONAN_MODEL_EMFORMER) ctx->finalize_emformer();
+    if (ctx->cfg.models & CONAN_MODEL_CONAN) ctx->finalize_conan();
+    ctx->raw.clear();
+    ctx->finalized = true;
+  });
+}
+
+int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, conan_streams** out) {
+  return guarded([&] {
+    if (!ctx || !out) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!ctx->finalized) throw Error(CONAN_ERR_STATE, "conan_ctx_finalize must run before conan_streams_create");
+    if (max_slots < 1 || max_frames < 1) throw Error(CONAN_ERR_INVALID, "max_slots / max_frames");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    conan_streams* s = new conan_streams();
+    try {
+      s->ctx = ctx; s->max_slots = max_slots; s->max_frames = std::max(max_frames, ctx->cfg.emf_segment); s->max_ref = std::max(4, max_ref_frames);
+      s->d_slots = (int*)s->alloc(max_slots); s->d_ident = (int*)s->alloc(max_slots); s->d_zero = (int*)s->alloc(max_slots);
+      s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
+      s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
+      s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
+      std::vector<int> id(max_slots);
+      for (int i = 0; i < max_slots; ++i) id[i] = i;
+      HIP_CHECK(hipMemcpy(s->d_ident, id.data(), max_slots * sizeof(int), hipMemcpyHostToDevice));
+      if (ctx->cfg.models & CONAN_MODEL_HIFIGAN) s->build_vocoder();
+      if (ctx->cfg.models & CONAN_MODEL_EMFORMER) s->build_emformer();
+      if (ctx->cfg.models & CONAN_MODEL_CONAN) s->build_decoder();
+    } catch (...) { delete s; throw; }
+    *out = s;
+  });
+}
+
+int conan_streams_destroy(conan_streams* s) {
+  return guarded([&] { if (s) { (void)hipDeviceSynchronize(); delete s; } });
+}
+
+int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which, void* stream) {
+  return guarded([&] {
+    if (!s || !slots) throw Error(CONAN_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->set_slots(slots, n, st);
+    const int models = s->ctx->cfg.models & which;
+    auto zero = [&](std::vector<std::pair<float*, long long>>& v, int* pos) {
+      for (auto& b : v) ck::launch_zero_slots(b.first, b.second, b.second, s->d_slots, n, st);
+      ck::launch_fill_int(pos, s->d_slots, n, 0, st);
+    };
+    if (models & CONAN_MODEL_HIFIGAN) zero(s->voc_state, s->pos_voc);
+    if (models & CONAN_MODEL_EMFORMER) zero(s->emf_state, s->pos_emf);
+    if (models & CONAN_MODEL_CONAN) zero(s->dec_state, s->pos_dec);
+  });
+}
+
+int conan_set_reference(conan_streams* s, const int32_t* slots, int n, const float* ref_mel_dev, const int32_t* ref_len,
+                        int max_len, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !ref_mel_dev || !ref_len) throw Error(CONAN_ERR_INVALID, "null argument (the reference raises ValueError when ref is None)");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
+    if (n < 1 || n > s->max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->set_reference(slots, n, ref_mel_dev, ref_len, max_len, (hipStream_t)stream);
+  });
+}
+
+int conan_emformer_step(conan_streams* s, const int32_t* slots, int n, const float* chunk_dev, float* out_dev, float* logits_dev,
+                        int32_t* codes_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !chunk_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_EMFORMER)) throw Error(CONAN_ERR_STATE, "context holds no Emformer model");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->set_slots(slots, n, (hipStream_t)stream);
+    s->emformer_step(n, chunk_dev, out_dev, logits_dev, codes_dev, (hipStream_t)stream);
+  });
+}
+
+int conan_decoder_step(conan_streams* s, const int32_t* slots, int n, int frames, const int32_t* codes_dev, float* mel_out_dev,
+                       float* uv_pred_dev, float* f0_dev, int32_t* bins_dev, float* decoder_inp_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !codes_dev || !mel_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
+    if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->set_slots(slots, n, (hipStream_t)stream);
+    s->decoder_step(n, frames, codes_dev, mel_out_dev, uv_pred_dev, f0_dev, bins_dev, decoder_inp_dev, (hipStream_t)stream);
+  });
+}
+
+int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames, const float* mel_dev, float* wav_out_dev,
+                       float* pre_tanh_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !mel_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_HIFIGAN)) throw Error(CONAN_ERR_STATE, "context holds no HiFi-GAN model");
+    if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->set_slots(slots, n, (hipStream_t)stream);
+    s->hifigan_step(n, frames, mel_dev, wav_out_dev, pre_tanh_dev, (hipStream_t)stream);
+  });
+}
+
+int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const float* mel_chunk_dev, int32_t* codes_dev,
+               float* mel_out_dev, float* wav_out_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !mel_chunk_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    const int all = CONAN_MODEL_EMFORMER | CONAN_MODEL_CONAN | CONAN_MODEL_HIFIGAN;
+    if ((s->ctx->cfg.models & all) != all) throw Error(CONAN_ERR_STATE, "conan_step needs all three models in the context");
+    const int seg = s->ctx->cfg.emf_segment;
+    if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->set_slots(slots, n, st);
+    int* codes_seg = codes_dev ? codes_dev : s->d_codes;
+    s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, st);
+    const int* codes_emit = codes_seg;
+    if (emit != seg && n > 1) {
+      int* compact = s->d_codes + (size_t)s->max_slots * s->max_frames;
+      ck::launch_copy_int_rows(compact, codes_seg, n, emit, seg, st);
+      codes_emit = compact;
+    }
+    float* mel = mel_out_dev ? mel_out_dev : s->c_mel.base;
+    s->decoder_step(n, emit, codes_emit, mel, nullptr, nullptr, nullptr, nullptr, st);
+    s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, st);
+  });
+}
+
+int conan_hop_size(const conan_ctx* ctx) { return ctx ? ctx->hop : 0; }
+int64_t conan_ctx_weight_bytes(const conan_ctx* ctx) { return ctx ? ctx->weight_bytes : 0; }
+int64_t conan_streams_state_bytes(const conan_streams* s) { return s ? s->state_bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+// conan_ctx: weight ingestion (state_dict keys of the reference), weight-norm folding and repacking
+// into the conv_mfma layout.  Host logic only; runs once at start-up.
+#include "host_common.h"
+
+namespace ch {
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw Error(CONAN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+}  // namespace ch
+
+using ch::Error;
+using ch::HostTensor;
+using ch::PackedConv;
+
+conan_ctx::~conan_ctx() {
+  for (void* p : allocs) (void)hipFree(p);
+}
+
+float* conan_ctx::dev_alloc(size_t floats, bool zero) {
+  void* p = nullptr;
+  if (floats == 0) floats = 4;
+  HIP_CHECK(hipMalloc(&p, floats * sizeof(float)));
+  if (zero) HIP_CHECK(hipMemset(p, 0, floats * sizeof(float)));
+  allocs.push_back(p);
+  return (float*)p;
+}
+
+float* conan_ctx::upload(const std::vector<float>& v) {
+  float* d = dev_alloc(v.size(), false);
+  HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  weight_bytes += (int64_t)v.size() * 4;
+  return d;
+}
+
+const HostTensor& conan_ctx::get(const std::string& key) const {
+  auto it = raw.find(key);
+  if (it == raw.end()) throw Error(CONAN_ERR_MISSING, "state_dict tensor not loaded: " + key);
+  return it->second;
+}
+
+const PackedConv& conan_ctx::conv(const std::string& name) const {
+  auto it = convs.find(name);
+  if (it == convs.end()) throw Error(CONAN_ERR_STATE, "packed conv missing: " + name);
+  return it->second;
+}
+
+float* conan_ctx::vec(const std::string& name) const {
+  auto it = vecs.find(name);
+  if (it == vecs.end()) throw Error(CONAN_ERR_STATE, "device vector missing: " + name);
+  return it->second;
+}
+
+// W is PyTorch Conv1d layout [Cout][Cin][k] (Linear: k = 1).  Packed: [k][Cin_pad/4][Cout_pad][4].
+// shuffle_r > 1: output channel c*r + j of the reference (hifigan_causal.py:186-188) is stored at
+// packed column j*(Cout/r) + c, which makes the pixel shuffle a plain row remap of the store.
+void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, const float* bias, int Cout, int Cin,
+                          int k, int shuffle_r) {
+  if (Cin % 4 != 0) throw Error(CONAN_ERR_UNSUPPORTED, "conv input channels must be a multiple of 4: " + name);
+  PackedConv pc;
+  pc.Cin = Cin; pc.Cout = Cout; pc.k = k; pc.shuffle_r = shuffle_r;
+  pc.Cin_pad = ch::round_up(Cin, 32);
+  pc.Cout_pad = ch::round_up(Cout, 64);
+  const int Cq = Cout / shuffle_r;
+  std::vector<float> P((size_t)k * (pc.Cin_pad / 4) * pc.Cout_pad * 4, 0.f);
+  std::vector<float> B((size_t)pc.Cout_pad, 0.f);
+  for (int co = 0; co < Cout; ++co) {
+    int col = co;
+    if (shuffle_r > 1) { int c = co / shuffle_r, j = co % shuffle_r; col = j * Cq + c; }
+    if (bias) B[col] = bias[co];
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int j = 0; j < k; ++j)
+        P[(((size_t)j * (pc.Cin_pad / 4) + ci / 4) * pc.Cout_pad + col) * 4 + (ci & 3)] = W[((size_t)co * Cin + ci) * k + j];
+  }
+  pc.w = upload(P);
+  pc.bias = upload(B);
+  convs[name] = pc;
+}
+
+void conan_ctx::pack_from_keys(const std::string& name, const std::string& wkey, const std::string& bkey, int shuffle_r) {
+  const HostTensor& w = get(wkey);
+  if (w.shape.size() != 2 && w.shape.size() != 3) throw Error(CONAN_ERR_SHAPE, "bad weight rank: " + wkey);
+  int Cout = (int)w.shape[0], Cin = (int)w.shape[1], k = w.shape.size() == 3 ? (int)w.shape[2] : 1;
+  const float* b = nullptr;
+  if (!bkey.empty()) { const HostTensor& bt = get(bkey); if (bt.numel() != Cout) throw Error(CONAN_ERR_SHAPE, "bad bias: " + bkey); b = bt.data.data(); }
+  pack_conv(name, w.data, b, Cout, Cin, k, shuffle_r);
+}
+
+// weight_norm fold: w = g * v / ||v||_2 per output channel (torch._weight_norm(v, g, 0));
+// accepts an already-folded '<prefix>.weight' (remove_weight_norm checkpoints, hifigan_causal.py:335).
+void conan_ctx::pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r) {
+  if (has(prefix + ".weight")) { pack_from_keys(name, prefix + ".weight", prefix + ".bias", shuffle_r); return; }
+  const HostTensor& v = get(prefix + ".weight_v");
+  const HostTensor& g = get(prefix + ".weight_g");
+  const HostTensor& b = get(prefix + ".bias");
+  int Cout = (int)v.shape[0], Cin = (int)v.shape[1], k = (int)v.shape[2];
+  if (g.numel() != Cout || b.numel() != Cout) throw Error(CONAN_ERR_SHAPE, "bad weight_g/bias: " + prefix);
+  std::vector<float> W(v.data.size());
+  const size_t per = (size_t)Cin * k;
+  for (int co = 0; co < Cout; ++co) {
+    // norm accumulated in fp32 like torch's norm kernel would round to; double accumulate then round keeps
+    // the fold within 1 ulp of torch._weight_norm
+    double s = 0.0;
+    for (size_t e = 0; e < per; ++e) { double x = v.data[co * per + e]; s += x * x; }
+    float nrm = (float)std::sqrt(s);
+    float gg = g.data[co];
+    for (size_t e = 0; e < per; ++e) W[co * per + e] = v.data[co * per + e] * (gg / nrm);
+  }
+  pack_conv(name, W, b.data.data(), Cout, Cin, k, shuffle_r);
+}
+
+void conan_ctx::upload_vec(const std::string& name, const std::string& key) { vecs[name] = upload(get(key).data); }
+
+void conan_ctx::finalize_hifigan() {
+  const conan_cfg& c = cfg;
+  const std::string P = "hifigan.";
+  pack_weightnorm("voc.conv_pre", P + "conv_pre.conv");
+  int ridx = 0;
+  for (int i = 0; i < c.voc_num_ups; ++i) {
+    pack_weightnorm("voc.ups." + std::to_string(i), P + "ups." + std::to_string(i) + ".conv.conv", c.voc_up_rates[i]);
+    for (int b = 0; b < c.voc_num_resblocks; ++b, ++ridx)
+      for (int d = 0; d < c.voc_rb_num_dil; ++d) {
+        std::string rb = "resblocks." + std::to_string(ridx);
+        pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
+        pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
+      }
+  }
+  pack_weightnorm("voc.conv_post", P + "conv_post.conv");
+}
+
+void conan_ctx::finalize_emformer() {
+  const conan_cfg& c = cfg;
+  for (int l = 0; l < c.emf_layers; ++l) {
+    std::string p = "emformer.emformer.emformer_layers." + std::to_string(l);
+    std::string n = "emf." + std::to_string(l);
+    pack_from_keys(n + ".q", p + ".attention.emb_to_query.weight", p + ".attention.emb_to_query.bias");
+    pack_from_keys(n + ".kv", p + ".attention.emb_to_key_value.weight", p + ".attention.emb_to_key_value.bias");
+    pack_from_keys(n + ".out", p + ".attention.out_proj.weight", p + ".attention.out_proj.bias");
+    pack_from_keys(n + ".ff1", p + ".pos_ff.1.weight", p + ".pos_ff.1.bias");
+    pack_from_keys(n + ".ff2", p + ".pos_ff.4.weight", p + ".pos_ff.4.bias");
+    upload_vec(n + ".ln_in.g", p + ".layer_norm_input.weight");
+    upload_vec(n + ".ln_in.b", p + ".layer_norm_input.bias");
+    upload_vec(n + ".ln_ff.g", p + ".pos_ff.0.weight");
+    upload_vec(n + ".ln_ff.b", p + ".pos_ff.0.bias");
+    upload_vec(n + ".ln_out.g", p + ".layer_norm_output.weight");
+    upload_vec(n + ".ln_out.b", p + ".layer_norm_output.bias");
+  }
+  if (c.emf_output_dim != c.emf_input_dim) pack_from_keys("emf.proj", "emformer.proj.weight", "emformer.proj.bias");
+}
+
+void conan_ctx::finalize_conan() {
+  const conan_cfg& c = cfg;
+  const std::string P = "conan.";
+  const int H = c.hidden_size;
+  upload_vec("conan.content_embedding", P + "content_embedding.weight");
+  upload_vec("conan.pitch_embed", P + "pitch_embed.weight");
+  pack_from_keys("conan.content_proj", P + "content_proj.0.conv.weight", P + "content_proj.0.conv.bias");
+  // aligner: in_proj rows [0,H) = Wq, [H,3H) = Wk|Wv
+  for (int l = 0; l < 2; ++l) {
+    std::string p = P + "align.layers." + std::to_string(l);
+    std::string n = "conan.align." + std::to_string(l);
+    const HostTensor& w = get(p + ".multihead_attn.in_proj_weight");
+    const HostTensor& b = get(p + ".multihead_attn.in_proj_bias");
+    if (w.shape.size() != 2 || w.shape[0] != 3 * H || w.shape[1] != H) throw Error(CONAN_ERR_SHAPE, "in_proj_weight");
+    std::vector<float> wq(w.data.begin(), w.data.begin() + (size_t)H * H);
+    std::vector<float> wkv(w.data.begin() + (size_t)H * H, w.data.end());
+    pack_conv(n + ".q", wq, b.data.data(), H, H, 1);
+    pack_conv(n + ".kv", wkv, b.data.data() + H, 2 * H, H, 1);
+    pack_from_keys(n + ".out", p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias");
+    pack_from_keys(n + ".ff1", p + ".linear1.weight", p + ".linear1.bias");
+    pack_from_keys(n + ".ff2", p + ".linear2.weight", p + ".linear2.bias");
+    upload_vec(n + ".norm1.g", p + ".norm1.weight"); upload_vec(n + ".norm1.b", p + ".norm1.bias");
+    upload_vec(n + ".norm2.g", p + ".norm2.weight"); upload_vec(n + ".norm2.b", p + ".norm2.bias");
+  }
+  // uv predictor
+  for (int i = 0; i < 5; ++i) {
+    std::string p = P + "uv_predictor.conv." + std::to_string(i) + ".0.conv";
+    pack_from_keys("conan.uv." + std::to_string(i), p + ".weight", p + ".bias");
+  }
+  upload_vec("conan.uv.ln.g", P + "uv_predictor.post_ln.weight");
+  upload_vec("conan.uv.ln.b", P + "uv_predictor.post_ln.bias");
+  upload_vec("conan.uv.lin.w", P + "uv_predictor.linear.weight");
+  upload_vec("conan.uv.lin.b", P + "uv_predictor.linear.bias");
+  // decoder (CausalConvBlocks)
+  auto conv_blocks = [&](const std::string& src, const std::string& dst, int nblocks, int nin, bool causal) {
+    const char* ic = causal ? ".2" : ".1";
+    const char* i1 = causal ? ".5" : ".4";
+    for (int b = 0; b < nblocks; ++b)
+      for (int j = 0; j < nin; ++j) {
+        std::string p = src + ".res_blocks." + std::to_string(b) + ".blocks." + std::to_string(j);
+        std::string n = dst + "." + std::to_string(b) + "." + std::to_string(j);
+        upload_vec(n + ".ln.g", p + ".0.weight"); upload_vec(n + ".ln.b", p + ".0.bias");
+        pack_from_keys(n + ".c1", p + ic + ".weight", p + ic + ".bias");
+        pack_from_keys(n + ".c2", p + i1 + ".weight", p + i1 + ".bias");
+      }
+    upload_vec(dst + ".last.g", src + ".last_norm.weight"); upload_vec(dst + ".last.b", src + ".last_norm.bias");
+    std::string pn = causal ? src + ".post_net1.1" : src + ".post_net1";
+    pack_from_keys(dst + ".post", pn + ".weight", pn + ".bias");
+  };
+  conv_blocks(P + "decoder", "conan.dec", c.dec_num_blocks, c.dec_layers_in_block, true);
+  pack_from_keys("conan.mel_out", P + "mel_out.weight", P + "mel_out.bias");
+  // style pass
+  pack_from_keys("conan.global_conv_in", P + "global_conv_in.weight", P + "global_conv_in.bias");
+  conv_blocks(P + "global_encoder", "conan.genc", 5, 2, false);
+  conv_blocks(P + "prosody_extractor.encoder", "conan.penc", 5, 2, false);
+  for (int i = 0; i < 4; ++i) {
+    pack_weightnorm("conan.wn.in." + std::to_string(i), P + "prosody_extractor.wavenet.in_layers." + std::to_string(i));
+    pack_weightnorm("conan.wn.rs." + std::to_string(i), P + "prosody_extractor.wavenet.res_skip_layers." + std::to_string(i));
+  }
+  {
+    const HostTensor& e = get(P + "prosody_extractor.vqvae.embedding");
+    if (e.shape.size() != 2 || e.shape[1] != H) throw Error(CONAN_ERR_SHAPE, "vqvae.embedding");
+    const int M = (int)e.shape[0];
+    vecs["conan.vq.emb"] = upload(e.data);
+    pack_conv("conan.vq.dot", e.data, nullptr, M, H, 1);      // dots[s][j] = x . e_j
+    std::vector<float> e2(M);
+    for (int j = 0; j < M; ++j) { float s = 0.f; for (int d = 0; d < H; ++d) { float x = e.data[(size_t)j * H + d]; s += x * x; } e2[j] = s; }
+    vecs["conan.vq.e2"] = upload(e2);
+  }
+  pack_from_keys("conan.l1", P + "l1.weight", P + "l1.bias");
+  {
+    // SinusoidalPositionalEmbedding.get_embedding (modules/commons/transformer.py:30-47), fp32 steps
+    const int n = 2002, half = H / 2;
+    std::vector<float> tab((size_t)n * H, 0.f);
+    const float e = (float)(std::log(10000.0) / (half - 1));
+    for (int p = 1; p < n; ++p)
+      for (int d = 0; d < half; ++d) {
+        float f = std::exp((float)d * -e);
+        float a = (float)p * f;
+        tab[(size_t)p * H + d] = std::sin(a);
+        tab[(size_t)p * H + half + d] = std::cos(a);
+      }
+    vecs["conan.postable"] = upload(tab);
+  }
+}

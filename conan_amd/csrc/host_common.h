@@ -1,0 +1,97 @@
+// Host-side runtime of libconan_hip.so: context (weights), streams (per-slot state), launch plans.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/conan_hip.h"
+#include "kernels.h"
+
+namespace ch {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char* what);
+#define HIP_CHECK(x) ::ch::hip_check((x), #x)
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+// A conv / linear weight repacked for conv_mfma: [taps][Cin_pad/4][Cout_pad][4], zero padded.
+struct PackedConv {
+  float* w = nullptr;
+  float* bias = nullptr;   // [Cout_pad] (zeros when the layer has no bias)
+  int Cin = 0, Cin_pad = 0, Cout = 0, Cout_pad = 0, k = 1;
+  int shuffle_r = 1;
+};
+
+struct Ring {
+  float* base = nullptr;
+  int L = 0, C = 0, rate = 1;
+  long long slot_stride = 0;
+  ck::TRef ref(int off = 0) const {
+    ck::TRef r; r.base = base; r.slot_stride = slot_stride; r.C = C; r.lmask = L - 1; r.rate = rate; r.off = off; r.mode = 0; r.pad_ = 0;
+    return r;
+  }
+  long long floats_per_slot() const { return slot_stride; }
+};
+
+struct Lin {   // batch-indexed linear buffer [n][rows][C]
+  float* base = nullptr;
+  int rows = 0, C = 0;
+  ck::TRef ref(int off = 0) const {
+    ck::TRef r; r.base = base; r.slot_stride = (long long)rows * C; r.C = C; r.lmask = 0; r.rate = 0; r.off = off; r.mode = 1; r.pad_ = 0;
+    return r;
+  }
+};
+
+inline ck::TRef lin_ref(float* p, int rows, int C, int off = 0) {
+  Lin l; l.base = p; l.rows = rows; l.C = C; return l.ref(off);
+}
+inline ck::TRef null_ref() { ck::TRef r; memset(&r, 0, sizeof(r)); r.mode = 1; return r; }
+
+inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace ch
+
+struct conan_ctx {
+  int device = 0;
+  conan_cfg cfg;
+  bool finalized = false;
+  std::map<std::string, ch::HostTensor> raw;
+  std::map<std::string, ch::PackedConv> convs;
+  std::map<std::string, float*> vecs;
+  std::vector<void*> allocs;
+  int64_t weight_bytes = 0;
+  int hop = 1;
+  int num_cu = 256;
+
+  float* dev_alloc(size_t floats, bool zero = true);
+  float* upload(const std::vector<float>& v);
+  const ch::HostTensor& get(const std::string& key) const;
+  bool has(const std::string& key) const { return raw.count(key) != 0; }
+  const ch::PackedConv& conv(const std::string& name) const;
+  float* vec(const std::string& name) const;
+  void pack_conv(const std::string& name, const std::vector<float>& W, const float* bias, int Cout, int Cin, int k,
+                 int shuffle_r = 1);
+  void pack_from_keys(const std::string& name, const std::string& wkey, const std::string& bkey, int shuffle_r = 1);
+  void pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r = 1);
+  void upload_vec(const std::string& name, const std::string& key);
+  void finalize_hifigan();
+  void finalize_conan();
+  void finalize_emformer();
+  ~conan_ctx();
+};

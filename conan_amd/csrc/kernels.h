@@ -1,0 +1,173 @@
+// Device-side argument structs and launch wrappers of the conan_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ck {
+
+// A channel-last fp32 activation tensor [slot][row][C].
+//  mode 0 (ring):   row(t) = (pos[slot] * rate + off + t) & lmask, slot = slots[i]
+//  mode 1 (linear): row(t) = off + t,                          slot = i        (scratch / caller buffers)
+struct TRef {
+  float* base;
+  long long slot_stride;  // floats between consecutive slots
+  int C;                  // floats per row
+  int lmask;              // ring length - 1 (mode 0)
+  int rate;               // rows per frame (mode 0)
+  int off;                // constant row offset
+  int mode;
+  int pad_;
+};
+
+enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4 };
+
+// Causal / shifted 1-D convolution as an implicit GEMM on the f32 MFMA:
+//   y[i][t][co] = epilogue( sum_{j<ktaps} sum_{ci<Cin} W[j][ci][co] * f(x[i][t + j*dil - pad_left][ci]) )
+//   f(v)        = in_act( (x0 + x1 + x2) / nsrc )
+//   epilogue(a) = ((out_act((a + bias[co]) * out_scale) + bvec[slot][co]) + res[i][t][co]) * m1[i][t] * m2[i][t]
+// and, with shuffle_r > 1, the pixel-shuffled store y[i][t*r + co / Cq][co % Cq] (Cq = Cout / r) for
+// weights whose output channels were permuted to j-major at pack time.
+struct ConvArgs {
+  TRef x[3];
+  TRef y;
+  TRef res;
+  TRef m1, m2;          // per-row masks (C == 1)
+  const float* w;       // packed [ktaps][Cin_pad/4][Cout_pad][4]
+  const float* bias;    // [Cout_pad] or nullptr
+  const float* bvec;    // per-slot broadcast vector [slot][bvec_stride] or nullptr (indexed by slots[i])
+  const int* slots;     // [n]
+  const int* pos;       // per-slot frame counters (indexed by slot) or nullptr
+  const int* lens;      // per-batch valid output rows (or nullptr: all T rows valid)
+  long long bvec_stride;
+  int nsrc;
+  int has_res, has_m1, has_m2;
+  int Cin, Cin_pad, Cout, Cout_pad;
+  int ktaps, dil, pad_left;
+  int T;                // output rows per slot
+  int n;                // slots in this batch
+  int in_act;
+  float in_slope;
+  int out_act;
+  float out_scale, out_slope;
+  int shuffle_r;
+  int ksplit_unused;
+};
+
+struct ConvGroup {      // up to 3 independent problems in one launch (blockIdx.z)
+  ConvArgs p[3];
+};
+
+// Tile configurations of conv_mfma (block = 256 threads = 4 waves).
+enum ConvCfg { CFG_128x64 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_32x64_K2 = 3, CFG_32x32_K4 = 4, CFG_64x32_K2 = 5, NUM_CFG };
+int conv_cfg_tm(int cfg);
+int conv_cfg_tn(int cfg);
+void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
+
+// LayerNorm over the channel axis of each row:
+//   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])
+// optionally writing mask_out[i][t] = (sum_c |x| > 0).
+struct LNArgs {
+  TRef x, pre, y, post, m1, m2, mask_out;
+  const float* gamma;
+  const float* beta;
+  const int* slots;
+  const int* pos;
+  const int* lens;
+  int has_pre, has_post, has_m1, has_m2, has_mask_out;
+  int T, n, C;
+  float eps;
+};
+void launch_layernorm(const LNArgs& a, hipStream_t st);
+
+// rows copy / gather helpers
+struct CopyArgs {
+  TRef x, y;
+  const int* slots; const int* pos; const int* lens;
+  int T, n, C;
+};
+void launch_copy_rows(const CopyArgs& a, hipStream_t st);
+
+struct EmbedArgs {       // y[i][t][:] = table[idx[i][t]][:]
+  TRef y;
+  const float* table; const int* idx;
+  const int* slots; const int* pos;
+  int T, n, C, vocab;
+};
+void launch_embed(const EmbedArgs& a, hipStream_t st);
+
+// Emformer attention for one layer (torchaudio _EmformerAttention.infer, no memory bank):
+// queries = R+U tokens; keys = rc(R) | cached left context (min(LC, past)) | utt(U); then the U
+// new utterance keys/values are appended to the per-slot rings.
+struct EmfAttnArgs {
+  const float* q;      // [n][R+U][D]      (emb_to_query output, unscaled)
+  const float* kv;     // [n][R+U][2D]     (emb_to_key_value output)
+  float* out;          // [n][R+U][D]
+  float* kring; float* vring;   // [slot][LR][D]
+  long long ring_slot_stride;
+  const int* slots; const int* past;   // past[slot]
+  int n, R, U, D, H, LC, lmask;
+  float scaling;
+};
+void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st);
+
+// Cross attention of the prosody aligner (nn.MultiheadAttention, 2 heads) against cached K/V.
+struct XAttnArgs {
+  TRef q;              // [i][t][E]   already scaled by 1/sqrt(dh)
+  TRef out;            // [i][t][E]
+  const float* kv;     // [slot][S_max][2E]  (K | V)
+  long long kv_slot_stride;
+  const float* kmask;  // [slot][S_max] 0 or -inf
+  const int* slen;     // [slot]
+  float* attn_avg;     // optional [i][t][S_max] head-averaged weights
+  const int* slots; const int* pos;
+  int T, n, E, H, S_max;
+};
+void launch_xattn(const XAttnArgs& a, hipStream_t st);
+
+// uv/f0 head: LN(128) -> Linear(128->2) -> uv/f0 -> coarse bin -> decoder_inp = pitch_inp + pitch_embed[bin]
+struct PitchHeadArgs {
+  TRef h;              // [i][t][Cp]
+  TRef pitch_inp;      // [i][t][E]
+  TRef dec_inp;        // [i][t][E]
+  const float* gamma; const float* beta; const float* w; const float* b;   // w [2][Cp]
+  const float* pitch_embed;     // [300][E]
+  const int* codes;             // [n][T]
+  float* uv_pred; float* f0; int* bins;   // optional taps, [n][T][2], [n][T], [n][T]
+  const int* slots; const int* pos;
+  int T, n, Cp, E, silent_token;
+};
+void launch_pitch_head(const PitchHeadArgs& a, hipStream_t st);
+
+struct ArgmaxArgs { const float* x; int* idx; int rows, C; };
+void launch_argmax(const ArgmaxArgs& a, hipStream_t st);
+
+void launch_advance(int* pos, const int* slots, int n, int delta, hipStream_t st);
+void launch_fill_int(int* p, const int* slots, int n, int value, hipStream_t st);
+void launch_copy_int_rows(int* dst, const int* src, int n, int T, int S, hipStream_t st);
+void launch_scatter_int(int* dst, const int* slots, const int* src, int n, hipStream_t st);
+void launch_zero_slots(float* base, long long slot_stride, long long count, const int* slots, int n, hipStream_t st);
+
+// ---- style pass (per utterance) helpers
+struct RowMaskArgs { TRef x; TRef m; const int* lens; int T, n, C; int mode; };  // mode 0: sum|x|>0, 1: x[0]!=0
+void launch_rowmask(const RowMaskArgs& a, hipStream_t st);
+struct WNGateArgs { TRef xin; TRef acts; const int* lens; int T, n, H; };          // tanh(a[:H])*sigmoid(a[H:])
+void launch_wn_gate(const WNGateArgs& a, hipStream_t st);
+struct WNUpdateArgs { TRef rs; TRef x; TRef out; TRef m; const int* lens; int T, n, H; int last; int first; };
+void launch_wn_update(const WNUpdateArgs& a, hipStream_t st);
+struct PoolArgs { TRef x; TRef m; TRef y; const int* lens; int T, n, C, group; };  // y = mean over groups of x*m
+void launch_group_pool(const PoolArgs& a, hipStream_t st);
+struct VQArgs {       // dots[i][s][M] = x.e ; picks argmin of (e2 + x2) - 2*dot, writes z = x + (q - x) and [z | posemb]
+  TRef x; TRef dots; TRef cat;
+  const float* emb; const float* e2; const float* postable;
+  int* ids;            // [i][S_max]
+  const int* lens; int S, n, E, M, S_max;
+};
+void launch_vq(const VQArgs& a, hipStream_t st);
+struct KMaskArgs { TRef tok; float* kmask; long long kmask_stride; const int* slots; const int* lens; int S, n, S_max; };
+void launch_kmask(const KMaskArgs& a, hipStream_t st);
+struct MeanArgs { TRef x; TRef m; float* out; long long out_stride; const int* slots; const int* lens; int T, n, C; };
+void launch_masked_mean(const MeanArgs& a, hipStream_t st);
+struct ScaleMaskArgs { TRef x; TRef m; const int* lens; int T, n, C; };           // x *= m (in place)
+void launch_mul_mask(const ScaleMaskArgs& a, hipStream_t st);
+
+}  // namespace ck

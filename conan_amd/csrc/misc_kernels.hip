@@ -1,0 +1,539 @@
+// Row-wise kernels of the streaming path: LayerNorm over channels, embedding gather, Emformer
+// chunk attention with K/V ring update, prosody cross-attention, uv/f0 head, argmax, and the small
+// per-utterance style-pass helpers.  All tensors are channel-last fp32 (see kernels.h: TRef).
+// Reductions use 64-lane wavefront shuffles; one wave owns one row.
+#include "kernels.h"
+
+namespace ck {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ unsigned trow(const TRef& r, int slot, const int* pos, int t) {
+  if (r.mode == 0) {
+    unsigned p = pos ? (unsigned)pos[slot] : 0u;
+    return (p * (unsigned)r.rate + (unsigned)(r.off + t)) & (unsigned)r.lmask;
+  }
+  return (unsigned)(r.off + t);
+}
+__device__ __forceinline__ float* trowptr(const TRef& r, int i, int slot, const int* pos, int t) {
+  int s = r.mode == 0 ? slot : i;
+  return r.base + (long long)s * r.slot_stride + (long long)trow(r, s, pos, t) * r.C;
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+constexpr int LN_MAXV = 8;  // C <= 512
+__global__ __launch_bounds__(256) void layernorm_kernel(const LNArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.n * a.T) return;
+  const int i = m / a.T, t = m - i * a.T;
+  if (a.lens && t >= a.lens[i]) return;
+  const int slot = a.slots ? a.slots[i] : i;
+  const float* x = trowptr(a.x, i, slot, a.pos, t);
+  const float* pre = a.has_pre ? trowptr(a.pre, i, slot, a.pos, t) : nullptr;
+  float v[LN_MAXV];
+  float s = 0.f, sa = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int c = lane + 64 * k;
+    float u = 0.f;
+    if (c < a.C) { u = x[c]; sa += fabsf(u); if (pre) u += pre[c]; }
+    v[k] = u; s += u;
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) { int c = lane + 64 * k; if (c < a.C) { float d = v[k] - mean; q += d * d; } }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  float mk = 1.f;
+  if (a.has_m1) mk *= *trowptr(a.m1, i, slot, a.pos, t);
+  if (a.has_m2) mk *= *trowptr(a.m2, i, slot, a.pos, t);
+  if (a.has_mask_out) {
+    sa = wave_sum(sa);
+    if (lane == 0) *trowptr(a.mask_out, i, slot, a.pos, t) = sa > 0.f ? 1.f : 0.f;
+  }
+  float* y = trowptr(a.y, i, slot, a.pos, t);
+  const float* post = a.has_post ? trowptr(a.post, i, slot, a.pos, t) : nullptr;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int c = lane + 64 * k;
+    if (c < a.C) {
+      float o = (v[k] - mean) * rstd * a.gamma[c] + a.beta[c];
+      if (a.has_m1 | a.has_m2) o *= mk;
+      if (post) o += post[c];
+      y[c] = o;
+    }
+  }
+}
+void launch_layernorm(const LNArgs& a, hipStream_t st) {
+  int rows = a.n * a.T;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------ copies
+__global__ __launch_bounds__(256) void copy_rows_kernel(const CopyArgs a) {
+  const int m = blockIdx.x;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = a.slots ? a.slots[i] : i;
+  float* y = trowptr(a.y, i, slot, a.pos, t);
+  const bool live = !(a.lens && t >= a.lens[i]);
+  const float* x = trowptr(a.x, i, slot, a.pos, t);
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) y[c] = live ? x[c] : 0.f;
+}
+void launch_copy_rows(const CopyArgs& a, hipStream_t st) {
+  int rows = a.n * a.T;
+  if (rows <= 0) return;
+  int bs = a.C >= 256 ? 256 : (a.C > 64 ? 128 : 64);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(rows), dim3(bs), 0, st, a);
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
+  const int m = blockIdx.x;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = a.slots ? a.slots[i] : i;
+  int id = a.idx[m];
+  id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+  float* y = trowptr(a.y, i, slot, a.pos, t);
+  const float* e = a.table + (long long)id * a.C;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) y[c] = e[c];
+}
+void launch_embed(const EmbedArgs& a, hipStream_t st) {
+  int rows = a.n * a.T;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(a.C >= 256 ? 256 : 64), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------ Emformer attention
+// one block (64 threads) per slot; thread = (query token, head) pair; online softmax over the keys.
+constexpr int EMF_MAX_DH = 16;
+__global__ __launch_bounds__(64) void emf_attn_kernel(const EmfAttnArgs a) {
+  const int i = blockIdx.x;
+  const int slot = a.slots[i];
+  const int Q = a.R + a.U;
+  const int dh = a.D / a.H;
+  const int past = a.past[slot];
+  const int Lc = past < a.LC ? past : a.LC;
+  const int nk = a.R + Lc + a.U;
+  const float* kvb = a.kv + (long long)i * Q * 2 * a.D;
+  const float* kr = a.kring + (long long)slot * a.ring_slot_stride;
+  const float* vr = a.vring + (long long)slot * a.ring_slot_stride;
+  for (int pair = threadIdx.x; pair < Q * a.H; pair += blockDim.x) {
+    const int qi = pair / a.H, h = pair - qi * a.H;
+    float qv[EMF_MAX_DH], acc[EMF_MAX_DH];
+    const float* qp = a.q + ((long long)i * Q + qi) * a.D + h * dh;
+#pragma unroll
+    for (int d = 0; d < EMF_MAX_DH; ++d) { qv[d] = d < dh ? qp[d] * a.scaling : 0.f; acc[d] = 0.f; }
+    float mx = -INFINITY, sum = 0.f;
+    for (int kk = 0; kk < nk; ++kk) {
+      const float *kp, *vp;
+      if (kk < a.R) { kp = kvb + (long long)kk * 2 * a.D; vp = kp + a.D; }
+      else if (kk < a.R + Lc) {
+        unsigned r = (unsigned)(past - Lc + (kk - a.R)) & (unsigned)a.lmask;
+        kp = kr + (long long)r * a.D; vp = vr + (long long)r * a.D;
+      } else { kp = kvb + (long long)(a.R + (kk - a.R - Lc)) * 2 * a.D; vp = kp + a.D; }
+      kp += h * dh; vp += h * dh;
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) sc += qv[d] * kp[d];
+      const float nm = fmaxf(mx, sc);
+      const float corr = expf(mx - nm);
+      const float p = expf(sc - nm);
+      sum = sum * corr + p;
+#pragma unroll
+      for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) acc[d] = acc[d] * corr + p * vp[d];
+      mx = nm;
+    }
+    float* op = a.out + ((long long)i * Q + qi) * a.D + h * dh;
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) op[d] = acc[d] * inv;
+  }
+  // append the U new utterance keys/values (rows past .. past+U-1; never read above)
+  float* kw = a.kring + (long long)slot * a.ring_slot_stride;
+  float* vw = a.vring + (long long)slot * a.ring_slot_stride;
+  for (int e = threadIdx.x; e < a.U * a.D; e += blockDim.x) {
+    const int u = e / a.D, c = e - u * a.D;
+    const unsigned r = (unsigned)(past + u) & (unsigned)a.lmask;
+    const float* src = kvb + (long long)(a.R + u) * 2 * a.D;
+    kw[(long long)r * a.D + c] = src[c];
+    vw[(long long)r * a.D + c] = src[a.D + c];
+  }
+}
+void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------ cross attention
+// block = one query row (slot, t); wave h = head h.  Scores: lane-per-key dot over dh dims with q
+// broadcast from LDS; softmax by wave reductions; output: lane-per-dim sum over keys.
+constexpr int XA_MAX_S = 512;
+constexpr int XA_MAX_H = 4;
+__global__ __launch_bounds__(256) void xattn_kernel(const XAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sq[1024];
+  __shared__ float sp[XA_MAX_H][XA_MAX_S];
+  const int m = blockIdx.x;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = a.slots[i];
+  const int S = a.slen[slot];
+  const int dh = a.E / a.H;
+  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* q = trowptr(a.q, i, slot, a.pos, t);
+  for (int c = threadIdx.x; c < a.E; c += blockDim.x) sq[c] = q[c];
+  __syncthreads();
+  const float* kv = a.kv + (long long)slot * a.kv_slot_stride;
+  const float* km = a.kmask + (long long)slot * a.S_max;
+  if (h < a.H) {
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) {
+      const float4* kp = reinterpret_cast<const float4*>(kv + (long long)s * 2 * a.E + h * dh);
+      const float4* qp = reinterpret_cast<const float4*>(sq + h * dh);
+      float sc = 0.f;
+      for (int d = 0; d < dh / 4; ++d) { float4 k4 = kp[d], q4 = qp[d]; sc += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w; }
+      sc += km[s];
+      sp[h][s] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) { float p = expf(sp[h][s] - mx); sp[h][s] = p; sum += p; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int s = lane; s < S; s += 64) sp[h][s] *= inv;
+  }
+  __syncthreads();
+  if (h < a.H) {
+    float* o = trowptr(a.out, i, slot, a.pos, t);
+    for (int d = lane; d < dh; d += 64) {
+      float acc = 0.f;
+      const float* vp = kv + a.E + h * dh + d;
+      for (int s = 0; s < S; ++s) acc += sp[h][s] * vp[(long long)s * 2 * a.E];
+      o[h * dh + d] = acc;
+    }
+  }
+  if (a.attn_avg) {
+    float* w = a.attn_avg + ((long long)i * a.T + t) * a.S_max;
+    for (int s = threadIdx.x; s < a.S_max; s += blockDim.x) {
+      float v = 0.f;
+      if (s < S) { for (int hh = 0; hh < a.H; ++hh) v += sp[hh][s]; v /= (float)a.H; }
+      w[s] = v;
+    }
+  }
+}
+void launch_xattn(const XAttnArgs& a, hipStream_t st) {
+  int rows = a.n * a.T;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(xattn_kernel, dim3(rows), dim3(64 * (a.H < 1 ? 1 : a.H)), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------ uv / f0 head
+// PitchPredictor tail (nar_tts_modules.py:141-146) + add_orig_pitch (Conan.py:330-340) + denorm_f0 /
+// f0_to_coarse (pitch/utils.py:71-82, :17-28) + pitch_embed add (Conan.py:301, :181); fp32 op order kept.
+__global__ __launch_bounds__(256) void pitch_head_kernel(const PitchHeadArgs a, float mel_min, float mel_den) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.n * a.T) return;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = a.slots[i];
+  const float* x = trowptr(a.h, i, slot, a.pos, t);
+  float v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; v[k] = c < a.Cp ? x[c] : 0.f; s += v[k]; }
+  s = wave_sum(s);
+  const float mean = s / (float)a.Cp;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; if (c < a.Cp) { float d = v[k] - mean; q += d * d; } }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)a.Cp + 1e-5f);
+  float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = lane + 64 * k;
+    if (c < a.Cp) { float y = (v[k] - mean) * rstd * a.gamma[c] + a.beta[c]; d0 += y * a.w[c]; d1 += y * a.w[a.Cp + c]; }
+  }
+  d0 = wave_sum(d0) + a.b[0];
+  d1 = wave_sum(d1) + a.b[1];
+  const int code = a.codes[m];
+  const bool uv = (d0 > 0.f) || (code == a.silent_token);
+  float f0 = exp2f(d1);
+  f0 = fminf(fmaxf(f0, 50.f), 900.f);
+  if (uv) f0 = 0.f;
+  float fm = 1127.f * logf(1.f + f0 / 700.f);
+  if (fm > 0.f) fm = (fm - mel_min) * 254.f / mel_den + 1.f;
+  if (fm <= 1.f) fm = 1.f;
+  if (fm > 255.f) fm = 255.f;
+  const int bin = (int)(fm + 0.5f);
+  if (lane == 0) {
+    if (a.uv_pred) { a.uv_pred[(long long)m * 2] = d0; a.uv_pred[(long long)m * 2 + 1] = d1; }
+    if (a.f0) a.f0[m] = f0;
+    if (a.bins) a.bins[m] = bin;
+  }
+  const float* pi = trowptr(a.pitch_inp, i, slot, a.pos, t);
+  float* di = trowptr(a.dec_inp, i, slot, a.pos, t);
+  const float* pe = a.pitch_embed + (long long)bin * a.E;
+  for (int c = lane; c < a.E; c += 64) di[c] = pi[c] + pe[c];
+}
+void launch_pitch_head(const PitchHeadArgs& a, hipStream_t st) {
+  int rows = a.n * a.T;
+  if (rows <= 0) return;
+  const double mn = 1127.0 * log(1.0 + 50.0 / 700.0), mxx = 1127.0 * log(1.0 + 900.0 / 700.0);
+  hipLaunchKernelGGL(pitch_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a, (float)mn, (float)(mxx - mn));
+}
+
+// ------------------------------------------------------------------------------------ argmax
+__global__ __launch_bounds__(256) void argmax_kernel(const ArgmaxArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.rows) return;
+  const float* x = a.x + (long long)r * a.C;
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int c = lane; c < a.C; c += 64) { float v = x[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) a.idx[r] = bi;
+}
+void launch_argmax(const ArgmaxArgs& a, hipStream_t st) {
+  if (a.rows <= 0) return;
+  hipLaunchKernelGGL(argmax_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------ small state ops
+__global__ void advance_kernel(int* pos, const int* slots, int n, int delta) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[slots[i]] += delta;
+}
+void launch_advance(int* pos, const int* slots, int n, int delta, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(advance_kernel, dim3((n + 63) / 64), dim3(64), 0, st, pos, slots, n, delta);
+}
+__global__ void fill_int_kernel(int* p, const int* slots, int n, int value) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[slots[i]] = value;
+}
+void launch_fill_int(int* p, const int* slots, int n, int value, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(fill_int_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p, slots, n, value);
+}
+__global__ void copy_int_rows_kernel(int* dst, const int* src, int n, int T, int S) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n * T) { int i = e / T, t = e - i * T; dst[e] = src[i * S + t]; }
+}
+void launch_copy_int_rows(int* dst, const int* src, int n, int T, int S, hipStream_t st) {
+  if (n * T <= 0) return;
+  hipLaunchKernelGGL(copy_int_rows_kernel, dim3((n * T + 255) / 256), dim3(256), 0, st, dst, src, n, T, S);
+}
+__global__ void scatter_int_kernel(int* dst, const int* slots, const int* src, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[slots[i]] = src[i];
+}
+void launch_scatter_int(int* dst, const int* slots, const int* src, int n, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scatter_int_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dst, slots, src, n);
+}
+__global__ __launch_bounds__(256) void zero_slots_kernel(float* base, long long slot_stride, long long count,
+                                                         const int* slots) {
+  float4* p = reinterpret_cast<float4*>(base + (long long)slots[blockIdx.y] * slot_stride);
+  const long long n4 = count >> 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x)
+    p[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_zero_slots(float* base, long long slot_stride, long long count, const int* slots, int n, hipStream_t st) {
+  if (n <= 0 || count <= 0) return;
+  long long n4 = count >> 2;
+  int gx = (int)((n4 + 255) / 256); if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(zero_slots_kernel, dim3(gx, n), dim3(256), 0, st, base, slot_stride, count, slots);
+}
+
+// ------------------------------------------------------------------------------------ style-pass helpers
+__global__ __launch_bounds__(256) void rowmask_kernel(const RowMaskArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.n * a.T) return;
+  const int i = m / a.T, t = m - i * a.T;
+  float* mo = trowptr(a.m, i, i, nullptr, t);
+  if (a.lens && t >= a.lens[i]) { if (lane == 0) *mo = 0.f; return; }
+  const float* x = trowptr(a.x, i, i, nullptr, t);
+  float r;
+  if (a.mode == 1) r = x[0] != 0.f ? 1.f : 0.f;
+  else { float s = 0.f; for (int c = lane; c < a.C; c += 64) s += fabsf(x[c]); s = wave_sum(s); r = s > 0.f ? 1.f : 0.f; }
+  if (lane == 0) *mo = r;
+}
+void launch_rowmask(const RowMaskArgs& a, hipStream_t st) {
+  int rows = a.n * a.T; if (rows <= 0) return;
+  hipLaunchKernelGGL(rowmask_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+}
+
+__global__ __launch_bounds__(128) void wn_gate_kernel(const WNGateArgs a) {
+  const int m = blockIdx.x;
+  const int i = m / a.T, t = m - i * a.T;
+  if (a.lens && t >= a.lens[i]) return;
+  const float* x = trowptr(a.xin, i, i, nullptr, t);
+  float* y = trowptr(a.acts, i, i, nullptr, t);
+  for (int c = threadIdx.x; c < a.H; c += blockDim.x) {
+    float tv = tanhf(x[c]);
+    float sv = 1.0f / (1.0f + expf(-x[a.H + c]));
+    y[c] = tv * sv;
+  }
+}
+void launch_wn_gate(const WNGateArgs& a, hipStream_t st) {
+  int rows = a.n * a.T; if (rows <= 0) return;
+  hipLaunchKernelGGL(wn_gate_kernel, dim3(rows), dim3(128), 0, st, a);
+}
+
+// WN.forward body after res_skip (wavenet.py:78-85): i < last: x = (x + rs[:H]) * m, out += rs[H:];
+// last: out += rs; out *= m.
+__global__ __launch_bounds__(128) void wn_update_kernel(const WNUpdateArgs a) {
+  const int m = blockIdx.x;
+  const int i = m / a.T, t = m - i * a.T;
+  if (a.lens && t >= a.lens[i]) return;
+  const float* rs = trowptr(a.rs, i, i, nullptr, t);
+  float* x = trowptr(a.x, i, i, nullptr, t);
+  float* o = trowptr(a.out, i, i, nullptr, t);
+  const float mk = *trowptr(a.m, i, i, nullptr, t);
+  for (int c = threadIdx.x; c < a.H; c += blockDim.x) {
+    float prev = a.first ? 0.f : o[c];
+    if (!a.last) { x[c] = (x[c] + rs[c]) * mk; o[c] = prev + rs[a.H + c]; }
+    else o[c] = (prev + rs[c]) * mk;
+  }
+}
+void launch_wn_update(const WNUpdateArgs& a, hipStream_t st) {
+  int rows = a.n * a.T; if (rows <= 0) return;
+  hipLaunchKernelGGL(wn_update_kernel, dim3(rows), dim3(128), 0, st, a);
+}
+
+// group_hidden_by_segs (utils/nn/seq_utils.py:307-325) with ids = t//group + 1: mean of each group.
+__global__ __launch_bounds__(128) void group_pool_kernel(const PoolArgs a) {
+  const int S = (a.T + a.group - 1) / a.group;
+  const int m = blockIdx.x;
+  const int i = m / S, s = m - i * S;
+  const int len = a.lens ? a.lens[i] : a.T;
+  float* y = trowptr(a.y, i, i, nullptr, s);
+  int t0 = s * a.group, t1 = t0 + a.group; if (t1 > len) t1 = len;
+  if (t0 >= len) return;
+  const float cnt = (float)(t1 - t0);
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) acc += trowptr(a.x, i, i, nullptr, t)[c];
+    y[c] = acc / fmaxf(cnt, 1.f);
+  }
+}
+void launch_group_pool(const PoolArgs& a, hipStream_t st) {
+  int S = (a.T + a.group - 1) / a.group;
+  if (a.n * S <= 0) return;
+  hipLaunchKernelGGL(group_pool_kernel, dim3(a.n * S), dim3(128), 0, st, a);
+}
+
+// VQEmbeddingEMA eval (prosody_util.py:34-46, :88) + positions (seq_utils.py:6-18, transformer.py:66-67):
+// kernel 1: per token argmin over codes of (e2[j] + x2) + (-2*dot) ; z = x + (q - x) -> cat[:, :E]
+// kernel 2: per stream running count of tokens with z[0] != 0 -> cat[:, E:2E] = postable[pos]
+__global__ __launch_bounds__(64) void vq_argmin_kernel(const VQArgs a) {
+  const int lane = threadIdx.x;
+  const int m = blockIdx.x;
+  const int i = m / a.S, s = m - i * a.S;
+  const int len = a.lens ? a.lens[i] : a.S;
+  if (s >= len) return;
+  const float* x = trowptr(a.x, i, i, nullptr, s);
+  const float* dots = trowptr(a.dots, i, i, nullptr, s);
+  float x2 = 0.f;
+  for (int c = lane; c < a.E; c += 64) x2 += x[c] * x[c];
+  x2 = wave_sum(x2);
+  float best = INFINITY; int bi = 0x7fffffff;
+  for (int j = lane; j < a.M; j += 64) {
+    float d = (a.e2[j] + x2) + (-2.0f * dots[j]);
+    if (d < best) { best = d; bi = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0 && a.ids) a.ids[(long long)i * a.S_max + s] = bi;
+  float* cat = trowptr(a.cat, i, i, nullptr, s);
+  const float* q = a.emb + (long long)bi * a.E;
+  for (int c = lane; c < a.E; c += 64) { float xv = x[c]; cat[c] = xv + (q[c] - xv); }
+}
+__global__ __launch_bounds__(256) void vq_pos_kernel(const VQArgs a) {
+  __shared__ int spos[XA_MAX_S];
+  const int i = blockIdx.x;
+  const int len = a.lens ? a.lens[i] : a.S;
+  if (threadIdx.x == 0) {
+    int cnt = 0;
+    for (int s = 0; s < len; ++s) { float z0 = trowptr(a.cat, i, i, nullptr, s)[0]; int nz = z0 != 0.f; cnt += nz; spos[s] = nz ? cnt : 0; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < len * a.E; e += blockDim.x) {
+    int s = e / a.E, c = e - s * a.E;
+    trowptr(a.cat, i, i, nullptr, s)[a.E + c] = a.postable[(long long)spos[s] * a.E + c];
+  }
+}
+void launch_vq(const VQArgs& a, hipStream_t st) {
+  if (a.n * a.S <= 0) return;
+  hipLaunchKernelGGL(vq_argmin_kernel, dim3(a.n * a.S), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(vq_pos_kernel, dim3(a.n), dim3(256), 0, st, a);
+}
+
+// key_padding_mask = tokens[:, :, 0] == 0 (Conan.py:249) as an additive -inf mask per slot
+__global__ void kmask_kernel(const KMaskArgs a) {
+  const int i = blockIdx.x;
+  const int slot = a.slots[i];
+  const int len = a.lens ? a.lens[i] : a.S;
+  for (int s = threadIdx.x; s < a.S_max; s += blockDim.x) {
+    float v = 0.f;
+    if (s < len) v = trowptr(a.tok, i, i, nullptr, s)[0] == 0.f ? -INFINITY : 0.f;
+    a.kmask[(long long)slot * a.kmask_stride + s] = v;
+  }
+}
+void launch_kmask(const KMaskArgs& a, hipStream_t st) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(kmask_kernel, dim3(a.n), dim3(128), 0, st, a);
+}
+
+// temporal_avg_pool (Conan.py:214-219): sum over non-masked frames / count
+__global__ __launch_bounds__(256) void masked_mean_kernel(const MeanArgs a) {
+  const int i = blockIdx.x;
+  const int slot = a.slots[i];
+  const int len = a.lens ? a.lens[i] : a.T;
+  float cnt = 0.f;
+  for (int t = 0; t < len; ++t) cnt += *trowptr(a.m, i, i, nullptr, t) != 0.f ? 1.f : 0.f;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int t = 0; t < len; ++t) { float mk = *trowptr(a.m, i, i, nullptr, t); if (mk != 0.f) acc += trowptr(a.x, i, i, nullptr, t)[c]; }
+    a.out[(long long)slot * a.out_stride + c] = acc / cnt;
+  }
+}
+void launch_masked_mean(const MeanArgs& a, hipStream_t st) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(a.n), dim3(256), 0, st, a);
+}
+
+__global__ __launch_bounds__(256) void mul_mask_kernel(const ScaleMaskArgs a) {
+  const int m = blockIdx.x;
+  const int i = m / a.T, t = m - i * a.T;
+  if (a.lens && t >= a.lens[i]) return;
+  const float mk = *trowptr(a.m, i, i, nullptr, t);
+  float* x = trowptr(a.x, i, i, nullptr, t);
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) x[c] *= mk;
+}
+void launch_mul_mask(const ScaleMaskArgs& a, hipStream_t st) {
+  int rows = a.n * a.T; if (rows <= 0) return;
+  hipLaunchKernelGGL(mul_mask_kernel, dim3(rows), dim3(a.C >= 256 ? 256 : 64), 0, st, a);
+}
+
+}  // namespace ck

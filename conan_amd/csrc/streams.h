@@ -1,0 +1,99 @@
+// conan_streams: per-slot streaming state and launch plans (see streams.hip, decoder.hip, style.hip).
+#pragma once
+#include "host_common.h"
+
+using ch::Error;
+using ch::Lin;
+using ch::PackedConv;
+using ch::Ring;
+using ck::ConvArgs;
+using ck::ConvGroup;
+using ck::TRef;
+
+constexpr int kMaxBranches = 3;
+constexpr int PADR = 16;   // zero rows before/after a reference utterance in the style-pass buffers (k31 -> 15)
+
+struct VocStage {
+  Ring up;                                  // ups[i] output (pixel shuffled), also residual source
+  std::vector<std::vector<Ring>> xt, xo;    // [branch][dilation]
+  int C = 0, rate = 1;
+};
+
+struct conan_streams {
+  conan_ctx* ctx = nullptr;
+  int max_slots = 0, max_frames = 0, max_ref = 0, S_max = 0;
+  std::vector<void*> allocs;
+  int64_t state_bytes = 0;
+  std::vector<std::pair<float*, long long>> voc_state, dec_state, emf_state;  // (base, floats per slot) to zero on reset
+
+  int* d_slots = nullptr;   // [max_slots]
+  int* d_ident = nullptr;   // identity 0..max_slots-1
+  int* d_zero = nullptr;    // zeros (pos array for batch-indexed style pass)
+  int* d_lens = nullptr;    // [max_slots] per-batch lengths (style pass)
+  int* d_lens2 = nullptr;
+  int* d_codes = nullptr;   // [max_slots][max_frames] codes scratch for the fused step
+  std::vector<int> h_slots;
+  int* pos_emf = nullptr; int* pos_dec = nullptr; int* pos_voc = nullptr;
+
+  // --- vocoder
+  Ring v_mel, v_pre;
+  std::vector<VocStage> v_st;
+  // --- emformer
+  std::vector<Ring> e_k, e_v;
+  Lin e_x[2], e_ln, e_q, e_kv, e_att, e_r1, e_ffn, e_h, e_r2, e_logits;
+  // --- conan decoder
+  Ring c_emb, c_pin2, c_uvh[4], c_lastr;
+  std::vector<Ring> c_lnrs;     // post-LN rings, one per (block, sub-layer)
+  Lin c_pin, c_q, c_att, c_a1, c_a2, c_ff, c_uv5, c_x[2], c_h, c_post, c_mask_blk, c_mask_out, c_mel;
+  float* c_style = nullptr;     // [slot][H]
+  float* c_kv = nullptr;        // [slot][2 layers][S_max][2H]
+  float* c_kmask = nullptr;     // [slot][S_max]
+  int* c_slen = nullptr;        // [slot]
+  bool has_ref = false;
+  // --- style pass workspace (batch indexed, max_slots_sp at a time)
+  int sp_batch = 0;
+  Lin s_mel, s_np, s_wnm, s_x[2], s_ln, s_h, s_blkm, s_wx, s_wout, s_win, s_acts, s_rs, s_ph, s_pm, s_px[2], s_pln, s_phh,
+      s_pblk, s_enc, s_dots, s_cat, s_tok, s_kvtmp;
+  int* s_ids = nullptr;
+
+  float* alloc(size_t floats) {
+    void* p = nullptr;
+    if (floats == 0) floats = 4;
+    HIP_CHECK(hipMalloc(&p, floats * sizeof(float)));
+    HIP_CHECK(hipMemset(p, 0, floats * sizeof(float)));
+    allocs.push_back(p);
+    state_bytes += (int64_t)floats * 4;
+    return (float*)p;
+  }
+  Ring mk_ring(int C, int rate, int hist, std::vector<std::pair<float*, long long>>* reg) {
+    Ring r; r.C = C; r.rate = rate;
+    r.L = ch::next_pow2(hist + max_frames * rate);
+    r.slot_stride = (long long)r.L * C;
+    r.base = alloc((size_t)max_slots * r.slot_stride);
+    if (reg) reg->push_back({r.base, r.slot_stride});
+    return r;
+  }
+  Lin mk_lin(int rows, int C, int nb = -1) {
+    Lin l; l.rows = rows; l.C = C;
+    l.base = alloc((size_t)(nb < 0 ? max_slots : nb) * rows * C);
+    return l;
+  }
+  ~conan_streams() { for (void* p : allocs) (void)hipFree(p); }
+
+  void build_vocoder();
+  void build_emformer();
+  void build_decoder();
+  void set_slots(const int32_t* slots, int n, hipStream_t st);
+  int pick_cfg(int M, int N, int nprob) const;
+  void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; ck::launch_conv(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
+  ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;
+
+  void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st);
+  void emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st);
+  void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, float* uv_pred, float* f0, int32_t* bins,
+                    float* dec_inp, hipStream_t st);
+  void set_reference(const int32_t* slots, int n, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st);
+  void conv_blocks_noncausal(const std::string& name, int nblocks, int k, int C, Lin* x, Lin& ln, Lin& h, Lin& blkm, const TRef& npm,
+                             const int* lens, int n, int T, int& cur, hipStream_t st);
+};
+

@@ -1,0 +1,243 @@
+// conan_streams: per-slot streaming state (activation rings with their left context, Emformer K/V
+// rings, cached style pass) and the launch plans of the vocoder and Emformer steps.
+#include "streams.h"
+
+
+ConvArgs conan_streams::mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil,
+                           int pad_left) const {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x[0] = x; a.x[1] = x; a.x[2] = x; a.nsrc = 1;
+  a.y = y; a.res = ch::null_ref(); a.m1 = ch::null_ref(); a.m2 = ch::null_ref();
+  a.w = pc.w; a.bias = pc.bias; a.bvec = nullptr; a.slots = d_slots; a.pos = pos; a.lens = nullptr;
+  a.Cin = pc.Cin; a.Cin_pad = pc.Cin_pad; a.Cout = pc.Cout; a.Cout_pad = pc.Cout_pad;
+  a.ktaps = pc.k; a.dil = dil; a.pad_left = pad_left < 0 ? (pc.k - 1) * dil : pad_left;
+  a.T = T; a.n = n; a.in_act = ck::ACT_NONE; a.in_slope = 0.f; a.out_act = ck::ACT_NONE; a.out_scale = 1.f; a.out_slope = 0.f;
+  a.shuffle_r = pc.shuffle_r;
+  if (x.C != pc.Cin && !(x.C > pc.Cin)) throw Error(CONAN_ERR_SHAPE, "conv input width mismatch");
+  return a;
+}
+
+int conan_streams::pick_cfg(int M, int N, int nprob) const {
+  // prefer the largest tile that still gives every CU a block; narrow outputs use the TN=32 shapes
+  const int order_wide[] = {ck::CFG_128x64, ck::CFG_64x64, ck::CFG_32x64_K2};
+  const int order_narrow[] = {ck::CFG_128x32, ck::CFG_64x32_K2, ck::CFG_32x32_K4};
+  const int* order = N <= 32 ? order_narrow : order_wide;
+  int best = order[2];
+  long long need = ctx->num_cu;
+  for (int k = 0; k < 3; ++k) {
+    int c = order[k];
+    long long blocks = (long long)((M + ck::conv_cfg_tm(c) - 1) / ck::conv_cfg_tm(c)) * ((N + ck::conv_cfg_tn(c) - 1) / ck::conv_cfg_tn(c)) * nprob;
+    if (blocks >= need) { best = c; break; }
+  }
+  return best;
+}
+
+void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
+  if (n <= 0 || n > max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
+  bool same = (int)h_slots.size() == n;
+  for (int i = 0; i < n; ++i) {
+    if (slots[i] < 0 || slots[i] >= max_slots) throw Error(CONAN_ERR_INVALID, "slot index out of range");
+    if (same && h_slots[i] != slots[i]) same = false;
+  }
+  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n && n <= 64; ++j) if (slots[i] == slots[j]) throw Error(CONAN_ERR_INVALID, "duplicate slot");
+  if (same) return;
+  h_slots.assign(slots, slots + n);
+  HIP_CHECK(hipMemcpyAsync(d_slots, h_slots.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+}
+
+// ------------------------------------------------------------------------------------------------ vocoder
+
+void conan_streams::build_vocoder() {
+  const conan_cfg& c = ctx->cfg;
+  int maxk = 0;
+  for (int b = 0; b < c.voc_num_resblocks; ++b) maxk = std::max(maxk, c.voc_rb_kernels[b]);
+  v_mel = mk_ring(c.num_mels, 1, 6, &voc_state);
+  v_pre = mk_ring(c.voc_initial_channel, 1, c.voc_up_kernels[0] - 1, &voc_state);
+  int ch_ = c.voc_initial_channel, rate = 1;
+  v_st.resize(c.voc_num_ups);
+  for (int i = 0; i < c.voc_num_ups; ++i) {
+    VocStage& s = v_st[i];
+    rate *= c.voc_up_rates[i];
+    ch_ /= 2;
+    s.C = ch_; s.rate = rate;
+    s.up = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
+    const int next_pad = (i + 1 < c.voc_num_ups) ? c.voc_up_kernels[i + 1] - 1 : 6;
+    s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks);
+    for (int b = 0; b < c.voc_num_resblocks; ++b)
+      for (int d = 0; d < c.voc_rb_num_dil; ++d) {
+        const int k = c.voc_rb_kernels[b];
+        s.xt[b].push_back(mk_ring(ch_, rate, k - 1, &voc_state));
+        const int h = (d + 1 < c.voc_rb_num_dil) ? (k - 1) * c.voc_rb_dilations[b][d + 1] : next_pad;
+        s.xo[b].push_back(mk_ring(ch_, rate, h, &voc_state));
+      }
+  }
+}
+
+void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st) {
+  const conan_cfg& c = ctx->cfg;
+  const int* pos = pos_voc;
+  const float LR = 0.1f;   // LRELU_SLOPE, hifigan_causal.py:20
+  {  // mel chunk -> ring (conv_pre needs 6 frames of left context)
+    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    ca.x = ch::lin_ref(const_cast<float*>(mel_dev), frames, c.num_mels); ca.y = v_mel.ref();
+    ca.slots = d_slots; ca.pos = pos; ca.lens = nullptr; ca.T = frames; ca.n = n; ca.C = c.num_mels;
+    ck::launch_copy_rows(ca, st);
+  }
+  conv(mk(ctx->conv("voc.conv_pre"), v_mel.ref(), v_pre.ref(), n, frames, pos), st);
+  const int NB = c.voc_num_resblocks, ND = c.voc_rb_num_dil;
+  if (NB > kMaxBranches) throw Error(CONAN_ERR_UNSUPPORTED, "more than 3 resblock branches");
+  int ridx = 0;
+  for (int i = 0; i < c.voc_num_ups; ++i) {
+    VocStage& s = v_st[i];
+    const int Tin = frames * (s.rate / c.voc_up_rates[i]);
+    const int T = frames * s.rate;
+    {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322); stage input = mean of the branches
+      ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xo[0][ND - 1].ref(), s.up.ref(), n, Tin, pos);
+      if (i > 0) { a.nsrc = NB; for (int b = 0; b < NB; ++b) a.x[b] = v_st[i - 1].xo[b][ND - 1].ref(); }
+      a.in_act = ck::ACT_LRELU; a.in_slope = LR;
+      conv(a, st);
+    }
+    for (int d = 0; d < ND; ++d) {  // ResBlock1 (hifigan_causal.py:230-238), the NB branches as one grouped launch
+      ConvGroup g1, g2;
+      for (int b = 0; b < NB; ++b) {
+        const TRef xin = d == 0 ? s.up.ref() : s.xo[b][d - 1].ref();
+        std::string base = "voc.rb." + std::to_string(ridx + b);
+        ConvArgs a1 = mk(ctx->conv(base + ".c1." + std::to_string(d)), xin, s.xt[b][d].ref(), n, T, pos, c.voc_rb_dilations[b][d]);
+        a1.in_act = ck::ACT_LRELU; a1.in_slope = LR;
+        g1.p[b] = a1;
+        ConvArgs a2 = mk(ctx->conv(base + ".c2." + std::to_string(d)), s.xt[b][d].ref(), s.xo[b][d].ref(), n, T, pos, 1);
+        a2.in_act = ck::ACT_LRELU; a2.in_slope = LR;
+        a2.res = xin; a2.has_res = 1;
+        g2.p[b] = a2;
+      }
+      const int cfg = pick_cfg(n * T, s.C, NB);
+      ck::launch_conv(g1, NB, cfg, st);
+      ck::launch_conv(g2, NB, cfg, st);
+    }
+    ridx += NB;
+  }
+  {  // x = leaky_relu(xs / NB); conv_post; tanh   (hifigan_causal.py:329-333)
+    VocStage& s = v_st.back();
+    const int T = frames * s.rate;
+    if (pre_tanh) {
+      ConvArgs a = mk(ctx->conv("voc.conv_post"), s.xo[0][ND - 1].ref(), ch::lin_ref(pre_tanh, T, 1), n, T, pos);
+      a.nsrc = NB; for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref();
+      a.in_act = ck::ACT_LRELU; a.in_slope = LR;
+      conv(a, st);
+    }
+    ConvArgs a = mk(ctx->conv("voc.conv_post"), s.xo[0][ND - 1].ref(), ch::lin_ref(wav_out, T, 1), n, T, pos);
+    a.nsrc = NB; for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref();
+    a.in_act = ck::ACT_LRELU; a.in_slope = LR; a.out_act = ck::ACT_TANH;
+    conv(a, st);
+  }
+  ck::launch_advance(pos_voc, d_slots, n, frames, st);
+}
+
+// ------------------------------------------------------------------------------------------------ emformer
+
+void conan_streams::build_emformer() {
+  const conan_cfg& c = ctx->cfg;
+  const int D = c.emf_input_dim, Q = c.emf_segment + c.emf_right_context;
+  for (int l = 0; l < c.emf_layers; ++l) {
+    Ring r; r.C = D; r.rate = 1; r.L = ch::next_pow2(c.emf_left_context + c.emf_segment); r.slot_stride = (long long)r.L * D;
+    r.base = alloc((size_t)max_slots * r.slot_stride); emf_state.push_back({r.base, r.slot_stride}); e_k.push_back(r);
+    Ring v = r; v.base = alloc((size_t)max_slots * r.slot_stride); emf_state.push_back({v.base, v.slot_stride}); e_v.push_back(v);
+  }
+  e_x[0] = mk_lin(Q, D); e_x[1] = mk_lin(Q, D); e_ln = mk_lin(Q, D); e_q = mk_lin(Q, D); e_kv = mk_lin(Q, 2 * D);
+  e_att = mk_lin(Q, D); e_r1 = mk_lin(Q, D); e_ffn = mk_lin(Q, D); e_h = mk_lin(Q, c.emf_ffn_dim); e_r2 = mk_lin(Q, D);
+  e_logits = mk_lin(c.emf_segment, c.emf_output_dim);
+}
+
+void conan_streams::emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st) {
+  const conan_cfg& c = ctx->cfg;
+  const int D = c.emf_input_dim, R = c.emf_right_context, U = c.emf_segment, Q = R + U;
+  // token order inside the layers is [right_context | utterance] (torchaudio _EmformerLayer.infer): reorder the chunk
+  {
+    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    ca.slots = nullptr; ca.pos = nullptr; ca.lens = nullptr; ca.n = n; ca.C = D;
+    ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, U); ca.y = e_x[0].ref(0); ca.T = R; if (R > 0) ck::launch_copy_rows(ca, st);
+    ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, 0); ca.y = e_x[0].ref(R); ca.T = U; ck::launch_copy_rows(ca, st);
+  }
+  int cur = 0;
+  auto ln = [&](const TRef& x, const TRef& y, float* g, float* b, const TRef* pre) {
+    ck::LNArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.gamma = g; a.beta = b; a.slots = nullptr; a.pos = nullptr; a.lens = nullptr; a.T = Q; a.n = n; a.C = D; a.eps = 1e-5f;
+    if (pre) { a.pre = *pre; a.has_pre = 1; }
+    ck::launch_layernorm(a, st);
+  };
+  for (int l = 0; l < c.emf_layers; ++l) {
+    const std::string nm = "emf." + std::to_string(l);
+    Lin& x = e_x[cur];
+    ln(x.ref(), e_ln.ref(), ctx->vec(nm + ".ln_in.g"), ctx->vec(nm + ".ln_in.b"), nullptr);
+    conv(mk(ctx->conv(nm + ".q"), e_ln.ref(), e_q.ref(), n, Q, nullptr), st);
+    conv(mk(ctx->conv(nm + ".kv"), e_ln.ref(), e_kv.ref(), n, Q, nullptr), st);
+    {
+      ck::EmfAttnArgs a; memset(&a, 0, sizeof(a));
+      a.q = e_q.base; a.kv = e_kv.base; a.out = e_att.base; a.kring = e_k[l].base; a.vring = e_v[l].base;
+      a.ring_slot_stride = e_k[l].slot_stride; a.slots = d_slots; a.past = pos_emf;
+      a.n = n; a.R = R; a.U = U; a.D = D; a.H = c.emf_heads; a.LC = c.emf_left_context; a.lmask = e_k[l].L - 1;
+      a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
+      ck::launch_emf_attn(a, st);
+    }
+    {  // out_proj + residual with the un-normalised layer input
+      ConvArgs a = mk(ctx->conv(nm + ".out"), e_att.ref(), e_r1.ref(), n, Q, nullptr);
+      a.res = x.ref(); a.has_res = 1;
+      conv(a, st);
+    }
+    ln(e_r1.ref(), e_ffn.ref(), ctx->vec(nm + ".ln_ff.g"), ctx->vec(nm + ".ln_ff.b"), nullptr);
+    { ConvArgs a = mk(ctx->conv(nm + ".ff1"), e_ffn.ref(), e_h.ref(), n, Q, nullptr); a.out_act = ck::ACT_RELU; conv(a, st); }
+    { ConvArgs a = mk(ctx->conv(nm + ".ff2"), e_h.ref(), e_r2.ref(), n, Q, nullptr); a.res = e_r1.ref(); a.has_res = 1; conv(a, st); }
+    ln(e_r2.ref(), e_x[cur ^ 1].ref(), ctx->vec(nm + ".ln_out.g"), ctx->vec(nm + ".ln_out.b"), nullptr);
+    cur ^= 1;
+  }
+  if (out) {
+    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    ca.n = n; ca.C = D; ca.T = U; ca.x = e_x[cur].ref(R); ca.y = ch::lin_ref(out, U, D);
+    ck::launch_copy_rows(ca, st);
+  }
+  if (logits || codes) {
+    float* lg = logits ? logits : e_logits.base;
+    const int K = c.emf_output_dim;
+    if (c.emf_output_dim != D) conv(mk(ctx->conv("emf.proj"), e_x[cur].ref(R), ch::lin_ref(lg, U, K), n, U, nullptr), st);
+    else { ck::CopyArgs ca; memset(&ca, 0, sizeof(ca)); ca.n = n; ca.C = D; ca.T = U; ca.x = e_x[cur].ref(R); ca.y = ch::lin_ref(lg, U, D); ck::launch_copy_rows(ca, st); }
+    if (codes) { ck::ArgmaxArgs a; a.x = lg; a.idx = codes; a.rows = n * U; a.C = K; ck::launch_argmax(a, st); }
+  }
+  ck::launch_advance(pos_emf, d_slots, n, U, st);
+}
+
+// ------------------------------------------------------------------------------------------------ conan decoder
+
+void conan_streams::build_decoder() {
+  const conan_cfg& c = ctx->cfg;
+  const int H = c.hidden_size, F = max_frames;
+  c_emb = mk_ring(H, 1, c.content_kernel - 1, &dec_state);
+  c_pin2 = mk_ring(H, 1, c.predictor_kernel - 1, &dec_state);
+  for (int i = 0; i < 4; ++i) c_uvh[i] = mk_ring(128, 1, c.predictor_kernel - 1, &dec_state);
+  // one post-LN ring per (block, sub-layer): each layer keeps its own left context
+  for (int b = 0; b < c.dec_num_blocks; ++b)
+    for (int j = 0; j < c.dec_layers_in_block; ++j) c_lnrs.push_back(mk_ring(H, 1, (c.dec_kernel - 1) * c.dec_dilations[b], &dec_state));
+  c_lastr = mk_ring(H, 1, c.dec_post_kernel - 1, &dec_state);
+  c_pin = mk_lin(F, H); c_q = mk_lin(F, H); c_att = mk_lin(F, H); c_a1 = mk_lin(F, H); c_a2 = mk_lin(F, H);
+  c_ff = mk_lin(F, 2048); c_uv5 = mk_lin(F, 128); c_x[0] = mk_lin(F, H); c_x[1] = mk_lin(F, H); c_h = mk_lin(F, 2 * H);
+  c_post = mk_lin(F, H); c_mask_blk = mk_lin(F, 1); c_mask_out = mk_lin(F, 1); c_mel = mk_lin(F, c.num_mels);
+  S_max = (max_ref + 3) / 4;
+  if (S_max > 512) throw Error(CONAN_ERR_UNSUPPORTED, "max_ref_frames > 2048");
+  c_style = alloc((size_t)max_slots * H);
+  c_kv = alloc((size_t)max_slots * 2 * S_max * 2 * H);
+  c_kmask = alloc((size_t)max_slots * S_max);
+  c_slen = (int*)alloc((size_t)max_slots);
+  // style-pass workspace
+  sp_batch = std::min(max_slots, 8);
+  const int TR = max_ref + 2 * PADR, SR = S_max + 2 * PADR;
+  s_mel = mk_lin(TR, c.num_mels, sp_batch); s_np = mk_lin(TR, 1, sp_batch); s_wnm = mk_lin(TR, 1, sp_batch);
+  s_x[0] = mk_lin(TR, H, sp_batch); s_x[1] = mk_lin(TR, H, sp_batch); s_ln = mk_lin(TR, H, sp_batch); s_h = mk_lin(TR, 2 * H, sp_batch);
+  s_blkm = mk_lin(TR, 1, sp_batch);
+  s_wx = mk_lin(TR, 80, sp_batch); s_wout = mk_lin(TR, 80, sp_batch); s_win = mk_lin(TR, 160, sp_batch); s_acts = mk_lin(TR, 80, sp_batch);
+  s_rs = mk_lin(TR, 160, sp_batch);
+  s_ph = mk_lin(SR, 80, sp_batch); s_pm = mk_lin(SR, 1, sp_batch); s_px[0] = mk_lin(SR, 80, sp_batch); s_px[1] = mk_lin(SR, 80, sp_batch);
+  s_pln = mk_lin(SR, 80, sp_batch); s_phh = mk_lin(SR, 160, sp_batch); s_pblk = mk_lin(SR, 1, sp_batch);
+  s_enc = mk_lin(SR, H, sp_batch); s_dots = mk_lin(SR, c.nvq, sp_batch); s_cat = mk_lin(SR, 2 * H, sp_batch); s_tok = mk_lin(SR, H, sp_batch);
+  s_kvtmp = mk_lin(SR, 2 * H, sp_batch);
+  s_ids = (int*)alloc((size_t)sp_batch * S_max);
+}

@@ -1,0 +1,182 @@
+"""Thin Python handles over the C-ABI: Context (weights) and Streams (per-slot state).
+
+PyTorch-ROCm is used only as the device-memory / stream plumbing: every tensor argument is a
+CUDA(=HIP) torch tensor whose data_ptr() is handed to libconan_hip.so, and work is enqueued on
+torch's current HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("conan_amd needs a HIP device (MI355X); there is no CPU fallback")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """conan_ctx: packed weights of up to three models on one device."""
+
+    def __init__(self, conan_hp=None, hifigan_hp=None, device=0, emformer=True, conan=True, hifigan=True):
+        _require_gpu()
+        self.lib = _lib.lib()
+        self.cfg = _lib.make_cfg(conan_hp, hifigan_hp, emformer, conan, hifigan)
+        self.device = int(device)
+        self.conan_hp, self.hifigan_hp = conan_hp, hifigan_hp
+        h = C.c_void_p()
+        _lib.check(self.lib.conan_ctx_create(self.device, C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.finalized = False
+
+    def load_state_dict(self, model, sd):
+        """model in {'emformer','conan','hifigan'}; sd maps the reference's state_dict keys to
+        numpy arrays / torch tensors (utils/commons/ckpt_utils.py:26-66)."""
+        for k, v in sd.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if a.dtype.kind != "f":
+                continue
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            _lib.check(self.lib.conan_ctx_load_tensor(self.h, f"{model}.{k}".encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        return self
+
+    def finalize(self):
+        _lib.check(self.lib.conan_ctx_finalize(self.h))
+        self.finalized = True
+        return self
+
+    @property
+    def hop(self):
+        return self.lib.conan_hop_size(self.h)
+
+    @property
+    def weight_bytes(self):
+        return self.lib.conan_ctx_weight_bytes(self.h)
+
+    def streams(self, max_slots, max_frames=4, max_ref_frames=256):
+        return Streams(self, max_slots, max_frames, max_ref_frames)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.conan_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Streams:
+    """conan_streams: per-slot streaming state + the step functions."""
+
+    def __init__(self, ctx, max_slots, max_frames=4, max_ref_frames=256):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.max_slots, self.max_frames, self.max_ref_frames = max_slots, max_frames, max_ref_frames
+        h = C.c_void_p()
+        _lib.check(self.lib.conan_streams_create(ctx.h, max_slots, max_frames, max_ref_frames, C.byref(h)))
+        self.h = h
+        self.dev = torch.device("cuda", ctx.device)
+        c = ctx.cfg
+        self.seg, self.rc = c.emf_segment, c.emf_right_context
+
+    @property
+    def state_bytes(self):
+        return self.lib.conan_streams_state_bytes(self.h)
+
+    def reset(self, slots, which=7):
+        a, p = _i32(slots)
+        _lib.check(self.lib.conan_streams_reset(self.h, p, len(a), which, _stream()))
+
+    def set_reference(self, slots, ref_mel, ref_len=None):
+        """ref_mel: cuda float32 [n, Tr, 80]."""
+        a, p = _i32(slots)
+        ref_mel = ref_mel.to(self.dev, torch.float32).contiguous()
+        n, tr = ref_mel.shape[0], ref_mel.shape[1]
+        if ref_len is None:
+            ref_len = [tr] * n
+        l, lp = _i32(ref_len)
+        _lib.check(self.lib.conan_set_reference(self.h, p, len(a), _ptr(ref_mel), lp, tr, _stream()))
+
+    def emformer_step(self, slots, chunk, want_out=True, want_logits=True, want_codes=True):
+        a, p = _i32(slots)
+        n = len(a)
+        c = self.ctx.cfg
+        chunk = chunk.to(self.dev, torch.float32).contiguous()
+        assert chunk.shape == (n, self.seg + self.rc, c.emf_input_dim), chunk.shape
+        out = torch.empty(n, self.seg, c.emf_input_dim, device=self.dev) if want_out else None
+        logits = torch.empty(n, self.seg, c.emf_output_dim, device=self.dev) if want_logits else None
+        codes = torch.empty(n, self.seg, dtype=torch.int32, device=self.dev) if want_codes else None
+        _lib.check(self.lib.conan_emformer_step(self.h, p, n, _ptr(chunk), _ptr(out), _ptr(logits), _ptr(codes), _stream()))
+        return out, logits, codes
+
+    def decoder_step(self, slots, codes, taps=False):
+        a, p = _i32(slots)
+        n = len(a)
+        c = self.ctx.cfg
+        codes = codes.to(self.dev, torch.int32).contiguous()
+        T = codes.shape[1]
+        mel = torch.empty(n, T, c.num_mels, device=self.dev)
+        uv = f0 = bins = dinp = None
+        if taps:
+            uv = torch.empty(n, T, 2, device=self.dev)
+            f0 = torch.empty(n, T, device=self.dev)
+            bins = torch.empty(n, T, dtype=torch.int32, device=self.dev)
+            dinp = torch.empty(n, T, c.hidden_size, device=self.dev)
+        _lib.check(self.lib.conan_decoder_step(self.h, p, n, T, _ptr(codes), _ptr(mel), _ptr(uv), _ptr(f0), _ptr(bins), _ptr(dinp), _stream()))
+        return (mel, {"uv_pred": uv, "f0_denorm_pred": f0, "pitch_bins": bins, "decoder_inp": dinp}) if taps else mel
+
+    def hifigan_step(self, slots, mel, want_pre_tanh=False, out=None):
+        """mel: cuda float32 [n, frames, 80] -> wav [n, frames*hop]."""
+        a, p = _i32(slots)
+        n = len(a)
+        mel = mel.to(self.dev, torch.float32).contiguous()
+        T = mel.shape[1]
+        hop = self.ctx.hop
+        wav = out if out is not None else torch.empty(n, T * hop, device=self.dev)
+        pre = torch.empty(n, T * hop, device=self.dev) if want_pre_tanh else None
+        _lib.check(self.lib.conan_hifigan_step(self.h, p, n, T, _ptr(mel), _ptr(wav), _ptr(pre), _stream()))
+        return (wav, pre) if want_pre_tanh else wav
+
+    def step(self, slots, mel_chunk, emit=None, codes=None, mel_out=None, wav_out=None):
+        """Fused chunk step (one iteration of inference/Conan.py:95-156 for all slots)."""
+        a, p = _i32(slots)
+        n = len(a)
+        emit = self.seg if emit is None else emit
+        hop = self.ctx.hop
+        if codes is None:
+            codes = torch.empty(n, self.seg, dtype=torch.int32, device=self.dev)
+        if mel_out is None:
+            mel_out = torch.empty(n, emit, self.ctx.cfg.num_mels, device=self.dev)
+        if wav_out is None:
+            wav_out = torch.empty(n, emit * hop, device=self.dev)
+        _lib.check(self.lib.conan_step(self.h, p, n, emit, _ptr(mel_chunk), _ptr(codes), _ptr(mel_out), _ptr(wav_out), _stream()))
+        return codes, mel_out, wav_out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.conan_streams_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,155 @@
+/*
+ * conan_hip.h -- C-ABI of libconan_hip.so, the MI355X (gfx950) implementation of the
+ * chunkwise streaming voice-conversion hot path of User-tian/Conan.
+ *
+ * The reference has no FFI (it is pure Python/PyTorch); its seams are Python-level.  Each entry
+ * point below names the reference interface it replaces.  All tensor pointers marked _dev are
+ * DEVICE pointers owned by the caller (e.g. PyTorch-ROCm `tensor.data_ptr()`), fp32 contiguous
+ * row-major as documented; the library owns only its handles.  Work is enqueued asynchronously on
+ * the hipStream_t passed in (`stream`, as void*; NULL = the default stream).  Functions return 0
+ * on success or a negative conan_status and never throw; conan_last_error() is thread-local.
+ * One conan_streams handle may be driven by one host thread at a time; distinct handles are
+ * independent.
+ */
+#ifndef CONAN_HIP_H
+#define CONAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONAN_HIP_ABI_VERSION 1
+
+typedef enum conan_status {
+  CONAN_OK = 0,
+  CONAN_ERR_INVALID = -1,     /* bad argument (the reference raises ValueError / assert)          */
+  CONAN_ERR_MISSING = -2,     /* a required state_dict tensor was not loaded (strict load failure) */
+  CONAN_ERR_SHAPE = -3,       /* tensor shape does not match the configured architecture          */
+  CONAN_ERR_HIP = -4,         /* HIP runtime error                                                */
+  CONAN_ERR_STATE = -5,       /* call order violation (e.g. step before finalize/set_reference)    */
+  CONAN_ERR_UNSUPPORTED = -6  /* configuration outside the implemented hot path                   */
+} conan_status;
+
+#define CONAN_MAX_UPS 8
+#define CONAN_MAX_RESBLOCKS 4
+#define CONAN_MAX_DILATIONS 4
+#define CONAN_MAX_DEC_BLOCKS 16
+
+/* Architecture hyper-parameters: the subset of the reference's `hparams` the hot path reads
+ * (utils/commons/hparams.py:25-131; egs/conan_emformer.yaml, egs/hifi_16k320_shuffle.yaml). */
+typedef struct conan_cfg {
+  int32_t abi_version;            /* must be CONAN_HIP_ABI_VERSION */
+  /* Conan (modules/Conan/Conan.py:46-113, modules/tts/fs.py:49-79) */
+  int32_t hidden_size;            /* hparams['hidden_size'] (256) */
+  int32_t num_mels;               /* audio_num_mel_bins (80) */
+  int32_t content_vocab;          /* nn.Embedding(102, H) */
+  int32_t content_kernel;         /* hparams['kernel_size'] (3) */
+  int32_t dec_kernel;             /* dec_kernel_size (5) */
+  int32_t dec_num_blocks;         /* len(dec_dilations) (4) */
+  int32_t dec_dilations[CONAN_MAX_DEC_BLOCKS];
+  int32_t dec_layers_in_block;    /* layers_in_block (2) */
+  int32_t dec_post_kernel;        /* dec_post_net_kernel (3) */
+  int32_t predictor_kernel;       /* predictor_kernel (5) */
+  int32_t nvq;                    /* nVQ (512) */
+  int32_t silent_token;           /* silent_token (57) */
+  /* Emformer (modules/Emformer/emformer.py:14-25) */
+  int32_t emf_input_dim;          /* 80 */
+  int32_t emf_heads;              /* 8 */
+  int32_t emf_ffn_dim;            /* 2048 */
+  int32_t emf_layers;             /* emformer_layers (6) */
+  int32_t emf_segment;            /* chunk_size // 20 (4) */
+  int32_t emf_left_context;       /* 50 */
+  int32_t emf_right_context;      /* right_context (2) */
+  int32_t emf_output_dim;         /* proj out (100) */
+  /* HiFi-GAN (modules/vocoder/hifigan/hifigan_causal.py:273-312) */
+  int32_t voc_initial_channel;    /* upsample_initial_channel (512) */
+  int32_t voc_num_ups;
+  int32_t voc_up_rates[CONAN_MAX_UPS];
+  int32_t voc_up_kernels[CONAN_MAX_UPS];
+  int32_t voc_num_resblocks;      /* len(resblock_kernel_sizes) (3) */
+  int32_t voc_rb_kernels[CONAN_MAX_RESBLOCKS];
+  int32_t voc_rb_num_dil;
+  int32_t voc_rb_dilations[CONAN_MAX_RESBLOCKS][CONAN_MAX_DILATIONS];
+  /* which sub-models this context holds (bit 0 Emformer, bit 1 Conan, bit 2 HiFi-GAN) */
+  int32_t models;
+} conan_cfg;
+
+#define CONAN_MODEL_EMFORMER 1
+#define CONAN_MODEL_CONAN 2
+#define CONAN_MODEL_HIFIGAN 4
+
+typedef struct conan_ctx conan_ctx;          /* per device: packed weights, workspaces */
+typedef struct conan_streams conan_streams;  /* per-slot streaming state               */
+
+const char* conan_last_error(void);
+int conan_abi_version(void);
+
+/* Replaces model construction: Conan(0, hp) inference/Conan.py:34-38, EmformerDistillModel(hp,
+ * output_dim=100) :47-52, HifiGanGenerator(config) tasks/tts/vocoder_infer/hifigan.py:17. */
+int conan_ctx_create(int device, const conan_cfg* cfg, conan_ctx** out);
+int conan_ctx_destroy(conan_ctx* ctx);
+
+/* Replaces load_ckpt / nn.Module.load_state_dict (utils/commons/ckpt_utils.py:26-66).
+ * `key` is "<model>.<state_dict key>" with model in {"emformer","conan","hifigan"}; `host`
+ * is a HOST pointer to fp32 data of `shape[0..ndim)`; the data is copied.  Unknown keys are
+ * ignored (strict=False behaviour) and reported through the return value 1. */
+int conan_ctx_load_tensor(conan_ctx* ctx, const char* key, const float* host, const int64_t* shape, int ndim);
+
+/* Fold weight-norm (w = g*v/||v||, hifigan_causal.py:45), permute pixel-shuffle output channels,
+ * repack every weight to the kernels' [tap][Cin/4][Cout][4] layout and upload.  Fails with
+ * CONAN_ERR_MISSING naming the first required tensor that was not loaded. */
+int conan_ctx_finalize(conan_ctx* ctx);
+
+/* Per-slot state: Emformer K/V rings + past length, Conan conv rings + cached style/prosody,
+ * HiFi-GAN conv rings.  max_frames = largest number of mel frames one step may carry;
+ * max_ref_frames = longest reference mel conan_set_reference may receive. */
+int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, conan_streams** out);
+int conan_streams_destroy(conan_streams* s);
+
+/* Start of utterance for the given slots (replaces `state = None` inference/Conan.py:92 and the
+ * zero left-padding of every causal conv).  which = bitmask of CONAN_MODEL_*. */
+int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which, void* stream);
+
+/* Per-utterance style pass = the reference-mel-only part of Conan.forward
+ * (modules/Conan/Conan.py:157-159 encode_spk_embed, :221-245 prosody tokens, K/V of the aligner).
+ * ref_mel_dev[n][max_len][num_mels] (rows >= ref_len[i] ignored), ref_len host array. */
+int conan_set_reference(conan_streams* s, const int32_t* slots, int n, const float* ref_mel_dev,
+                        const int32_t* ref_len, int max_len, void* stream);
+
+/* One streaming step of torchaudio Emformer.infer + proj + argmax
+ * (inference/Conan.py:115-124).  chunk_dev[n][seg+rc][D]; out_dev[n][seg][D] (may be NULL);
+ * logits_dev[n][seg][K] (may be NULL); codes_dev[n][seg] int32 (may be NULL). */
+int conan_emformer_step(conan_streams* s, const int32_t* slots, int n, const float* chunk_dev,
+                        float* out_dev, float* logits_dev, int32_t* codes_dev, void* stream);
+
+/* `frames` new content codes per slot -> `frames` mel rows: Conan.forward(infer=True) restricted to
+ * the new frames (modules/Conan/Conan.py:140-198 given the cached style pass).
+ * codes_dev[n][frames] int32; mel_out_dev[n][frames][num_mels].  Optional taps (may be NULL):
+ * uv_pred_dev[n][frames][2], f0_dev[n][frames], bins_dev[n][frames] int32, decoder_inp_dev[n][frames][H]. */
+int conan_decoder_step(conan_streams* s, const int32_t* slots, int n, int frames, const int32_t* codes_dev,
+                       float* mel_out_dev, float* uv_pred_dev, float* f0_dev, int32_t* bins_dev,
+                       float* decoder_inp_dev, void* stream);
+
+/* `frames` new mel rows per slot -> frames*hop samples: HifiGanGenerator.forward restricted to the
+ * new frames (hifigan_causal.py:314-333).  mel_dev[n][frames][num_mels]; wav_out_dev[n][frames*hop];
+ * pre_tanh_dev optional. */
+int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames, const float* mel_dev,
+                       float* wav_out_dev, float* pre_tanh_dev, void* stream);
+
+/* Fused chunk step = one iteration of the loop inference/Conan.py:95-156 for n slots:
+ * mel_chunk_dev[n][seg+rc][D] -> codes_dev[n][seg] (int32), mel_out_dev[n][seg][num_mels],
+ * wav_out_dev[n][seg*hop].  emit = number of leading frames that are real (<= seg). */
+int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const float* mel_chunk_dev,
+               int32_t* codes_dev, float* mel_out_dev, float* wav_out_dev, void* stream);
+
+/* Introspection for tests / INTEGRATION.md. */
+int conan_hop_size(const conan_ctx* ctx);             /* prod(upsample_rates) */
+int64_t conan_ctx_weight_bytes(const conan_ctx* ctx); /* packed device weight bytes */
+int64_t conan_streams_state_bytes(const conan_streams* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONAN_HIP_H */
