@@ -62,7 +62,7 @@ HIFIGAN_16K320_SHUFFLE = {
 # Tiny variants for fast unit tests; same topology, small widths.
 CONAN_TINY = dict(copy.deepcopy(CONAN_EMFORMER), hidden_size=32, nVQ=16, emformer_layers=2,
                   tiny=True)
-HIFIGAN_TINY = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample_initial_channel=32)
+HIFIGAN_TINY = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample_initial_channel=64)
 
 
 def conan_hparams(tiny=False):

@@ -43,7 +43,7 @@ def build_ref_models(tiny):
         from modules.Conan.Conan import Conan
         m = Conan(0, hp).eval()
         vhp = dict(vhp)
-        vhp["upsample_initial_channel"] = 32
+        vhp["upsample_initial_channel"] = configs.HIFIGAN_TINY["upsample_initial_channel"]
         from modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
         g = HifiGanGenerator(vhp).eval()
     chp, ghp = configs.conan_hparams(tiny), configs.hifigan_hparams(tiny)
