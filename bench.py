@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: chunks/sec + p50 per-chunk latency of the chunkwise streaming VC path
+(Emformer -> Conan -> causal HiFi-GAN, 80 ms chunks @16 kHz) on N MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one fused chunk step (conan_step) for all B streams of a rank: B chunks of 80 ms.
+Inputs (synthetic mel chunks, reference mels, random-init weights of the egs/conan_emformer.yaml +
+egs/hifi_16k320_shuffle.yaml architectures) are resident in HBM before the timed region.
+Streams are sharded across ranks (weak scaling: B per GPU fixed); the only collective is the RCCL
+gather of the finished audio to rank 0, inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense
+N_FRAMES, N_REF = 151, 151     # 3 s source + 3 s reference at 50 frames/s
+
+WORKLOADS = {
+    "b64": dict(streams=64, desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full "
+                                 "Emformer->Conan->HiFi-GAN pipeline"),
+    "b1": dict(streams=1, desc="batch=1 stream, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
+}
+
+
+def build_context(device):
+    from conan_amd import configs, synth
+    from conan_amd.runtime import Context
+    chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
+    ctx = Context(chp, vhp, device)
+    ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0))
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    return ctx, chp, vhp
+
+
+def make_engine(ctx, B, first_stream):
+    """B streams with their reference set and every full chunk of the 3 s utterance staged in HBM."""
+    from conan_amd import synth
+    from conan_amd.engine import StreamingVoiceConversionEngine
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1)
+    src = np.concatenate([synth.mel(N_FRAMES, 1234 + first_stream + s) for s in range(B)])
+    ref = np.concatenate([synth.mel(N_REF, 4321 + first_stream + s) for s in range(B)])
+    src = torch.from_numpy(src).cuda()
+    eng.start(torch.from_numpy(ref).cuda())
+    chunks = [c for _, emit, c in eng.chunks(src) if emit == eng.seg]
+    return eng, chunks
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle's reference-semantics loop (inference/Conan.py:95-156: prefix re-run of Conan and the
+    vocoder every chunk, numpy hops) timed on the host cores, B=1, on a time-bounded prefix of the same
+    3 s utterance; plus the stateful CPU variant (same arithmetic the GPU path performs)."""
+    from conan_amd import configs, synth
+    from oracle import emformer as oemf
+    from oracle import loop as oloop
+    from oracle.common import to_torch_sd
+    torch.set_num_threads(os.cpu_count() or 1)
+    chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
+    esd = to_torch_sd(synth.emformer_state_dict(chp, 0))
+    csd = to_torch_sd(synth.conan_state_dict(chp, 0))
+    vsd = to_torch_sd(synth.hifigan_state_dict(vhp, 0))
+    cfg = oemf.EmformerCfg(chp)
+    src, ref = synth.mel(N_FRAMES, 1234)[0], synth.mel(N_REF, 4321)[0]
+
+    class Stop(Exception):
+        pass
+
+    def run(fn, budget):
+        stamps = [time.perf_counter()]
+
+        def tick():
+            stamps.append(time.perf_counter())
+            if stamps[-1] - stamps[0] > budget:
+                raise Stop()
+        try:
+            fn(esd, cfg, csd, chp, vsd, vhp, src, ref, on_chunk=tick)
+        except Stop:
+            pass
+        n = len(stamps) - 1
+        dt = stamps[-1] - stamps[0]
+        lat = sorted(b - a for a, b in zip(stamps[:-1], stamps[1:]))
+        return n, dt, (lat[len(lat) // 2] if lat else float("nan"))
+
+    n_ref, t_ref, p50_ref = run(oloop.infer_once_ref, budget_s * 0.7)
+    n_st, t_st, p50_st = run(oloop.infer_once_stateful, budget_s * 0.3)
+    return {
+        "value": n_ref / t_ref, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle ref-semantics loop (prefix re-run per chunk, inference/Conan.py:95-156), B=1, first {n_ref} of 38 "
+                  f"chunks of the 3 s utterance in {t_ref:.1f} s; stateful CPU variant over {n_st} chunks",
+        "p50_ms": p50_ref * 1e3,
+        "stateful_value": n_st / t_st, "stateful_p50_ms": p50_st * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="b64", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-steps", type=int, default=40)
+    args = ap.parse_args()
+
+    from conan_amd.engine import gather_audio_equal, init_distributed
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    B = args.streams or WORKLOADS[args.workload]["streams"]
+
+    ctx, chp, vhp = build_context(local)
+    eng, chunks = make_engine(ctx, B, first_stream=rank * B)
+    hop, seg = ctx.hop, eng.seg
+    codes = torch.empty(B, seg, dtype=torch.int32, device="cuda")
+    mel_out = torch.empty(B, seg, 80, device="cuda")
+    wav = torch.empty(B, seg * hop, device="cuda")
+    gbufs = [torch.empty_like(wav) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step(j):
+        eng.st.step(eng.slots, chunks[j % len(chunks)], emit=seg, codes=codes, mel_out=mel_out, wav_out=wav)
+        if world > 1:
+            gather_audio_equal(wav, world, rank, gbufs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    j = 0
+    for _ in range(args.warmup):
+        step(j); j += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(j); j += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # per-chunk latency: one step for all B streams, host submit -> audio complete on device
+    lats = []
+    for _ in range(args.latency_steps):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        step(j); j += 1
+        torch.cuda.synchronize()
+        lats.append((time.perf_counter() - a) * 1e3)
+    p50 = statistics.median(lats)
+
+    # roofline of the dominant kernel family (conv_mfma): HIP events around every launch on its stream
+    roof = None
+    b1 = None
+    cpu = None
+    if rank == 0:
+        nprof = 5
+        torch.cuda.synchronize()
+        eng.st.profile_begin()
+        for _ in range(nprof):
+            eng.st.step(eng.slots, chunks[j % len(chunks)], emit=seg, codes=codes, mel_out=mel_out, wav_out=wav); j += 1
+        conv_ms, conv_flops, conv_launches = eng.st.profile_end()
+        ach = conv_flops / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "ck::conv_mfma_kernel<TM,TN,...> (all tile variants)",
+                "launches_per_step": conv_launches / nprof,
+                "avg_launch_us": conv_ms * 1e3 / conv_launches,
+                "flops_per_launch": conv_flops / conv_launches,
+                "conv_ms_per_step": conv_ms / nprof,
+                "gflop_per_chunk_per_stream": conv_flops / nprof / B / 1e9}
+        # batch=1 latency configuration (BASELINE.json configs[1]) beside the throughput one
+        if B != 1:
+            e1, ch1 = make_engine(ctx, 1, first_stream=100000)
+            c1 = torch.empty(1, seg, dtype=torch.int32, device="cuda")
+            m1 = torch.empty(1, seg, 80, device="cuda")
+            w1 = torch.empty(1, seg * hop, device="cuda")
+            l1 = []
+            for k in range(10 + args.latency_steps):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                e1.st.step(e1.slots, ch1[k % len(ch1)], emit=seg, codes=c1, mel_out=m1, wav_out=w1)
+                torch.cuda.synchronize()
+                if k >= 10:
+                    l1.append((time.perf_counter() - a) * 1e3)
+            b1 = {"workload": WORKLOADS["b1"]["desc"], "p50_latency_ms": statistics.median(l1),
+                  "chunks_per_s": 1e3 / statistics.median(l1)}
+            e1.st.close()
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        total_chunks = world * B * args.steps
+        out = {
+            "metric": "chunks/sec (80 ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it",
+            "value": total_chunks / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload]["desc"] if not args.streams else f"batch={B} streams per GPU, 80 ms chunk, stateful",
+                       "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": 80, "sample_rate": 16000,
+                       "architecture": "egs/conan_emformer.yaml + egs/hifi_16k320_shuffle.yaml shapes, random-init weights",
+                       "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1"},
+            "p50_latency_ms": p50,
+            "realtime_streams_supported": (total_chunks / dt) / 12.5,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if b1 is not None:
+            out["latency_b1"] = b1
+        print(json.dumps(out))
+    eng.st.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,7 @@ static void validate_cfg(const conan_cfg& c) {
     if (c.emf_input_dim % c.emf_heads || c.emf_input_dim / c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer head_dim must be <= 16");
     if (c.emf_input_dim % 4 || c.emf_input_dim > 512) throw Error(CONAN_ERR_UNSUPPORTED, "emformer input_dim");
     if (c.emf_segment < 1 || c.emf_right_context < 0) throw Error(CONAN_ERR_INVALID, "emformer segment/right context");
+    if (c.emf_right_context + c.emf_left_context + c.emf_segment > 128 || c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer attention supports <= 128 keys, <= 16 heads");
   }
   if (c.models & CONAN_MODEL_CONAN) {
     if (c.hidden_size % 8 || c.hidden_size > 512) throw Error(CONAN_ERR_UNSUPPORTED, "hidden_size must be a multiple of 8 and <= 512");
@@ -213,6 +214,30 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
     float* mel = mel_out_dev ? mel_out_dev : s->c_mel.base;
     s->decoder_step(n, emit, codes_emit, mel, nullptr, nullptr, nullptr, nullptr, st);
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, st);
+  });
+}
+
+int conan_profile_begin(conan_streams* s) {
+  return guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    s->prof_on = true; s->prof_used = 0; s->prof_flops = 0.0; s->prof_launches = 0;
+  });
+}
+
+int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int64_t* conv_launches) {
+  return guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    s->prof_on = false;
+    double ms = 0.0;
+    for (size_t i = 0; i < s->prof_used; ++i) {
+      HIP_CHECK(hipEventSynchronize(s->prof_ev[i].second));
+      float t = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&t, s->prof_ev[i].first, s->prof_ev[i].second));
+      ms += t;
+    }
+    if (conv_ms) *conv_ms = ms;
+    if (conv_flops) *conv_flops = s->prof_flops;
+    if (conv_launches) *conv_launches = s->prof_launches;
   });
 }
 

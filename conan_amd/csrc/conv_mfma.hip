@@ -4,14 +4,19 @@
 // GEMM view:  M = n*T output rows (slot, time), N = Cout, K = ktaps*Cin.
 //   A[m][(j,ci)] = f(x[slot][t + j*dil - pad_left][ci])   gathered per tap from the activation rings
 //   B[(j,ci)][co] = packed weights [tap][ci/4][co][4]
-// Block = 256 threads (4 waves on the 4 SIMDs of a CU).  Per K-step (one tap, 32 input channels) the
-// block stages an A tile [TM][32] and a W tile [32][TN] through LDS (register prefetch of step s+1
-// while step s runs on the matrix pipe; two LDS buffers, one barrier per step).  Fragments are read
-// with ds_read_b128: a K-chunk of 8 feeds 4 MFMAs, lanes 0-31 carrying k 0..3 and lanes 32-63 k 4..7
-// (the MFMA's two k-slots), so one 16-byte LDS read per operand serves 4 matrix instructions.
-// A rows are padded to 36 floats: bank-conflict-free for the b128 lane groups.
+// Block = 256 threads (4 waves on the 4 SIMDs of a CU).  Per K-step (one tap, KS input channels) the
+// block stages an A tile [TM][KS] and a W tile [KS][TN] through LDS.  The raw global loads of step
+// s+1 are issued back-to-back right after the barrier of step s (no dependent instruction between
+// them, so their latencies overlap each other and the MFMAs of step s); the input transform
+// (branch mean, LeakyReLU, zero fill) runs on the registers when they are written to LDS at the top
+// of step s+1.  Two LDS buffers, one barrier per step.
+// Fragments are read with ds_read_b128: a K-chunk of 8 feeds 4 MFMAs, lanes 0-31 carrying k 0..3 and
+// lanes 32-63 k 4..7 (the MFMA's two k-slots), so one 16-byte LDS read per operand serves 4 matrix
+// instructions.  A rows are padded by 4 floats: bank-conflict-free for the b128 lane groups.
 // Output tile D[time][co] keeps co on the lane -> 128-byte coalesced channel-last stores; the pixel
 // shuffle of CausalUpsampleBlock3 is a pure address remap of that store (weights pre-permuted).
+// KS = 32 for the large streaming tiles; KS = 128 for the small-M (latency-bound) tiles, where a
+// longer K-step amortises the per-step load latency and barrier.
 #include "kernels.h"
 
 namespace ck {
@@ -36,108 +41,140 @@ __device__ __forceinline__ unsigned tref_row(const TRef& r, int slot, const int*
   return (unsigned)(r.off + t);
 }
 
-template <int TM, int TN, int WM, int WN, int WK>
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
   static_assert(WM * WN * WK == 4, "4 waves per block");
+  static_assert(KS == 32 || KS == 64 || KS == 128, "K-step");
   constexpr int RM = TM / WM / 32;
   constexpr int RN = TN / WN / 32;
-  constexpr int AQ = TM / 32;            // A rows staged per thread
-  constexpr int WV = (8 * TN) / 256;     // W float4 staged per thread
-  constexpr int LDA = 36;
+  constexpr int SB = KS / 32;                 // 32-channel sub-blocks per K-step
+  constexpr int AQ = (TM / 32) * SB;          // A float4 staged per thread
+  constexpr int WV = (KS / 4 * TN) / 256;     // W float4 staged per thread
+  constexpr int NKQ = KS / 8;                 // 8-deep K chunks per step
+  constexpr int LDA = KS + 4;
   constexpr int A_FLOATS = TM * LDA;
-  constexpr int W_FLOATS = 8 * TN * 4;
+  constexpr int W_FLOATS = KS * TN;
   constexpr int RED_FLOATS = (WK > 1) ? (WK - 1) * WM * WN * RM * RN * 16 * 64 : 0;
   constexpr int STAGE_FLOATS = 2 * (A_FLOATS + W_FLOATS);
   constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const ConvArgs& a = g.p[blockIdx.z];
-  const int Mtot = a.n * a.T;
+  // ---- launch-uniform scalars, read once (keeps the K loop free of kernarg re-loads)
+  const int T = a.T, nslot = a.n, ktaps = a.ktaps, dil = a.dil, Cin = a.Cin, CoutP = a.Cout_pad, Cout = a.Cout;
+  const int Mtot = nslot * T;
   const int m0 = blockIdx.x * TM;
   const int n0 = blockIdx.y * TN;
-  if (m0 >= Mtot || n0 >= a.Cout) return;
+  if (m0 >= Mtot || n0 >= Cout) return;
+  const int* __restrict__ slots = a.slots;
+  const int* __restrict__ posp = a.pos;
+  const float* __restrict__ wbase = a.w;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wn = wave % WN;
   const int wm = (wave / WN) % WM;
-  const int wk = wave / (WN * WM);
+  const int wk = (WK == 1) ? 0 : wave / (WN * WM);
   const int l31 = lane & 31;
   const int lh = lane >> 5;
 
-  // ---- per-thread A staging geometry (fixed over the K loop)
+  // ---- tile row -> (batch index i, time t).  A tile that fits inside one stream's T rows touches at most two
+  // streams: their slot / position are fetched once; short-T layers (frame-rate tensors) divide per row.
+  const int i0 = m0 / T;
+  const int t0 = m0 - i0 * T;
+  const bool fast = T >= TM;
+  const int i1 = (i0 + 1 < nslot) ? i0 + 1 : i0;
+  const int slotA = slots ? slots[i0] : i0, slotB = slots ? slots[i1] : i1;
+  const int posA = posp ? posp[slotA] : 0, posB = posp ? posp[slotB] : 0;
+  auto rowmap = [&](int ml, int& i, int& t, int& slot, int& pv) __attribute__((always_inline)) {
+    if (fast) {
+      const int tt = t0 + ml;
+      const bool w = tt >= T;
+      i = w ? i1 : i0; t = w ? tt - T : tt; slot = w ? slotB : slotA; pv = w ? posB : posA;
+    } else {
+      const int m = m0 + ml;
+      i = m / T; t = m - i * T;
+      i = i < nslot ? i : nslot - 1;
+      slot = slots ? slots[i] : i; pv = posp ? posp[slot] : 0;
+    }
+  };
+
+  // ---- per-thread A staging geometry (fixed over the K loop): rows arow + 32*q, channel quad ac4
   const int arow = tid >> 3;
   const int ac4 = tid & 7;
-  const float* arowbase[AQ];
-  int abrow[AQ];
-  bool avalid[AQ];
-#pragma unroll
-  for (int q = 0; q < AQ; ++q) {
-    int m = m0 + arow + 32 * q;
-    bool v = m < Mtot;
-    int i = v ? m / a.T : 0;
-    int t = v ? m - i * a.T : 0;
-    int slot = (a.x[0].mode == 0) ? a.slots[i] : i;
-    int p = (a.x[0].mode == 0 && a.pos) ? a.pos[slot] * a.x[0].rate : 0;
-    abrow[q] = p + a.x[0].off + t - a.pad_left;
-    arowbase[q] = a.x[0].base + (long long)slot * a.x[0].slot_stride;
-    avalid[q] = v;
-  }
-  const long long d1 = (a.nsrc > 1) ? (a.x[1].base - a.x[0].base) : 0;
-  const long long d2 = (a.nsrc > 2) ? (a.x[2].base - a.x[0].base) : 0;
-  const int xC = a.x[0].C;
-  const int xmask = a.x[0].lmask;
+  const float* arowbase[TM / 32];
+  int abrow[TM / 32];
+  unsigned avalid = 0;
   const bool xring = a.x[0].mode == 0;
-  const int ncb = a.Cin_pad >> 5;
-  const int nks = a.ktaps * ncb;
-  const int ci4n = a.Cin_pad >> 2;
-
-  float4 pa[AQ];
-  float4 pw0 = make_float4(0.f, 0.f, 0.f, 0.f), pw1 = pw0;
-  static_assert(WV == 1 || WV == 2, "W staging vectors per thread");
-
-  auto prefetch = [&](int ks) __attribute__((always_inline)) {
-    const int cb = ks / a.ktaps;          // tap index fastest: consecutive steps re-touch the same rows
-    const int j = ks - cb * a.ktaps;
-    const int col = cb * 32 + ac4 * 4;
-    const bool cok = col < a.Cin;
+  {
+    const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
+    const long long xss = a.x[0].slot_stride;
+    const float* xb = a.x[0].base;
 #pragma unroll
-    for (int q = 0; q < AQ; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (avalid[q] && cok) {
-        int r = abrow[q] + j * a.dil;
-        if (xring) r &= xmask;
-        const float* p = arowbase[q] + (long long)r * xC + col;
-        v = *reinterpret_cast<const float4*>(p);
-        if (a.nsrc > 1) {
-          float4 v1 = *reinterpret_cast<const float4*>(p + d1);
-          v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
-          if (a.nsrc > 2) {
-            float4 v2 = *reinterpret_cast<const float4*>(p + d2);
-            v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-          }
-          const float dn = (float)a.nsrc;
-          v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
-        }
-        if (a.in_act == ACT_LRELU) {
-          v.x = v.x > 0.f ? v.x : v.x * a.in_slope;
-          v.y = v.y > 0.f ? v.y : v.y * a.in_slope;
-          v.z = v.z > 0.f ? v.z : v.z * a.in_slope;
-          v.w = v.w > 0.f ? v.w : v.w * a.in_slope;
-        }
-      }
-      pa[q] = v;
+    for (int q = 0; q < TM / 32; ++q) {
+      const int ml = arow + 32 * q;
+      int i, t, slot, pv;
+      rowmap(ml, i, t, slot, pv);
+      abrow[q] = (xring ? pv * xrate : 0) + xoff + t;
+      arowbase[q] = xb + (long long)(xring ? slot : i) * xss;
+      avalid |= ((m0 + ml) < Mtot ? 1u : 0u) << q;
     }
-    const float* wbase = a.w + ((long long)(j * ci4n + cb * 8) * a.Cout_pad + n0) * 4;
-    {
-      const int kq4 = tid / TN, co = tid - kq4 * TN;
-      pw0 = *reinterpret_cast<const float4*>(wbase + ((long long)kq4 * a.Cout_pad + co) * 4);
-      if constexpr (WV > 1) {
-        const int idx1 = tid + 256, kq41 = idx1 / TN, co1 = idx1 - kq41 * TN;
-        pw1 = *reinterpret_cast<const float4*>(wbase + ((long long)kq41 * a.Cout_pad + co1) * 4);
+  }
+  const long long d1 = (NSRC > 1) ? (a.x[1].base - a.x[0].base) : 0;
+  const long long d2 = (NSRC > 2) ? (a.x[2].base - a.x[0].base) : 0;
+  const int xC = a.x[0].C;
+  const int xmask = xring ? a.x[0].lmask : -1;
+  const int ncb32 = a.Cin_pad >> 5;                 // 32-channel blocks per tap
+  const int ncb = (ncb32 + SB - 1) / SB;            // K-steps per tap
+  const int nks = ktaps * ncb;
+  const int ci4n = a.Cin_pad >> 2;
+  const float neg_mul = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
+  // per-thread W staging offsets (floats, relative to the K-step's tile base)
+  int woff[WV];
+#pragma unroll
+  for (int v = 0; v < WV; ++v) { const int idx = tid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
+
+  float4 ra[AQ][NSRC];
+  static_assert(WV >= 1 && WV <= 8, "W staging vectors per thread");
+  float4 rw0 = f4zero(), rw1 = rw0, rw2 = rw0, rw3 = rw0, rw4 = rw0, rw5 = rw0, rw6 = rw0, rw7 = rw0;  // named (not an array): keeps them in VGPRs
+  unsigned okmask = 0;     // bit (q*SB+sb): staged quad is inside the tile and inside Cin
+  int jn = 0, cbn = 0;     // (tap, channel block) of the next K-step to issue; tap index fastest so that
+                           // consecutive steps re-touch the same activation rows (L1/L2 hits)
+
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int j = jn, cb = cbn;
+    okmask = 0;
+#pragma unroll
+    for (int q = 0; q < TM / 32; ++q) {
+      const int r = (abrow[q] + j * dil) & xmask;
+      const float* rowp = arowbase[q] + r * xC;
+#pragma unroll
+      for (int sb = 0; sb < SB; ++sb) {
+        const int col = (cb * SB + sb) * 32 + ac4 * 4;
+        const bool ok = ((avalid >> q) & 1u) && col < Cin;
+        const float* p = ok ? rowp + col : arowbase[q];     // always a mapped address; value dropped if !ok
+        ra[q * SB + sb][0] = *reinterpret_cast<const float4*>(p);
+        if constexpr (NSRC > 1) ra[q * SB + sb][1] = *reinterpret_cast<const float4*>(p + d1);
+        if constexpr (NSRC > 2) ra[q * SB + sb][2] = *reinterpret_cast<const float4*>(p + d2);
+        okmask |= (ok ? 1u : 0u) << (q * SB + sb);
       }
     }
+    const float* wstep = wbase + ((long long)(j * ci4n + cb * (KS / 4)) * CoutP + n0) * 4;
+#define CK_W_ISSUE(V)                                                                                   \
+    if constexpr (WV > V) {                                                                               \
+      int o = woff[V];                                                                                    \
+      if constexpr (KS == 128) { /* past Cin_pad: any mapped row; the A side is zero there */             \
+        const int kq4 = (tid + 256 * V) / TN;                                                             \
+        if (cb * (KS / 4) + kq4 >= ci4n) o -= kq4 * CoutP * 4;                                            \
+      }                                                                                                   \
+      rw##V = *reinterpret_cast<const float4*>(wstep + o);                                                \
+    }
+    CK_W_ISSUE(0) CK_W_ISSUE(1) CK_W_ISSUE(2) CK_W_ISSUE(3) CK_W_ISSUE(4) CK_W_ISSUE(5) CK_W_ISSUE(6) CK_W_ISSUE(7)
+#undef CK_W_ISSUE
+    if (++jn == ktaps) { jn = 0; ++cbn; }
   };
 
   f32x16 acc[RM][RN];
@@ -148,19 +185,47 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
 
-  prefetch(0);
+  issue();
   for (int ks = 0; ks < nks; ++ks) {
     float* As = lds + (ks & 1) * (A_FLOATS + W_FLOATS);
     float* Ws = As + A_FLOATS;
+    // ---- transform + store the staged registers
 #pragma unroll
-    for (int q = 0; q < AQ; ++q)
-      *reinterpret_cast<float4*>(As + (arow + 32 * q) * LDA + ac4 * 4) = pa[q];
-    *reinterpret_cast<float4*>(Ws + tid * 4) = pw0;
-    if constexpr (WV > 1) *reinterpret_cast<float4*>(Ws + (tid + 256) * 4) = pw1;
+    for (int q = 0; q < TM / 32; ++q)
+#pragma unroll
+      for (int sb = 0; sb < SB; ++sb) {
+        float4 v = ra[q * SB + sb][0];
+        if constexpr (NSRC > 1) {
+          const float4 v1 = ra[q * SB + sb][1];
+          v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+          if constexpr (NSRC > 2) {
+            const float4 v2 = ra[q * SB + sb][2];
+            v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+          }
+          const float dn = (float)NSRC;       // xs / num_resblocks (hifigan_causal.py:329): true division
+          v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
+        }
+        // LeakyReLU as a select on the multiplier (neg_mul == 1 when no input activation)
+        v.x *= v.x > 0.f ? 1.0f : neg_mul;
+        v.y *= v.y > 0.f ? 1.0f : neg_mul;
+        v.z *= v.z > 0.f ? 1.0f : neg_mul;
+        v.w *= v.w > 0.f ? 1.0f : neg_mul;
+        if (!((okmask >> (q * SB + sb)) & 1u)) v = f4zero();
+        *reinterpret_cast<float4*>(As + (arow + 32 * q) * LDA + sb * 32 + ac4 * 4) = v;
+      }
+#define CK_W_STORE(V) if constexpr (WV > V) *reinterpret_cast<float4*>(Ws + (tid + 256 * V) * 4) = rw##V;
+    CK_W_STORE(0) CK_W_STORE(1) CK_W_STORE(2) CK_W_STORE(3) CK_W_STORE(4) CK_W_STORE(5) CK_W_STORE(6) CK_W_STORE(7)
+#undef CK_W_STORE
     __syncthreads();
-    if (ks + 1 < nks) prefetch(ks + 1);
+#ifdef CK_ABLATE
+    if (ks + 1 < nks && !(a.ksplit_unused & 1)) issue();
+    if (a.ksplit_unused & 2) continue;
+#else
+    if (ks + 1 < nks) issue();
+#endif
 #pragma unroll
-    for (int kq = wk; kq < 4; kq += WK) {
+    for (int kc = 0; kc < NKQ / WK; ++kc) {
+      const int kq = kc * WK + wk;      // fixed trip count: no divergent control flow around the MFMAs
       float4 af[RM], bf[RN];
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
@@ -207,53 +272,105 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
     }
   }
 
-  // ---- epilogue
-  const int Cq = a.Cout / a.shuffle_r;
+  // ---- epilogue: per lane the column (co) is fixed per rn, the 16 accumulator registers walk the rows.
+  // Pass 1 resolves every row's addresses and issues all residual / mask loads back-to-back (one latency,
+  // not one per row); pass 2 applies bias/scale/activation/residual/mask and stores 128-byte row segments.
+  constexpr int NR = RM * 16;
+  const int shuf = a.shuffle_r;
+  const int Cq = Cout / shuf;
+  int ocol[RN], ojj[RN];
+  float bco[RN];
+  bool cok[RN];
 #pragma unroll
-  for (int rm = 0; rm < RM; ++rm) {
+  for (int rn = 0; rn < RN; ++rn) {
+    const int co = n0 + (wn * RN + rn) * 32 + l31;
+    cok[rn] = co < Cout;
+    bco[rn] = (a.bias && cok[rn]) ? a.bias[co] : 0.f;
+    if (shuf > 1) { ojj[rn] = co / Cq; ocol[rn] = co - ojj[rn] * Cq; } else { ojj[rn] = 0; ocol[rn] = co; }
+  }
+  const float oscale = a.out_scale, oslope = a.out_slope;
+  const int oact = a.out_act;
+  const int* lens = a.lens;
+  const bool yring = a.y.mode == 0;
+  const int yC = a.y.C, ymask = yring ? a.y.lmask : -1, yrate = a.y.rate, yoff = a.y.off;
+  const long long yss = a.y.slot_stride;
+  float* const ybase0 = a.y.base;
+  const bool has_res = a.has_res != 0, has_mask = (a.has_m1 | a.has_m2) != 0, has_bvec = a.bvec != nullptr;
+
+  int yrow[NR];          // first output row (before the per-column shuffle offset), -1 = skip
+  int ysel[NR];          // batch index / slot that owns the row (selects the y base)
+  float rv[NR][RN];
+  float mkv[NR];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ml = (wm * RM + rm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-      const int m = m0 + ml;
-      if (m >= Mtot) continue;
-      const int i = m / a.T;
-      const int t = m - i * a.T;
-      if (a.lens && t >= a.lens[i]) continue;
-      const int slot = a.slots ? a.slots[i] : i;
+  for (int r = 0; r < NR; ++r) {
+    const int rm = r >> 4, e = r & 15;
+    const int ml = (wm * RM + rm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+    int i, t, slot, pv;
+    rowmap(ml, i, t, slot, pv);
+    bool ok = (m0 + ml) < Mtot;
+    if (lens) ok = ok && t < lens[i];
+    yrow[r] = ok ? ((yring ? pv * yrate : 0) + yoff + t * shuf) : -1;
+    ysel[r] = yring ? slot : i;
+    mkv[r] = 1.f;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) rv[r][rn] = 0.f;
+    if (has_res) {
+      const TRef& rr = a.res; const int sidx = rr.mode == 0 ? slot : i;
+      const float* resrow = rr.base + (long long)sidx * rr.slot_stride + (long long)tref_row(rr, sidx, posp, t) * rr.C;
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) if (cok[rn]) rv[r][rn] = resrow[n0 + (wn * RN + rn) * 32 + l31];
+    }
+    if (has_bvec) {
+      const float* bv = a.bvec + (long long)slot * a.bvec_stride;
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) if (cok[rn]) rv[r][rn] += bv[n0 + (wn * RN + rn) * 32 + l31];
+    }
+    if (has_mask) {
       float mk = 1.f;
-      if (a.has_m1) { const TRef& r = a.m1; int s = r.mode == 0 ? slot : i; mk *= r.base[(long long)s * r.slot_stride + tref_row(r, s, a.pos, t)]; }
-      if (a.has_m2) { const TRef& r = a.m2; int s = r.mode == 0 ? slot : i; mk *= r.base[(long long)s * r.slot_stride + tref_row(r, s, a.pos, t)]; }
-      const float* resrow = nullptr;
-      if (a.has_res) {
-        const TRef& r = a.res; int s = r.mode == 0 ? slot : i;
-        resrow = r.base + (long long)s * r.slot_stride + (long long)tref_row(r, s, a.pos, t) * r.C;
-      }
-      const int ys = a.y.mode == 0 ? slot : i;
-      float* ybase = a.y.base + (long long)ys * a.y.slot_stride;
+      if (a.has_m1) { const TRef& q = a.m1; int sidx = q.mode == 0 ? slot : i; mk *= q.base[(long long)sidx * q.slot_stride + tref_row(q, sidx, posp, t)]; }
+      if (a.has_m2) { const TRef& q = a.m2; int sidx = q.mode == 0 ? slot : i; mk *= q.base[(long long)sidx * q.slot_stride + tref_row(q, sidx, posp, t)]; }
+      mkv[r] = mk;
+    }
+  }
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn) {
-        const int co = n0 + (wn * RN + rn) * 32 + l31;
-        if (co >= a.Cout) continue;
-        float v = acc[rm][rn][e];
-        if (a.bias) v += a.bias[co];
-        v *= a.out_scale;
-        v = apply_act(v, a.out_act, a.out_slope);
-        if (a.bvec) v += a.bvec[(long long)slot * a.bvec_stride + co];
-        if (resrow) v += resrow[co];
-        if (a.has_m1 | a.has_m2) v *= mk;
-        int orow_t, ocol;
-        if (a.shuffle_r > 1) { int jj = co / Cq; ocol = co - jj * Cq; orow_t = t * a.shuffle_r + jj; }
-        else { ocol = co; orow_t = t; }
-        ybase[(long long)tref_row(a.y, ys, a.pos, orow_t) * a.y.C + ocol] = v;
-      }
+  for (int r = 0; r < NR; ++r) {
+    const int rm = r >> 4, e = r & 15;
+    if (yrow[r] < 0) continue;
+    float* ybase = ybase0 + (long long)ysel[r] * yss;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) {
+      if (!cok[rn]) continue;
+      float v = acc[rm][rn][e] + bco[rn];
+      v *= oscale;
+      v = apply_act(v, oact, oslope);
+      v += rv[r][rn];          // bvec (added after the activation) + residual
+      v *= mkv[r];
+      ybase[((yrow[r] + ojj[rn]) & ymask) * yC + ocol[rn]] = v;
     }
   }
 }
 
-static const int kTM[NUM_CFG] = {128, 64, 128, 32, 32, 64};
-static const int kTN[NUM_CFG] = {64, 64, 32, 64, 32, 32};
+static const int kTM[NUM_CFG] = {128, 64, 128, 32, 32, 64, 64, 128, 128};
+static const int kTN[NUM_CFG] = {64, 64, 32, 64, 32, 32, 64, 64, 32};
 int conv_cfg_tm(int cfg) { return kTM[cfg]; }
 int conv_cfg_tn(int cfg) { return kTN[cfg]; }
+
+template <int NSRC>
+static void launch_conv_n(const ConvGroup& g, int cfg, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  switch (cfg) {
+    case CFG_128x64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
+    case CFG_64x64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
+    case CFG_128x32: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1, 32, NSRC>), grid, block, 0, st, g); break;
+    case CFG_32x64_K2: hipLaunchKernelGGL((conv_mfma_kernel<32, 64, 1, 2, 2, 128, NSRC>), grid, block, 0, st, g); break;
+    case CFG_32x32_K4: hipLaunchKernelGGL((conv_mfma_kernel<32, 32, 1, 1, 4, 128, NSRC>), grid, block, 0, st, g); break;
+    case CFG_64x32_K2: hipLaunchKernelGGL((conv_mfma_kernel<64, 32, 2, 1, 2, 32, NSRC>), grid, block, 0, st, g); break;
+    case CFG_64x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 64, NSRC>), grid, block, 0, st, g); break;
+    case CFG_128x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 64, NSRC>), grid, block, 0, st, g); break;
+    case CFG_128x32_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1, 64, NSRC>), grid, block, 0, st, g); break;
+    default: break;
+  }
+}
 
 void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st) {
   int maxM = 0, maxN = 0;
@@ -265,16 +382,10 @@ void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st) {
   if (maxM == 0) return;
   const int TM = kTM[cfg], TN = kTN[cfg];
   dim3 grid((maxM + TM - 1) / TM, (maxN + TN - 1) / TN, nprob);
-  dim3 block(256);
-  switch (cfg) {
-    case CFG_128x64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1>), grid, block, 0, st, g); break;
-    case CFG_64x64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1>), grid, block, 0, st, g); break;
-    case CFG_128x32: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1>), grid, block, 0, st, g); break;
-    case CFG_32x64_K2: hipLaunchKernelGGL((conv_mfma_kernel<32, 64, 1, 2, 2>), grid, block, 0, st, g); break;
-    case CFG_32x32_K4: hipLaunchKernelGGL((conv_mfma_kernel<32, 32, 1, 1, 4>), grid, block, 0, st, g); break;
-    case CFG_64x32_K2: hipLaunchKernelGGL((conv_mfma_kernel<64, 32, 2, 1, 2>), grid, block, 0, st, g); break;
-    default: break;
-  }
+  const int nsrc = g.p[0].nsrc;
+  if (nsrc == 1) launch_conv_n<1>(g, cfg, grid, st);
+  else if (nsrc == 2) launch_conv_n<2>(g, cfg, grid, st);
+  else launch_conv_n<3>(g, cfg, grid, st);
 }
 
 }  // namespace ck

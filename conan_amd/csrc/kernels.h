@@ -58,7 +58,8 @@ struct ConvGroup {      // up to 3 independent problems in one launch (blockIdx.
 };
 
 // Tile configurations of conv_mfma (block = 256 threads = 4 waves).
-enum ConvCfg { CFG_128x64 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_32x64_K2 = 3, CFG_32x32_K4 = 4, CFG_64x32_K2 = 5, NUM_CFG };
+enum ConvCfg { CFG_128x64 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_32x64_K2 = 3, CFG_32x32_K4 = 4, CFG_64x32_K2 = 5,
+               CFG_64x64_KS64 = 6, CFG_128x64_KS64 = 7, CFG_128x32_KS64 = 8, NUM_CFG };
 int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);
 void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st);

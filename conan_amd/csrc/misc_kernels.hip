@@ -116,9 +116,12 @@ void launch_embed(const EmbedArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------ Emformer attention
-// one block (64 threads) per slot; thread = (query token, head) pair; online softmax over the keys.
+// one block per slot, one wave per head; lanes own keys (rc | cached left context | utterance), each lane
+// keeps its key/value head-slice in registers and re-uses it for every query token; softmax and the
+// weighted value sum are 64-lane shuffle reductions.
 constexpr int EMF_MAX_DH = 16;
-__global__ __launch_bounds__(64) void emf_attn_kernel(const EmfAttnArgs a) {
+constexpr int EMF_MAX_KPL = 2;   // keys per lane: up to 128 keys
+__global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
   const int i = blockIdx.x;
   const int slot = a.slots[i];
   const int Q = a.R + a.U;
@@ -126,41 +129,61 @@ __global__ __launch_bounds__(64) void emf_attn_kernel(const EmfAttnArgs a) {
   const int past = a.past[slot];
   const int Lc = past < a.LC ? past : a.LC;
   const int nk = a.R + Lc + a.U;
+  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* kvb = a.kv + (long long)i * Q * 2 * a.D;
   const float* kr = a.kring + (long long)slot * a.ring_slot_stride;
   const float* vr = a.vring + (long long)slot * a.ring_slot_stride;
-  for (int pair = threadIdx.x; pair < Q * a.H; pair += blockDim.x) {
-    const int qi = pair / a.H, h = pair - qi * a.H;
-    float qv[EMF_MAX_DH], acc[EMF_MAX_DH];
-    const float* qp = a.q + ((long long)i * Q + qi) * a.D + h * dh;
+  if (h < a.H) {
+    float kreg[EMF_MAX_KPL][EMF_MAX_DH], vreg[EMF_MAX_KPL][EMF_MAX_DH];
 #pragma unroll
-    for (int d = 0; d < EMF_MAX_DH; ++d) { qv[d] = d < dh ? qp[d] * a.scaling : 0.f; acc[d] = 0.f; }
-    float mx = -INFINITY, sum = 0.f;
-    for (int kk = 0; kk < nk; ++kk) {
-      const float *kp, *vp;
+    for (int s = 0; s < EMF_MAX_KPL; ++s) {
+      const int kk = lane + 64 * s;
+      const float *kp = kvb, *vp = kvb;
       if (kk < a.R) { kp = kvb + (long long)kk * 2 * a.D; vp = kp + a.D; }
       else if (kk < a.R + Lc) {
         unsigned r = (unsigned)(past - Lc + (kk - a.R)) & (unsigned)a.lmask;
         kp = kr + (long long)r * a.D; vp = vr + (long long)r * a.D;
-      } else { kp = kvb + (long long)(a.R + (kk - a.R - Lc)) * 2 * a.D; vp = kp + a.D; }
-      kp += h * dh; vp += h * dh;
-      float sc = 0.f;
+      } else if (kk < nk) { kp = kvb + (long long)(a.R + (kk - a.R - Lc)) * 2 * a.D; vp = kp + a.D; }
 #pragma unroll
-      for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) sc += qv[d] * kp[d];
-      const float nm = fmaxf(mx, sc);
-      const float corr = expf(mx - nm);
-      const float p = expf(sc - nm);
-      sum = sum * corr + p;
-#pragma unroll
-      for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) acc[d] = acc[d] * corr + p * vp[d];
-      mx = nm;
+      for (int d = 0; d < EMF_MAX_DH; ++d) {
+        const bool ok = kk < nk && d < dh;
+        kreg[s][d] = ok ? kp[h * dh + d] : 0.f;
+        vreg[s][d] = ok ? vp[h * dh + d] : 0.f;
+      }
     }
-    float* op = a.out + ((long long)i * Q + qi) * a.D + h * dh;
-    const float inv = 1.0f / sum;
+    for (int qi = 0; qi < Q; ++qi) {
+      const float* qp = a.q + ((long long)i * Q + qi) * a.D + h * dh;
+      float sc[EMF_MAX_KPL];
+      float mx = -INFINITY;
 #pragma unroll
-    for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) op[d] = acc[d] * inv;
+      for (int s = 0; s < EMF_MAX_KPL; ++s) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) acc += (qp[d] * a.scaling) * kreg[s][d];
+        sc[s] = (lane + 64 * s) < nk ? acc : -INFINITY;
+        mx = fmaxf(mx, sc[s]);
+      }
+      mx = wave_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int s = 0; s < EMF_MAX_KPL; ++s) { sc[s] = (lane + 64 * s) < nk ? expf(sc[s] - mx) : 0.f; sum += sc[s]; }
+      sum = wave_sum(sum);
+      const float inv = 1.0f / sum;
+      float* op = a.out + ((long long)i * Q + qi) * a.D + h * dh;
+#pragma unroll
+      for (int d = 0; d < EMF_MAX_DH; ++d) {
+        if (d < dh) {
+          float o = 0.f;
+#pragma unroll
+          for (int s = 0; s < EMF_MAX_KPL; ++s) o += sc[s] * vreg[s][d];
+          o = wave_sum(o);
+          if (lane == 0) op[d] = o * inv;
+        }
+      }
+    }
   }
-  // append the U new utterance keys/values (rows past .. past+U-1; never read above)
+  __syncthreads();
+  // append the U new utterance keys/values (rows past .. past+U-1; not read above)
   float* kw = a.kring + (long long)slot * a.ring_slot_stride;
   float* vw = a.vring + (long long)slot * a.ring_slot_stride;
   for (int e = threadIdx.x; e < a.U * a.D; e += blockDim.x) {
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(64) void emf_attn_kernel(const EmfAttnArgs a) {
 }
 void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64 * a.H), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------ cross attention

@@ -78,14 +78,24 @@ struct conan_streams {
     l.base = alloc((size_t)(nb < 0 ? max_slots : nb) * rows * C);
     return l;
   }
-  ~conan_streams() { for (void* p : allocs) (void)hipFree(p); }
+  ~conan_streams() {
+    for (void* p : allocs) (void)hipFree(p);
+    for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  }
 
   void build_vocoder();
   void build_emformer();
   void build_decoder();
   void set_slots(const int32_t* slots, int n, hipStream_t st);
   int pick_cfg(int M, int N, int nprob) const;
-  void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; ck::launch_conv(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
+  // optional per-launch timing of the conv kernel family (conan_profile_*): HIP events on the launch stream
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
+  double prof_flops = 0.0;
+  long long prof_launches = 0;
+  void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
+  void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;
 
   void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st);

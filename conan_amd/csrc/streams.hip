@@ -19,18 +19,36 @@ ConvArgs conan_streams::mk(const PackedConv& pc, const TRef& x, const TRef& y, i
 }
 
 int conan_streams::pick_cfg(int M, int N, int nprob) const {
-  // prefer the largest tile that still gives every CU a block; narrow outputs use the TN=32 shapes
-  const int order_wide[] = {ck::CFG_128x64, ck::CFG_64x64, ck::CFG_32x64_K2};
-  const int order_narrow[] = {ck::CFG_128x32, ck::CFG_64x32_K2, ck::CFG_32x32_K4};
-  const int* order = N <= 32 ? order_narrow : order_wide;
-  int best = order[2];
+  // largest tile that still gives every CU a block; below that the small-M (KS=128) shapes, and when even
+  // those cannot fill the chip the one with the most blocks (these problems are latency-bound).
+  const int wide[] = {ck::CFG_128x64, ck::CFG_64x64, ck::CFG_32x64_K2, ck::CFG_32x32_K4};
+  const int narrow[] = {ck::CFG_128x32, ck::CFG_64x32_K2, ck::CFG_32x32_K4};
+  const int* order = N <= 32 ? narrow : wide;
+  const int cnt = N <= 32 ? 3 : 4;
   long long need = ctx->num_cu;
-  for (int k = 0; k < 3; ++k) {
+  int best = order[cnt - 1];
+  for (int k = 0; k < cnt; ++k) {
     int c = order[k];
     long long blocks = (long long)((M + ck::conv_cfg_tm(c) - 1) / ck::conv_cfg_tm(c)) * ((N + ck::conv_cfg_tn(c) - 1) / ck::conv_cfg_tn(c)) * nprob;
     if (blocks >= need) { best = c; break; }
   }
   return best;
+}
+
+void conan_streams::launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st) {
+  if (!prof_on) { ck::launch_conv(g, nprob, cfg, st); return; }
+  if (prof_used == prof_ev.size()) {
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    prof_ev.push_back({a, b});
+  }
+  auto& ev = prof_ev[prof_used++];
+  HIP_CHECK(hipEventRecord(ev.first, st));
+  ck::launch_conv(g, nprob, cfg, st);
+  HIP_CHECK(hipEventRecord(ev.second, st));
+  for (int p = 0; p < nprob; ++p)
+    prof_flops += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
+  prof_launches += 1;
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
@@ -112,8 +130,8 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         g2.p[b] = a2;
       }
       const int cfg = pick_cfg(n * T, s.C, NB);
-      ck::launch_conv(g1, NB, cfg, st);
-      ck::launch_conv(g2, NB, cfg, st);
+      launch_group(g1, NB, cfg, st);
+      launch_group(g2, NB, cfg, st);
     }
     ridx += NB;
   }

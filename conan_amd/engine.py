@@ -1,0 +1,106 @@
+"""Batched multi-stream serving engine: B independent utterance streams on one GPU, sharded by
+slot range over the ranks of a torch.distributed job (one process per GPU).
+
+Streams are independent units (private conv/KV state, no cross-stream arithmetic),
+so the compute path has no collective.  The only exchange is the gather of finished audio to
+rank 0 (RCCL `gather` over xGMI on GPUs, gloo in the CPU tests)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """Contiguous slot range [lo, hi) of `rank`: GPU g owns streams [g*B/W, (g+1)*B/W)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_distributed(backend=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def gather_audio(wav_local, world, rank, dst=0):
+    """Gather per-rank audio [b_r, samples] to `dst` (ragged b_r allowed); returns the concatenated
+    [B, samples] tensor on dst, None elsewhere."""
+    if world == 1:
+        return wav_local
+    counts = [torch.zeros(1, dtype=torch.int64, device=wav_local.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([wav_local.shape[0]], dtype=torch.int64, device=wav_local.device))
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    pad = wav_local
+    if wav_local.shape[0] < mx:
+        pad = torch.cat([wav_local, wav_local.new_zeros(mx - wav_local.shape[0], wav_local.shape[1])])
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+
+
+def gather_audio_equal(wav_local, world, rank, bufs=None, dst=0):
+    """Fast path when every rank holds the same number of streams (the benchmark's weak scaling)."""
+    if world == 1:
+        return wav_local
+    if rank == dst and bufs is None:
+        bufs = [torch.empty_like(wav_local) for _ in range(world)]
+    dist.gather(wav_local, bufs if rank == dst else None, dst=dst)
+    return bufs
+
+
+class StreamingVoiceConversionEngine:
+    """The chunk loop of StreamingVoiceConversion.infer_once (inference/Conan.py:72-166) for many
+    streams at once: mel in -> (wav, mel, codes) out, state carried in a conan_streams handle."""
+
+    def __init__(self, ctx, n_streams, max_ref_frames=256):
+        self.ctx = ctx
+        self.n = n_streams
+        self.st = ctx.streams(n_streams, max_frames=ctx.cfg.emf_segment, max_ref_frames=max_ref_frames)
+        self.slots = list(range(n_streams))
+        self.seg, self.rc = ctx.cfg.emf_segment, ctx.cfg.emf_right_context
+
+    def start(self, ref_mel, ref_len=None):
+        self.st.reset(self.slots)
+        self.st.set_reference(self.slots, ref_mel, ref_len)
+
+    def chunks(self, src_mel):
+        """inference/Conan.py:95-110: (pos, emit, chunk[B, seg+rc, 80]) with repeat-last padding."""
+        B, T, F = src_mel.shape
+        pos = 0
+        while pos < T:
+            emit = min(self.seg, T - pos)
+            look = min(self.rc, T - (pos + emit))
+            real = emit + look
+            chunk = src_mel[:, pos:pos + real]
+            need = self.seg + self.rc - real
+            if need > 0:
+                chunk = torch.cat([chunk, chunk[:, -1:].expand(B, need, F)], 1)
+            yield pos, emit, chunk.contiguous()
+            pos += emit
+
+    @torch.no_grad()
+    def infer(self, src_mel, ref_mel, ref_len=None):
+        """src_mel [B,T,80], ref_mel [B,Tr,80] (cuda) -> wav [B, T*hop], mel [B,T,80], codes [B,T]."""
+        self.start(ref_mel, ref_len)
+        wavs, mels, codes = [], [], []
+        for pos, emit, chunk in self.chunks(src_mel):
+            c, m, w = self.st.step(self.slots, chunk, emit=emit)
+            wavs.append(w)
+            mels.append(m)
+            codes.append(c[:, :emit])
+        return torch.cat(wavs, 1), torch.cat(mels, 1), torch.cat(codes, 1)

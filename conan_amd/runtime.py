@@ -170,6 +170,15 @@ class Streams:
         _lib.check(self.lib.conan_step(self.h, p, n, emit, _ptr(mel_chunk), _ptr(codes), _ptr(mel_out), _ptr(wav_out), _stream()))
         return codes, mel_out, wav_out
 
+    def profile_begin(self):
+        _lib.check(self.lib.conan_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> (conv kernel ms, algorithmic conv FLOPs, conv launches) since profile_begin()."""
+        ms, fl, nl = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(self.lib.conan_profile_end(self.h, C.byref(ms), C.byref(fl), C.byref(nl)))
+        return ms.value, fl.value, nl.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.conan_streams_destroy(self.h)

@@ -144,6 +144,14 @@ int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames
 int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const float* mel_chunk_dev,
                int32_t* codes_dev, float* mel_out_dev, float* wav_out_dev, void* stream);
 
+/* Measurement hook (replaces the reference's Timer('hifigan') around the vocoder forward,
+ * utils/commons/meters.py:21-42, tasks/tts/vocoder_infer/hifigan.py:28): between begin and end every
+ * launch of the conv_mfma kernel family is bracketed by HIP events on its launch stream.  end() waits
+ * for them and returns the summed kernel time, the algorithmic FLOPs (2*M*N*K of the convolutions,
+ * unpadded) and the launch count. */
+int conan_profile_begin(conan_streams* s);
+int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int64_t* conv_launches);
+
 /* Introspection for tests / INTEGRATION.md. */
 int conan_hop_size(const conan_ctx* ctx);             /* prod(upsample_rates) */
 int64_t conan_ctx_weight_bytes(const conan_ctx* ctx); /* packed device weight bytes */

@@ -1,0 +1,73 @@
+// Micro-benchmark of ck::launch_conv on synthetic shapes (developer tool; not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I conan_amd/csrc tools/conv_bench.hip conan_amd/csrc/conv_mfma.hip -o gpurun_out/conv_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "kernels.h"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Shape { const char* name; int n, T, Cin, Cout, k, dil, nprob, cfg; };
+
+int main(int argc, char** argv) {
+  int ablate = argc > 1 ? atoi(argv[1]) : 0;
+  std::vector<Shape> shapes = {
+    {"stage1 rb (B64: M=2048,C=256,k7)", 64, 32, 256, 256, 7, 3, 3, ck::CFG_64x64},
+    {"stage2 rb (M=10240,C=128,k7)", 64, 160, 128, 128, 7, 3, 3, ck::CFG_128x64},
+    {"stage2 rb 64x64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_64x64},
+    {"stage2 rb 64x64 KS64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_64x64_KS64},
+    {"stage2 rb 128x64 KS64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_128x64_KS64},
+    {"stage3 rb (M=40960,C=64,k7)", 64, 640, 64, 64, 7, 3, 3, ck::CFG_128x64},
+    {"stage3 rb 128x64 KS64", 64, 640, 64, 64, 7, 3, 3, ck::CFG_128x64_KS64},
+    {"stage3 rb 64x64 KS64", 64, 640, 64, 64, 7, 3, 3, ck::CFG_64x64_KS64},
+    {"stage4 rb (M=81920,C=32,k7)", 64, 1280, 32, 32, 7, 3, 3, ck::CFG_128x32},
+    {"stage4 rb 128x32 KS64... (Cin=32: n/a)", 64, 1280, 32, 32, 7, 3, 3, ck::CFG_128x32},
+    {"ups0 (M=256,Cin=512,N=2048,k16)", 64, 4, 512, 2048, 16, 1, 1, ck::CFG_64x64},
+    {"ups0 32x64", 64, 4, 512, 2048, 16, 1, 1, ck::CFG_32x64_K2},
+    {"dec c1 (M=256,256->512,k5)", 64, 4, 256, 512, 5, 1, 1, ck::CFG_32x32_K4},
+    {"emf ff2 (M=384,2048->80)", 64, 6, 2048, 80, 1, 1, 1, ck::CFG_32x32_K4},
+  };
+  int nslots = 64;
+  for (auto& s : shapes) {
+    const int L = 4096;  // ring rows (pow2) >= T + halo
+    int Lr = 1; while (Lr < s.T + 64) Lr <<= 1;
+    size_t xfl = (size_t)nslots * Lr * s.Cin, yfl = (size_t)nslots * Lr * s.Cout;
+    float *x, *y, *w, *b; int *slots, *pos;
+    CHECK(hipMalloc(&x, xfl * 4 * 3)); CHECK(hipMalloc(&y, yfl * 4 * 3));
+    int Cin_pad = (s.Cin + 31) / 32 * 32, Cout_pad = (s.Cout + 63) / 64 * 64;
+    size_t wfl = (size_t)s.k * Cin_pad * Cout_pad;
+    CHECK(hipMalloc(&w, wfl * 4 * 3)); CHECK(hipMalloc(&b, Cout_pad * 4));
+    CHECK(hipMemset(x, 0, xfl * 4 * 3)); CHECK(hipMemset(w, 0, wfl * 4 * 3)); CHECK(hipMemset(b, 0, Cout_pad * 4));
+    std::vector<float> hx(xfl); for (auto& v : hx) v = (float)rand() / RAND_MAX - 0.5f;
+    for (int p = 0; p < 3; ++p) CHECK(hipMemcpy(x + p * xfl, hx.data(), xfl * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw(wfl); for (auto& v : hw) v = (float)rand() / RAND_MAX - 0.5f;
+    for (int p = 0; p < 3; ++p) CHECK(hipMemcpy(w + p * wfl, hw.data(), wfl * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&slots, nslots * 4)); CHECK(hipMalloc(&pos, nslots * 4));
+    std::vector<int> hs(nslots); for (int i = 0; i < nslots; ++i) hs[i] = i;
+    CHECK(hipMemcpy(slots, hs.data(), nslots * 4, hipMemcpyHostToDevice)); CHECK(hipMemset(pos, 0, nslots * 4));
+    ck::ConvGroup g; memset(&g, 0, sizeof(g));
+    for (int p = 0; p < s.nprob; ++p) {
+      ck::ConvArgs& a = g.p[p];
+      ck::TRef xr; xr.base = x + p * xfl; xr.slot_stride = (long long)Lr * s.Cin; xr.C = s.Cin; xr.lmask = Lr - 1; xr.rate = 1; xr.off = 0; xr.mode = 0; xr.pad_ = 0;
+      ck::TRef yr = xr; yr.base = y + p * yfl; yr.slot_stride = (long long)Lr * s.Cout; yr.C = s.Cout;
+      a.x[0] = a.x[1] = a.x[2] = xr; a.nsrc = 1; a.y = yr; a.res = xr; a.has_res = (s.Cin == s.Cout);
+      a.w = w + p * wfl; a.bias = b; a.slots = slots; a.pos = pos;
+      a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cout = s.Cout; a.Cout_pad = Cout_pad; a.ktaps = s.k; a.dil = s.dil; a.pad_left = (s.k - 1) * s.dil;
+      a.T = s.T; a.n = s.n; a.in_act = ck::ACT_LRELU; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1; a.ksplit_unused = ablate;
+    }
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int it = 0; it < 3; ++it) ck::launch_conv(g, s.nprob, s.cfg, 0);
+    CHECK(hipDeviceSynchronize());
+    const int iters = 20;
+    CHECK(hipEventRecord(e0, 0));
+    for (int it = 0; it < iters; ++it) ck::launch_conv(g, s.nprob, s.cfg, 0);
+    CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    double fl = 2.0 * s.n * s.T * (double)s.Cout * s.k * s.Cin * s.nprob;
+    printf("%-40s cfg=%d  %8.1f us  %7.2f TFLOP/s (%.1f%% of 157.3)\n", s.name, s.cfg, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+    hipFree(x); hipFree(y); hipFree(w); hipFree(b); hipFree(slots); hipFree(pos);
+  }
+  return 0;
+}
