@@ -86,6 +86,9 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()').  conan_amd has no CPU fallback.")
+        # PyTorch-ROCm bundles its own HIP runtime; load it first so that libconan_hip.so binds to the same
+        # libamdhip64 (two runtimes in one process do not see each other's devices / streams).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(l, name)

@@ -1,0 +1,129 @@
+"""EmformerDistillModel with the reference's constructor / attribute / state_dict contract
+(modules/Emformer/emformer.py:6-98).  `.emformer.infer(input, lengths, states)` is the streaming step of
+torchaudio.models.Emformer (used at inference/Conan.py:115); states are opaque handles onto the per-slot K/V
+rings of a conan_streams object instead of lists of tensors."""
+import torch
+from torch import nn
+
+from .. import _tree
+from ... import specs
+from ...runtime import Context
+
+
+class EmformerState:
+    """Opaque streaming state returned by Emformer.infer (replaces torchaudio's List[List[Tensor]])."""
+
+    def __init__(self, streams, slots):
+        self.streams, self.slots = streams, slots
+
+
+class _Proj:
+    """`.proj` of EmformerDistillModel (emformer.py:25).  The projection runs inside conan_emformer_step; calling
+    proj() on the tensor that infer() just returned hands back those logits."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __call__(self, x):
+        last = self.owner._last
+        if last is None or x is not last[0]:
+            raise RuntimeError("proj() must be applied to the tensor returned by the preceding emformer.infer() call")
+        return last[1]
+
+
+class _Emformer:
+    def __init__(self, owner):
+        self.owner = owner
+
+    @torch.no_grad()
+    def infer(self, input, lengths, states=None):
+        o = self.owner
+        seg, rc = o.segment_length, o.right_context_len
+        if input.size(1) != seg + rc:
+            raise ValueError(f"Per configured segment_length and right_context_length, expected size of {seg + rc} for "
+                             f"dimension 1 of input, but got {input.size(1)}.")
+        if not input.is_cuda:
+            raise RuntimeError("conan_amd.Emformer runs on a HIP device only (no CPU fallback)")
+        B = input.shape[0]
+        if states is None:
+            st = o._get_streams(B)
+            slots = list(range(B))
+            st.reset(slots, which=1)
+            states = EmformerState(st, slots)
+        out, logits, _ = states.streams.emformer_step(states.slots, input.float().contiguous(), want_codes=False)
+        o._last = (out, logits)
+        return out, torch.clamp(lengths - rc, min=0), states
+
+
+class EmformerDistillModel(_tree.ParamTree):
+    def __init__(self, hparams, input_dim=80, output_dim=None):
+        super().__init__()
+        if output_dim is None:
+            output_dim = hparams.get("emformer_output_dim", 768)
+        self.hp = dict(hparams, emformer_output_dim=output_dim)
+        self.segment_length = hparams["chunk_size"] // 20
+        self.right_context_len = hparams["right_context"]
+        self.mode = hparams.get("mode", None)
+        if self.mode == "both":
+            raise NotImplementedError("mode='both' dual heads are a next row (SURVEY.md §8f.2)")
+        _tree.build_tree(self, specs.emformer_spec(hparams, input_dim, output_dim))
+        # `.emformer` must stay the container of the parameter tree (state_dict keys 'emformer.emformer_layers...'),
+        # so the streaming entry point is attached to that sub-module; `.proj` keeps its parameters likewise.
+        self._modules["emformer"].infer = _Emformer(self).infer
+        if "proj" in self._modules:
+            self._modules["proj"].forward = _Proj(self)
+        self._last = None
+        self._ctx = None
+        self._streams = None
+
+    def refresh(self):
+        self._drop()
+        ctx = Context(self.hp, None, torch.cuda.current_device(), emformer=True, conan=False, hifigan=False)
+        ctx.load_state_dict("emformer", _tree.host_state_dict(self))
+        ctx.finalize()
+        self._ctx = ctx
+
+    def _drop(self):
+        if self._streams is not None:
+            self._streams.close()
+            self._streams = None
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._drop()
+        return out
+
+    def _get_streams(self, B):
+        if self._ctx is None:
+            self.refresh()
+        if self._streams is None or self._streams.max_slots < B:
+            if self._streams is not None:
+                self._streams.close()
+            self._streams = self._ctx.streams(B, max_frames=self.segment_length, max_ref_frames=4)
+        return self._streams
+
+    @torch.inference_mode()
+    def inference(self, mel_input):
+        """emformer.py:48-98: chunked streaming over mel_input[B, T, F] -> proj features [B, T, out_dim]."""
+        B, T, F = mel_input.shape
+        seg, rc = self.segment_length, self.right_context_len
+        pos, state, outs = 0, None, []
+        while pos < T:
+            emit = min(seg, T - pos)
+            look = min(rc, T - (pos + emit))
+            real = emit + look
+            chunk = mel_input[:, pos:pos + real, :]
+            need = (seg + rc) - real
+            if need > 0:
+                chunk = torch.cat([chunk, chunk[:, -1:, :].expand(B, need, F)], dim=1)
+            lengths = torch.full((B,), chunk.size(1), dtype=torch.long, device=mel_input.device)
+            out, _, state = self.emformer.infer(chunk, lengths, state)
+            outs.append(self.proj(out)[:, :emit, :].clone())
+            pos += emit
+        return torch.cat(outs, dim=1)
+
+    def forward(self, mel_input, lengths):
+        raise NotImplementedError("non-streaming Emformer.forward (training) is outside the hot path")

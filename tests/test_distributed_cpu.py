@@ -1,0 +1,54 @@
+"""world_size-2 gloo test of the only exchange on the path: gather of finished audio to rank 0
+(stream-sharded data parallelism)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conan_amd.engine import gather_audio, gather_audio_equal, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(total, rank, world)
+    # each stream's "audio" is its global stream id, so the gathered tensor must come back in stream order
+    wav = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 8)
+    out = gather_audio(wav, world, rank)
+    ok = True
+    if rank == 0:
+        ok = out.shape == (total, 8) and torch.equal(out[:, 0], torch.arange(total, dtype=torch.float32))
+    else:
+        ok = out is None
+    if (hi - lo) * world == total:       # equal shards: the benchmark's fast path
+        bufs = gather_audio_equal(wav, world, rank)
+        if rank == 0:
+            ok = ok and torch.equal(torch.cat(bufs)[:, 0], torch.arange(total, dtype=torch.float32))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_gather_audio_world2(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,107 @@
+"""GPU tests through the reference-shaped Python interfaces (module/forward API, vocoder registry, inference
+driver) -- the seams SURVEY.md §8b lists -- against the golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conan_amd import configs, synth
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def test_generator_forward_and_spec2wav_match_reference_golden():
+    from conan_amd.modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
+    from conan_amd.tasks.tts.vocoder_infer.base_vocoder import get_vocoder_cls
+    import conan_amd.tasks.tts.vocoder_infer.hifigan  # noqa: F401  (registers 'HifiGAN')
+    vhp = configs.hifigan_hparams()
+    g = load_golden("hifigan_full.npz")
+    gen = HifiGanGenerator(vhp)
+    gen.load_state_dict(_t(synth.hifigan_state_dict(vhp, 0)))
+    y = gen(torch.from_numpy(g["mel_150"]).cuda())
+    assert y.shape == (1, 1, 150 * 320)
+    np.testing.assert_allclose(y[0, 0].cpu().numpy(), g["wav_150"], atol=1e-4, rtol=0)
+    voc = get_vocoder_cls("HifiGAN")(config=vhp, state_dict=_t(synth.hifigan_state_dict(vhp, 0)))
+    wav = voc.spec2wav(g["mel_12"][0].T)                      # numpy [T,80] -> numpy [T*hop]
+    assert wav.dtype == np.float32 and wav.shape == (12 * 320,)
+    np.testing.assert_allclose(wav, g["wav_12"], atol=1e-4, rtol=0)
+    assert get_vocoder_cls("NoSuchVocoder") is None
+
+
+def test_conan_forward_matches_reference_golden():
+    from conan_amd.modules.Conan.Conan import Conan
+    chp = configs.conan_hparams()
+    g = load_golden("conan_full.npz")
+    m = Conan(0, chp)
+    m.load_state_dict(_t(synth.conan_state_dict(chp, 0)), strict=True)
+    ret = m(content=torch.from_numpy(g["content"]).cuda(), ref=torch.from_numpy(g["ref"]).cuda(), infer=True, global_steps=200000)
+    assert ret["mel_out"].shape == (1, 150, 80)
+    assert np.array_equal(ret["pitch_bins"].cpu().numpy(), g["pitch_bins"])
+    np.testing.assert_allclose(ret["uv_pred"].cpu().numpy(), g["uv_pred"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(ret["decoder_inp"].cpu().numpy(), g["decoder_inp"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(ret["mel_out"].cpu().numpy(), g["mel_out"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(ret["f0_denorm_pred"].cpu().numpy(), g["f0_denorm_pred"], atol=2e-2, rtol=1e-4)
+
+
+def test_emformer_module_streaming_api():
+    from conan_amd.modules.Emformer.emformer import EmformerDistillModel
+    from oracle import emformer as oemf
+    from oracle.common import to_torch_sd
+    chp = configs.conan_hparams()
+    sd = synth.emformer_state_dict(chp, 0)
+    e = EmformerDistillModel(chp, output_dim=100)
+    e.load_state_dict(_t(sd), strict=True)
+    mel = torch.from_numpy(synth.mel(30, 1234, 2))
+    logits = e.inference(mel.cuda())
+    ref_logits, _ = oemf.stream_codes(to_torch_sd(sd), oemf.EmformerCfg(chp), mel)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), atol=2e-4, rtol=1e-4)
+    with pytest.raises(ValueError):        # torchaudio raises ValueError for a wrong chunk length
+        e.emformer.infer(mel[:, :5].cuda(), torch.tensor([5, 5]).cuda(), None)
+
+
+def test_streaming_voice_conversion_infer_once():
+    from conan_amd.inference.Conan import StreamingVoiceConversion
+    from oracle import emformer as oemf
+    from oracle import loop as oloop
+    from oracle.common import to_torch_sd
+    chp, vhp = configs.conan_hparams(True), configs.hifigan_hparams(True)
+    sds = {"emformer": synth.emformer_state_dict(chp, 0), "conan": synth.conan_state_dict(chp, 0), "hifigan": synth.hifigan_state_dict(vhp, 0)}
+    eng = StreamingVoiceConversion(chp, vhp, sds)
+    src, ref = synth.mel(31, 1234)[0], synth.mel(40, 4321)[0]
+    wav, mel = eng.infer_once({"src_mel": src, "ref_mel": ref})
+    t = {k: to_torch_sd(v) for k, v in sds.items()}
+    w_ref, m_ref, _ = oloop.infer_once_ref(t["emformer"], oemf.EmformerCfg(chp), t["conan"], chp, t["hifigan"], vhp, src, ref)
+    assert wav.shape == (31 * 320,) and mel.shape == (31, 80)
+    np.testing.assert_allclose(mel, m_ref, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(wav, w_ref, atol=1e-4, rtol=0)
+    with pytest.raises(ValueError):
+        StreamingVoiceConversion(dict(chp, vocoder="Nope"), vhp, sds)
+
+
+def test_error_conventions_through_the_c_abi():
+    from conan_amd import _lib
+    from conan_amd.runtime import Context
+    chp, vhp = configs.conan_hparams(True), configs.hifigan_hparams(True)
+    ctx = Context(chp, vhp, 0)
+    with pytest.raises(_lib.ConanError) as ei:      # finalize with nothing loaded names the first missing tensor
+        ctx.finalize()
+    assert ei.value.code == _lib.ERR_MISSING and "conv_pre" in str(ei.value)
+    ctx.close()
+    ctx = Context(chp, vhp, 0)
+    for k, sd in (("emformer", synth.emformer_state_dict(chp, 0)), ("conan", synth.conan_state_dict(chp, 0)), ("hifigan", synth.hifigan_state_dict(vhp, 0))):
+        ctx.load_state_dict(k, sd)
+    ctx.finalize()
+    st = ctx.streams(2, 4, 16)
+    with pytest.raises(_lib.ConanError) as ei:      # decoder before set_reference (reference: ValueError when ref is None)
+        st.decoder_step([0], torch.zeros(1, 4, dtype=torch.int32).cuda())
+    assert ei.value.code == _lib.ERR_STATE
+    with pytest.raises(_lib.ConanError):            # slot out of range
+        st.reset([5])
+    with pytest.raises(_lib.ConanError):            # more frames than the streams were created for
+        st.hifigan_step([0], torch.zeros(1, 9, 80).cuda())
+    st.close()
+    ctx.close()

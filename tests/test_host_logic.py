@@ -1,0 +1,129 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol (no compute without a GPU),
+config/ckpt compatibility helpers, state_dict contracts, error conventions, stream sharding."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conan_amd import _lib, configs, specs, synth
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _lib._PROTOS, f"{n} declared in include/conan_hip.h but not bound in _lib.py"
+    assert lib.conan_abi_version() == _lib.ABI_VERSION
+
+
+def test_cfg_struct_matches_header_and_hparams():
+    cfg = _lib.make_cfg(configs.conan_hparams(), configs.hifigan_hparams())
+    assert C.sizeof(cfg) == 4 * 77
+    assert cfg.models == 7 and cfg.hidden_size == 256 and cfg.emf_segment == 4 and cfg.emf_right_context == 2
+    assert list(cfg.voc_up_rates)[:4] == [8, 5, 4, 2] and list(cfg.voc_up_kernels)[:4] == [16, 10, 8, 4]
+    assert [list(r)[:3] for r in cfg.voc_rb_dilations][:3] == [[1, 3, 5]] * 3
+    with pytest.raises(_lib.ConanError):
+        _lib.make_cfg(None, dict(configs.hifigan_hparams(), upsample="nn"))
+    with pytest.raises(_lib.ConanError):
+        _lib.make_cfg(dict(configs.conan_hparams(), f0_gen="flow"), None)
+
+
+def test_ctx_create_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.lib()
+    cfg = _lib.make_cfg(configs.conan_hparams(True), configs.hifigan_hparams(True))
+    h = C.c_void_p()
+    rc = lib.conan_ctx_create(0, C.byref(cfg), C.byref(h))
+    assert rc == _lib.ERR_HIP and b"device" in lib.conan_last_error().lower()
+    from conan_amd.runtime import Context
+    with pytest.raises(RuntimeError):
+        Context(configs.conan_hparams(True), configs.hifigan_hparams(True))
+
+
+def test_bad_cfg_rejected_before_touching_the_gpu():
+    lib = _lib.lib()
+    cfg = _lib.make_cfg(configs.conan_hparams(True), configs.hifigan_hparams(True))
+    cfg.abi_version = 99
+    h = C.c_void_p()
+    assert lib.conan_ctx_create(0, C.byref(cfg), C.byref(h)) == _lib.ERR_INVALID
+
+
+def test_state_dict_contracts():
+    from conan_amd.modules.Conan.Conan import Conan
+    from conan_amd.modules.Emformer.emformer import EmformerDistillModel
+    from conan_amd.modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
+    chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
+    g = HifiGanGenerator(vhp)
+    assert len(g.state_dict()) == 234 and sum(p.numel() for p in g.parameters()) == 29972450
+    c = Conan(0, chp)
+    assert len(c.state_dict()) == 271 and sum(p.numel() for p in c.parameters()) == 54922868
+    assert "prosody_extractor.vqvae.embedding" in dict(c.named_buffers())
+    e = EmformerDistillModel(chp, output_dim=100)
+    keys = list(e.state_dict().keys())
+    assert keys[0].startswith("emformer.emformer_layers.0.attention.") and "proj.weight" in keys
+    assert abs(sum(p.numel() for p in e.parameters()) - 2.145e6) < 2e4
+    # a reference-style checkpoint round-trips through load_state_dict unchanged
+    sd = {k: torch.from_numpy(v) for k, v in synth.hifigan_state_dict(vhp, 3).items()}
+    g.load_state_dict(sd, strict=True)
+    assert torch.equal(g.state_dict()["ups.0.conv.conv.weight_v"], sd["ups.0.conv.conv.weight_v"])
+    with pytest.raises(ValueError):
+        c.forward(torch.zeros(1, 4, dtype=torch.long), ref=None, infer=True)      # Conan.py:152-155
+    with pytest.raises(NotImplementedError):
+        HifiGanGenerator(dict(vhp, upsample="nn"))
+
+
+def test_hparams_yaml_chain(tmp_path, monkeypatch):
+    from conan_amd.utils.commons import hparams as H
+    (tmp_path / "egs" / "bases").mkdir(parents=True)
+    (tmp_path / "egs" / "bases" / "root.yaml").write_text(yaml.safe_dump({"a": 1, "nested": {"x": 1, "y": 2}, "lst": [1, 2]}))
+    (tmp_path / "egs" / "bases" / "mid.yaml").write_text(yaml.safe_dump({"base_config": "./root.yaml", "a": 2, "b": "s"}))
+    (tmp_path / "egs" / "top.yaml").write_text(yaml.safe_dump({"base_config": ["egs/bases/mid.yaml"], "nested": {"y": 3}, "c": True}))
+    monkeypatch.chdir(tmp_path)
+    hp = H.set_hparams("egs/top.yaml", hparams_str="a=5,nested.x=7,lst=[3 4],c=False", print_hparams=False)
+    assert hp["a"] == 5 and hp["b"] == "s" and hp["nested"] == {"x": 7, "y": 3} and hp["lst"] == [3, 4] and hp["c"] is False
+    assert H.hparams["a"] == 5 and hp["work_dir"] == ""
+    v = H.set_hparams("egs/bases/mid.yaml", global_hparams=False, print_hparams=False)
+    assert v["a"] == 2 and H.hparams["a"] == 5          # vocoder config does not clobber the global dict
+
+
+def test_ckpt_utils(tmp_path):
+    from conan_amd.utils.commons import ckpt_utils as K
+    from conan_amd.modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
+    vhp = configs.hifigan_hparams(True)
+    sd = {k: torch.from_numpy(v) for k, v in synth.hifigan_state_dict(vhp, 5).items()}
+    torch.save({"state_dict": {"model_gen": sd}, "global_step": 10}, tmp_path / "model_ckpt_steps_10.ckpt")
+    torch.save({"state_dict": {"model_gen": {k: v * 0 for k, v in sd.items()}}}, tmp_path / "model_ckpt_steps_2.ckpt")
+    g = HifiGanGenerator(vhp)
+    K.load_ckpt(g, str(tmp_path), "model_gen")                       # highest step wins
+    assert torch.equal(g.state_dict()["conv_pre.conv.bias"], sd["conv_pre.conv.bias"])
+    flat = {"state_dict": {f"model.{k}": v for k, v in sd.items()}}
+    torch.save(flat, tmp_path / "flat.ckpt")
+    g2 = HifiGanGenerator(vhp)
+    K.load_ckpt(g2, str(tmp_path / "flat.ckpt"), "model")
+    assert torch.equal(g2.state_dict()["conv_post.conv.weight_v"], sd["conv_post.conv.weight_v"])
+    with pytest.raises(AssertionError):
+        K.load_ckpt(g, str(tmp_path / "nothing_here"))
+
+
+def test_synth_is_deterministic_and_weightnorm_positive():
+    a = synth.hifigan_state_dict(configs.hifigan_hparams(True), 0)
+    b = synth.hifigan_state_dict(configs.hifigan_hparams(True), 0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert all((v > 0).all() for k, v in a.items() if k.endswith("weight_g"))
+    assert synth.mel(151, 1234).shape == (1, 151, 80) and synth.mel(4, 1).min() >= -6 and synth.mel(4, 1).max() <= 1.5
+
+
+def test_shard_range_partitions_streams():
+    from conan_amd.engine import shard_range
+    for total, world in ((512, 8), (10, 4), (3, 8)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
