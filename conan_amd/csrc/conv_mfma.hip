@@ -4,12 +4,12 @@
 // GEMM view:  M = n*T output rows (slot, time), N = Cout, K = ktaps*Cin.
 //   A[m][(j,ci)] = f(x[slot][t + j*dil - pad_left][ci])   gathered per tap from the activation rings
 //   B[(j,ci)][co] = packed weights [tap][ci/4][co][4]
-// Block = 256 threads (4 waves on the 4 SIMDs of a CU).  Per K-step (one tap, KS input channels) the
-// block stages an A tile [TM][KS] and a W tile [KS][TN] through LDS.  The raw global loads of step
-// s+1 are issued back-to-back right after the barrier of step s (no dependent instruction between
-// them, so their latencies overlap each other and the MFMAs of step s); the input transform
-// (branch mean, LeakyReLU, zero fill) runs on the registers when they are written to LDS at the top
-// of step s+1.  Two LDS buffers, one barrier per step.
+// Block = 512 threads = 8 waves, two per SIMD, specialised: waves 0-3 issue nothing but fragment reads and
+// MFMAs; waves 4-7 stage the tiles.  Per K-step (one tap, KS input channels) the loader waves move an A tile
+// [TM][KS] (gathered ring rows; branch mean, LeakyReLU and zero fill applied on the registers) and a W tile
+// [KS][TN] global -> registers -> LDS; their global loads are issued TWO K-steps ahead of the LDS store (two
+// register sets), back-to-back with no dependent instruction between them.  Two LDS buffers, one barrier per
+// step shared by both roles: the loaders run one step ahead of the matrix waves.
 // Fragments are read with ds_read_b128: a K-chunk of 8 feeds 4 MFMAs, lanes 0-31 carrying k 0..3 and
 // lanes 32-63 k 4..7 (the MFMA's two k-slots), so one 16-byte LDS read per operand serves 4 matrix
 // instructions.  A rows are padded by 4 floats: bank-conflict-free for the b128 lane groups.
@@ -17,6 +17,8 @@
 // shuffle of CausalUpsampleBlock3 is a pure address remap of that store (weights pre-permuted).
 // KS = 32 for the large streaming tiles; KS = 128 for the small-M (latency-bound) tiles, where a
 // longer K-step amortises the per-step load latency and barrier.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ck {
@@ -44,21 +46,23 @@ __device__ __forceinline__ unsigned tref_row(const TRef& r, int slot, const int*
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
-  static_assert(WM * WN * WK == 4, "4 waves per block");
+__global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(const ConvGroup g) {
+  static_assert(WM * WN * WK == 4, "4 compute waves per block");
   static_assert(KS == 32 || KS == 64 || KS == 128, "K-step");
   constexpr int RM = TM / WM / 32;
   constexpr int RN = TN / WN / 32;
   constexpr int SB = KS / 32;                 // 32-channel sub-blocks per K-step
-  constexpr int AQ = (TM / 32) * SB;          // A float4 staged per thread
-  constexpr int WV = (KS / 4 * TN) / 256;     // W float4 staged per thread
+  constexpr int AQ = (TM / 32) * SB;          // A float4 staged per loader thread
+  constexpr int WV = (KS / 4 * TN) / 256;     // W float4 staged per loader thread
   constexpr int NKQ = KS / 8;                 // 8-deep K chunks per step
   constexpr int LDA = KS + 4;
   constexpr int A_FLOATS = TM * LDA;
   constexpr int W_FLOATS = KS * TN;
   constexpr int RED_FLOATS = (WK > 1) ? (WK - 1) * WM * WN * RM * RN * 16 * 64 : 0;
   constexpr int STAGE_FLOATS = 2 * (A_FLOATS + W_FLOATS);
-  constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
+  constexpr int STAGE_FLOATS_TOTAL = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
+  constexpr int EPI_LD = 36;                    // epilogue transpose patch: 32 rows x 36 floats per compute wave
+  constexpr int LDS_FLOATS = STAGE_FLOATS_TOTAL + 4 * 32 * EPI_LD;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const ConvArgs& a = g.p[blockIdx.z];
@@ -72,9 +76,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
   const int* __restrict__ posp = a.pos;
   const float* __restrict__ wbase = a.w;
 
+  // Wave specialisation: waves 0-3 (one per SIMD) only read fragments and issue MFMAs; waves 4-7 (their SIMD
+  // partners) only stage tiles global -> registers -> LDS.  The two instruction streams interleave in hardware,
+  // so address arithmetic, loads, the input transform and the LDS writes run in the shadow of the (dependent,
+  // 64-cycle) MFMA chain instead of in front of it.
   const int tid = threadIdx.x;
+  const bool is_loader = tid >= 256;
+  const int ltid = tid & 255;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = (tid >> 6) & 3;
   const int wn = wave % WN;
   const int wm = (wave / WN) % WM;
   const int wk = (WK == 1) ? 0 : wave / (WN * WM);
@@ -102,81 +112,135 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
     }
   };
 
-  // ---- per-thread A staging geometry (fixed over the K loop): rows arow + 32*q, channel quad ac4
-  const int arow = tid >> 3;
-  const int ac4 = tid & 7;
-  const float* arowbase[TM / 32];
-  int abrow[TM / 32];
-  unsigned avalid = 0;
-  const bool xring = a.x[0].mode == 0;
-  {
-    const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
-    const long long xss = a.x[0].slot_stride;
-    const float* xb = a.x[0].base;
-#pragma unroll
-    for (int q = 0; q < TM / 32; ++q) {
-      const int ml = arow + 32 * q;
-      int i, t, slot, pv;
-      rowmap(ml, i, t, slot, pv);
-      abrow[q] = (xring ? pv * xrate : 0) + xoff + t;
-      arowbase[q] = xb + (long long)(xring ? slot : i) * xss;
-      avalid |= ((m0 + ml) < Mtot ? 1u : 0u) << q;
-    }
-  }
-  const long long d1 = (NSRC > 1) ? (a.x[1].base - a.x[0].base) : 0;
-  const long long d2 = (NSRC > 2) ? (a.x[2].base - a.x[0].base) : 0;
-  const int xC = a.x[0].C;
-  const int xmask = xring ? a.x[0].lmask : -1;
   const int ncb32 = a.Cin_pad >> 5;                 // 32-channel blocks per tap
   const int ncb = (ncb32 + SB - 1) / SB;            // K-steps per tap
   const int nks = ktaps * ncb;
-  const int ci4n = a.Cin_pad >> 2;
-  const float neg_mul = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
-  // per-thread W staging offsets (floats, relative to the K-step's tile base)
-  int woff[WV];
-#pragma unroll
-  for (int v = 0; v < WV; ++v) { const int idx = tid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
 
-  float4 ra[AQ][NSRC];
-  static_assert(WV >= 1 && WV <= 8, "W staging vectors per thread");
-  float4 rw0 = f4zero(), rw1 = rw0, rw2 = rw0, rw3 = rw0, rw4 = rw0, rw5 = rw0, rw6 = rw0, rw7 = rw0;  // named (not an array): keeps them in VGPRs
-  unsigned okmask = 0;     // bit (q*SB+sb): staged quad is inside the tile and inside Cin
-  int jn = 0, cbn = 0;     // (tap, channel block) of the next K-step to issue; tap index fastest so that
-                           // consecutive steps re-touch the same activation rows (L1/L2 hits)
-
-  auto issue = [&]() __attribute__((always_inline)) {
-    const int j = jn, cb = cbn;
-    okmask = 0;
+  if (is_loader) {
+    // ================================================================= loader waves
+    // per-thread A staging geometry (fixed over the K loop): rows arow + 32*q, channel quad ac4
+    const int arow = ltid >> 3;
+    const int ac4 = ltid & 7;
+    const float* arowbase[TM / 32];
+    int abrow[TM / 32];
+    unsigned avalid = 0;
+    const bool xring = a.x[0].mode == 0;
+    {
+      const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
+      const long long xss = a.x[0].slot_stride;
+      const float* xb = a.x[0].base;
 #pragma unroll
-    for (int q = 0; q < TM / 32; ++q) {
-      const int r = (abrow[q] + j * dil) & xmask;
-      const float* rowp = arowbase[q] + r * xC;
-#pragma unroll
-      for (int sb = 0; sb < SB; ++sb) {
-        const int col = (cb * SB + sb) * 32 + ac4 * 4;
-        const bool ok = ((avalid >> q) & 1u) && col < Cin;
-        const float* p = ok ? rowp + col : arowbase[q];     // always a mapped address; value dropped if !ok
-        ra[q * SB + sb][0] = *reinterpret_cast<const float4*>(p);
-        if constexpr (NSRC > 1) ra[q * SB + sb][1] = *reinterpret_cast<const float4*>(p + d1);
-        if constexpr (NSRC > 2) ra[q * SB + sb][2] = *reinterpret_cast<const float4*>(p + d2);
-        okmask |= (ok ? 1u : 0u) << (q * SB + sb);
+      for (int q = 0; q < TM / 32; ++q) {
+        const int ml = arow + 32 * q;
+        int i, t, slot, pv;
+        rowmap(ml, i, t, slot, pv);
+        abrow[q] = (xring ? pv * xrate : 0) + xoff + t;
+        arowbase[q] = xb + (long long)(xring ? slot : i) * xss;
+        avalid |= ((m0 + ml) < Mtot ? 1u : 0u) << q;
       }
     }
-    const float* wstep = wbase + ((long long)(j * ci4n + cb * (KS / 4)) * CoutP + n0) * 4;
-#define CK_W_ISSUE(V)                                                                                   \
+    const long long d1 = (NSRC > 1) ? (a.x[1].base - a.x[0].base) : 0;
+    const long long d2 = (NSRC > 2) ? (a.x[2].base - a.x[0].base) : 0;
+    const int xC = a.x[0].C;
+    const int xmask = xring ? a.x[0].lmask : -1;
+    const int ci4n = a.Cin_pad >> 2;
+    const float neg_mul = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
+    static_assert(WV >= 1 && WV <= 8, "W staging vectors per thread");
+    int woff[WV];      // per-thread W staging offsets (floats, relative to the K-step's tile base)
+#pragma unroll
+    for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
+    int jn = 0, cbn = 0;   // (tap, channel block) of the next K-step to issue; tap index fastest so that
+                           // consecutive steps re-touch the same activation rows (L1/L2 hits)
+
+    // two register sets (P, Q): loads are issued TWO K-steps ahead of their LDS store
+#define CK_DECL(S)                                                                                                      \
+    float4 ra##S[AQ][NSRC];                                                                                             \
+    float4 rw##S##0 = f4zero(), rw##S##1 = rw##S##0, rw##S##2 = rw##S##0, rw##S##3 = rw##S##0, rw##S##4 = rw##S##0,     \
+           rw##S##5 = rw##S##0, rw##S##6 = rw##S##0, rw##S##7 = rw##S##0;                                               \
+    unsigned ok##S = 0;
+    CK_DECL(P) CK_DECL(Q)
+#undef CK_DECL
+
+#define CK_W_ISSUE(S, V)                                                                                  \
     if constexpr (WV > V) {                                                                               \
       int o = woff[V];                                                                                    \
       if constexpr (KS == 128) { /* past Cin_pad: any mapped row; the A side is zero there */             \
-        const int kq4 = (tid + 256 * V) / TN;                                                             \
+        const int kq4 = (ltid + 256 * V) / TN;                                                            \
         if (cb * (KS / 4) + kq4 >= ci4n) o -= kq4 * CoutP * 4;                                            \
       }                                                                                                   \
-      rw##V = *reinterpret_cast<const float4*>(wstep + o);                                                \
+      rw##S##V = *reinterpret_cast<const float4*>(wstep + o);                                             \
     }
-    CK_W_ISSUE(0) CK_W_ISSUE(1) CK_W_ISSUE(2) CK_W_ISSUE(3) CK_W_ISSUE(4) CK_W_ISSUE(5) CK_W_ISSUE(6) CK_W_ISSUE(7)
-#undef CK_W_ISSUE
-    if (++jn == ktaps) { jn = 0; ++cbn; }
-  };
+#define CK_ISSUE(S)                                                                                       \
+    {                                                                                                     \
+      const int j = jn, cb = cbn;                                                                         \
+      ok##S = 0;                                                                                          \
+      _Pragma("unroll") for (int q = 0; q < TM / 32; ++q) {                                               \
+        const int r = (abrow[q] + j * dil) & xmask;                                                       \
+        const float* rowp = arowbase[q] + r * xC;                                                         \
+        _Pragma("unroll") for (int sb = 0; sb < SB; ++sb) {                                               \
+          const int col = (cb * SB + sb) * 32 + ac4 * 4;                                                  \
+          const bool ok = ((avalid >> q) & 1u) && col < Cin;                                              \
+          const float* p = ok ? rowp + col : arowbase[q]; /* always mapped; value dropped if !ok */       \
+          ra##S[q * SB + sb][0] = *reinterpret_cast<const float4*>(p);                                    \
+          if constexpr (NSRC > 1) ra##S[q * SB + sb][1] = *reinterpret_cast<const float4*>(p + d1);       \
+          if constexpr (NSRC > 2) ra##S[q * SB + sb][2] = *reinterpret_cast<const float4*>(p + d2);       \
+          ok##S |= (ok ? 1u : 0u) << (q * SB + sb);                                                       \
+        }                                                                                                 \
+      }                                                                                                   \
+      const float* wstep = wbase + ((long long)(j * ci4n + cb * (KS / 4)) * CoutP + n0) * 4;              \
+      CK_W_ISSUE(S, 0) CK_W_ISSUE(S, 1) CK_W_ISSUE(S, 2) CK_W_ISSUE(S, 3)                                 \
+      CK_W_ISSUE(S, 4) CK_W_ISSUE(S, 5) CK_W_ISSUE(S, 6) CK_W_ISSUE(S, 7)                                 \
+      if (++jn == ktaps) { jn = 0; ++cbn; }                                                               \
+    }
+#define CK_W_STORE(S, V) if constexpr (WV > V) *reinterpret_cast<float4*>(Ws + (ltid + 256 * V) * 4) = rw##S##V;
+#define CK_STORE(S, BUF)                                                                                  \
+    {                                                                                                     \
+      float* As = lds + (BUF) * (A_FLOATS + W_FLOATS);                                                    \
+      float* Ws = As + A_FLOATS;                                                                          \
+      _Pragma("unroll") for (int q = 0; q < TM / 32; ++q)                                                 \
+        _Pragma("unroll") for (int sb = 0; sb < SB; ++sb) {                                               \
+          float4 v = ra##S[q * SB + sb][0];                                                               \
+          if constexpr (NSRC > 1) {                                                                       \
+            const float4 v1 = ra##S[q * SB + sb][1];                                                      \
+            v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;                                           \
+            if constexpr (NSRC > 2) {                                                                     \
+              const float4 v2 = ra##S[q * SB + sb][2];                                                    \
+              v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;                                         \
+            }                                                                                             \
+            const float dn = (float)NSRC; /* xs / num_resblocks (hifigan_causal.py:329): true division */ \
+            v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;                                                   \
+          }                                                                                               \
+          /* LeakyReLU as a select on the multiplier (neg_mul == 1 when no input activation) */           \
+          v.x *= v.x > 0.f ? 1.0f : neg_mul; v.y *= v.y > 0.f ? 1.0f : neg_mul;                           \
+          v.z *= v.z > 0.f ? 1.0f : neg_mul; v.w *= v.w > 0.f ? 1.0f : neg_mul;                           \
+          if (!((ok##S >> (q * SB + sb)) & 1u)) v = f4zero();                                             \
+          *reinterpret_cast<float4*>(As + (arow + 32 * q) * LDA + sb * 32 + ac4 * 4) = v;                 \
+        }                                                                                                 \
+      CK_W_STORE(S, 0) CK_W_STORE(S, 1) CK_W_STORE(S, 2) CK_W_STORE(S, 3)                                 \
+      CK_W_STORE(S, 4) CK_W_STORE(S, 5) CK_W_STORE(S, 6) CK_W_STORE(S, 7)                                 \
+    }
 
+    CK_ISSUE(P)
+    if (nks > 1) CK_ISSUE(Q)
+    for (int ks = 0; ks < nks; ks += 2) {
+      CK_STORE(P, 0)
+      if (ks + 2 < nks) CK_ISSUE(P)
+      __syncthreads();                       // step ks staged (buffer 0)
+      if (ks + 1 < nks) {
+        CK_STORE(Q, 1)
+        if (ks + 3 < nks) CK_ISSUE(Q)
+        __syncthreads();                     // step ks+1 staged (buffer 1)
+      }
+    }
+#undef CK_STORE
+#undef CK_W_STORE
+#undef CK_ISSUE
+#undef CK_W_ISSUE
+    if constexpr (WK > 1) { __syncthreads(); __syncthreads(); }   // the compute waves' split-K reduction barriers
+    return;
+  }
+
+  // ===================================================================== compute waves
   f32x16 acc[RM][RN];
 #pragma unroll
   for (int rm = 0; rm < RM; ++rm)
@@ -185,44 +249,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
 
-  issue();
   for (int ks = 0; ks < nks; ++ks) {
-    float* As = lds + (ks & 1) * (A_FLOATS + W_FLOATS);
-    float* Ws = As + A_FLOATS;
-    // ---- transform + store the staged registers
-#pragma unroll
-    for (int q = 0; q < TM / 32; ++q)
-#pragma unroll
-      for (int sb = 0; sb < SB; ++sb) {
-        float4 v = ra[q * SB + sb][0];
-        if constexpr (NSRC > 1) {
-          const float4 v1 = ra[q * SB + sb][1];
-          v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
-          if constexpr (NSRC > 2) {
-            const float4 v2 = ra[q * SB + sb][2];
-            v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-          }
-          const float dn = (float)NSRC;       // xs / num_resblocks (hifigan_causal.py:329): true division
-          v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
-        }
-        // LeakyReLU as a select on the multiplier (neg_mul == 1 when no input activation)
-        v.x *= v.x > 0.f ? 1.0f : neg_mul;
-        v.y *= v.y > 0.f ? 1.0f : neg_mul;
-        v.z *= v.z > 0.f ? 1.0f : neg_mul;
-        v.w *= v.w > 0.f ? 1.0f : neg_mul;
-        if (!((okmask >> (q * SB + sb)) & 1u)) v = f4zero();
-        *reinterpret_cast<float4*>(As + (arow + 32 * q) * LDA + sb * 32 + ac4 * 4) = v;
-      }
-#define CK_W_STORE(V) if constexpr (WV > V) *reinterpret_cast<float4*>(Ws + (tid + 256 * V) * 4) = rw##V;
-    CK_W_STORE(0) CK_W_STORE(1) CK_W_STORE(2) CK_W_STORE(3) CK_W_STORE(4) CK_W_STORE(5) CK_W_STORE(6) CK_W_STORE(7)
-#undef CK_W_STORE
-    __syncthreads();
-#ifdef CK_ABLATE
-    if (ks + 1 < nks && !(a.ksplit_unused & 1)) issue();
-    if (a.ksplit_unused & 2) continue;
-#else
-    if (ks + 1 < nks) issue();
-#endif
+    const float* As = lds + (ks & 1) * (A_FLOATS + W_FLOATS);
+    const float* Ws = As + A_FLOATS;
+    __syncthreads();                         // step ks staged by the loader waves
 #pragma unroll
     for (int kc = 0; kc < NKQ / WK; ++kc) {
       const int kq = kc * WK + wk;      // fixed trip count: no divergent control flow around the MFMAs
@@ -272,22 +302,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
     }
   }
 
-  // ---- epilogue: per lane the column (co) is fixed per rn, the 16 accumulator registers walk the rows.
-  // Pass 1 resolves every row's addresses and issues all residual / mask loads back-to-back (one latency,
-  // not one per row); pass 2 applies bias/scale/activation/residual/mask and stores 128-byte row segments.
-  constexpr int NR = RM * 16;
+  // ---- epilogue.  Each 32x32 accumulator tile (column on the lane, 16 rows in registers) is transposed through a
+  // wave-private LDS patch so that every lane owns 4 consecutive output channels of one row: residual loads and
+  // output stores become 16-byte accesses (4 store instructions per tile instead of 16 -- the store tail is
+  // issue-bound, not bandwidth-bound) and the row -> stream/time/slot arithmetic is done for 4 rows per lane
+  // instead of 16.  Every run-time option and the activation are uniform branches around straight-line passes, so
+  // the loads of a pass are issued back-to-back and waited for once.
   const int shuf = a.shuffle_r;
   const int Cq = Cout / shuf;
-  int ocol[RN], ojj[RN];
-  float bco[RN];
-  bool cok[RN];
-#pragma unroll
-  for (int rn = 0; rn < RN; ++rn) {
-    const int co = n0 + (wn * RN + rn) * 32 + l31;
-    cok[rn] = co < Cout;
-    bco[rn] = (a.bias && cok[rn]) ? a.bias[co] : 0.f;
-    if (shuf > 1) { ojj[rn] = co / Cq; ocol[rn] = co - ojj[rn] * Cq; } else { ojj[rn] = 0; ocol[rn] = co; }
-  }
   const float oscale = a.out_scale, oslope = a.out_slope;
   const int oact = a.out_act;
   const int* lens = a.lens;
@@ -295,58 +317,161 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvGroup g) {
   const int yC = a.y.C, ymask = yring ? a.y.lmask : -1, yrate = a.y.rate, yoff = a.y.off;
   const long long yss = a.y.slot_stride;
   float* const ybase0 = a.y.base;
-  const bool has_res = a.has_res != 0, has_mask = (a.has_m1 | a.has_m2) != 0, has_bvec = a.bvec != nullptr;
+  const bool has_res = a.has_res != 0, has_bvec = a.bvec != nullptr;
+  const bool vec_ok = ((Cout & 3) == 0) && ((yC & 3) == 0) && ((Cq & 3) == 0);
+  float* patch = lds + STAGE_FLOATS_TOTAL + wave * (32 * EPI_LD);
+  const int er = lane >> 3;          // row within an 8-row group
+  const int ec4 = lane & 7;          // channel quad within the 32-wide tile
 
-  int yrow[NR];          // first output row (before the per-column shuffle offset), -1 = skip
-  int ysel[NR];          // batch index / slot that owns the row (selects the y base)
-  float rv[NR][RN];
-  float mkv[NR];
+  auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int rm = r >> 4, e = r & 15;
-    const int ml = (wm * RM + rm) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-    int i, t, slot, pv;
-    rowmap(ml, i, t, slot, pv);
-    bool ok = (m0 + ml) < Mtot;
-    if (lens) ok = ok && t < lens[i];
-    yrow[r] = ok ? ((yring ? pv * yrate : 0) + yoff + t * shuf) : -1;
-    ysel[r] = yring ? slot : i;
-    mkv[r] = 1.f;
+    for (int rm = 0; rm < RM; ++rm) {
+      // (1) the lane's 4 rows: tile row er + 8g -> (batch index, time, slot, position)
+      int ri[4], rt[4], rslot[4], rpos[4];
+      unsigned okbits = 0;
+      if (fast) {
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn) rv[r][rn] = 0.f;
-    if (has_res) {
-      const TRef& rr = a.res; const int sidx = rr.mode == 0 ? slot : i;
-      const float* resrow = rr.base + (long long)sidx * rr.slot_stride + (long long)tref_row(rr, sidx, posp, t) * rr.C;
+        for (int gq = 0; gq < 4; ++gq) {
+          const int ml = (wm * RM + rm) * 32 + er + 8 * gq;
+          const int tt = t0 + ml;
+          const bool w = tt >= T;
+          ri[gq] = w ? i1 : i0; rt[gq] = w ? tt - T : tt; rslot[gq] = w ? slotB : slotA; rpos[gq] = w ? posB : posA;
+          okbits |= ((m0 + ml) < Mtot ? 1u : 0u) << gq;
+        }
+      } else {
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn) if (cok[rn]) rv[r][rn] = resrow[n0 + (wn * RN + rn) * 32 + l31];
+        for (int gq = 0; gq < 4; ++gq) {
+          const int m = m0 + (wm * RM + rm) * 32 + er + 8 * gq;
+          const int i = m / T;
+          rt[gq] = m - i * T;
+          okbits |= (m < Mtot ? 1u : 0u) << gq;
+          ri[gq] = i < nslot ? i : nslot - 1;
+        }
+        if (slots) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rslot[gq] = slots[ri[gq]];
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rslot[gq] = ri[gq];
+        }
+        if (posp) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rpos[gq] = posp[rslot[gq]];
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rpos[gq] = 0;
+        }
+      }
+      if (lens) {
+        int rl[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) rl[gq] = lens[ri[gq]];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) if (rt[gq] >= rl[gq]) okbits &= ~(1u << gq);
+      }
+      float mkv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.has_m1) {
+        const TRef q = a.m1;
+        const bool qring = q.mode == 0;
+        const int qmask = qring ? q.lmask : -1;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int sidx = qring ? rslot[gq] : ri[gq];
+          mkv[gq] = q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+        }
+      }
+      if (a.has_m2) {
+        const TRef q = a.m2;
+        const bool qring = q.mode == 0;
+        const int qmask = qring ? q.lmask : -1;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int sidx = qring ? rslot[gq] : ri[gq];
+          mkv[gq] *= q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+        }
+      }
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const int co4 = n0 + (wn * RN + rn) * 32 + ec4 * 4;      // first of the lane's 4 channels
+        const bool cok = co4 < Cout;
+        const int cc = cok ? co4 : 0;
+        // (2) residual + style vector (16-byte loads where the layout allows)
+        float4 rv[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) rv[gq] = f4zero();
+        if (has_res) {
+          const TRef rr = a.res;
+          const bool rring = rr.mode == 0;
+          const int rmask = rring ? rr.lmask : -1;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int sidx = rring ? rslot[gq] : ri[gq];
+            const int row = ((rring ? rpos[gq] * rr.rate : 0) + rr.off + rt[gq]) & rmask;
+            const float* p = rr.base + (long long)sidx * rr.slot_stride + row * rr.C + cc;
+            if (vec_ok && (rr.C & 3) == 0) rv[gq] = *reinterpret_cast<const float4*>(p);
+            else { rv[gq].x = p[0]; rv[gq].y = cc + 1 < Cout ? p[1] : 0.f; rv[gq].z = cc + 2 < Cout ? p[2] : 0.f; rv[gq].w = cc + 3 < Cout ? p[3] : 0.f; }
+          }
+        }
+        if (has_bvec) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const float* bv = a.bvec + (long long)rslot[gq] * a.bvec_stride + cc;
+            rv[gq].x += bv[0]; rv[gq].y += cc + 1 < Cout ? bv[1] : 0.f; rv[gq].z += cc + 2 < Cout ? bv[2] : 0.f; rv[gq].w += cc + 3 < Cout ? bv[3] : 0.f;
+          }
+        }
+        float4 bq = f4zero();
+        if (a.bias) { bq.x = a.bias[cc]; bq.y = a.bias[cc + 1]; bq.z = a.bias[cc + 2]; bq.w = a.bias[cc + 3]; }   // bias is padded to Cout_pad
+        // (3) transpose the accumulator tile through the wave's LDS patch
+#pragma unroll
+        for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * lh) * EPI_LD + l31] = acc[rm][rn][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 v[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) v[gq] = *reinterpret_cast<const float4*>(patch + (er + 8 * gq) * EPI_LD + ec4 * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (4) bias -> scale -> activation -> (+style vector, +residual) -> mask -> store
+        int jj = 0, ocol = cc;
+        if (shuf > 1) { jj = cc / Cq; ocol = cc - jj * Cq; }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          float o[4] = {v[gq].x + bq.x, v[gq].y + bq.y, v[gq].z + bq.z, v[gq].w + bq.w};
+          const float r4[4] = {rv[gq].x, rv[gq].y, rv[gq].z, rv[gq].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float x = o[k] * oscale;
+            if constexpr (ACT == ACT_LRELU) x = x > 0.f ? x : x * oslope;
+            if constexpr (ACT == ACT_RELU) x = x > 0.f ? x : 0.f;
+            if constexpr (ACT == ACT_GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+            if constexpr (ACT == ACT_TANH) x = tanhf(x);
+            o[k] = (x + r4[k]) * mkv[gq];
+          }
+          if (((okbits >> gq) & 1u) && cok) {
+            float* ybase = ybase0 + (long long)(yring ? rslot[gq] : ri[gq]) * yss;
+            const int yrow = ((yring ? rpos[gq] * yrate : 0) + yoff + rt[gq] * shuf + jj) & ymask;
+            float* dst = ybase + yrow * yC + ocol;
+            if (vec_ok) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (cc + k < Cout) {
+                  int j2 = 0, oc2 = cc + k;
+                  if (shuf > 1) { j2 = oc2 / Cq; oc2 -= j2 * Cq; }
+                  ybase[(((yring ? rpos[gq] * yrate : 0) + yoff + rt[gq] * shuf + j2) & ymask) * yC + oc2] = o[k];
+                }
+              }
+            }
+          }
+        }
+      }
     }
-    if (has_bvec) {
-      const float* bv = a.bvec + (long long)slot * a.bvec_stride;
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) if (cok[rn]) rv[r][rn] += bv[n0 + (wn * RN + rn) * 32 + l31];
-    }
-    if (has_mask) {
-      float mk = 1.f;
-      if (a.has_m1) { const TRef& q = a.m1; int sidx = q.mode == 0 ? slot : i; mk *= q.base[(long long)sidx * q.slot_stride + tref_row(q, sidx, posp, t)]; }
-      if (a.has_m2) { const TRef& q = a.m2; int sidx = q.mode == 0 ? slot : i; mk *= q.base[(long long)sidx * q.slot_stride + tref_row(q, sidx, posp, t)]; }
-      mkv[r] = mk;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    const int rm = r >> 4, e = r & 15;
-    if (yrow[r] < 0) continue;
-    float* ybase = ybase0 + (long long)ysel[r] * yss;
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn) {
-      if (!cok[rn]) continue;
-      float v = acc[rm][rn][e] + bco[rn];
-      v *= oscale;
-      v = apply_act(v, oact, oslope);
-      v += rv[r][rn];          // bvec (added after the activation) + residual
-      v *= mkv[r];
-      ybase[((yrow[r] + ojj[rn]) & ymask) * yC + ocol[rn]] = v;
-    }
+  };
+  switch (oact) {
+    case ACT_LRELU: epilogue(std::integral_constant<int, ACT_LRELU>{}); break;
+    case ACT_RELU: epilogue(std::integral_constant<int, ACT_RELU>{}); break;
+    case ACT_GELU: epilogue(std::integral_constant<int, ACT_GELU>{}); break;
+    case ACT_TANH: epilogue(std::integral_constant<int, ACT_TANH>{}); break;
+    default: epilogue(std::integral_constant<int, ACT_NONE>{}); break;
   }
 }
 
@@ -357,7 +482,7 @@ int conv_cfg_tn(int cfg) { return kTN[cfg]; }
 
 template <int NSRC>
 static void launch_conv_n(const ConvGroup& g, int cfg, dim3 grid, hipStream_t st) {
-  dim3 block(256);
+  dim3 block(512);
   switch (cfg) {
     case CFG_128x64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
     case CFG_64x64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
