@@ -55,11 +55,20 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
   constexpr int AQ = (TM / 32) * SB;          // A float4 staged per loader thread
   constexpr int WV = (KS / 4 * TN) / 256;     // W float4 staged per loader thread
   constexpr int NKQ = KS / 8;                 // 8-deep K chunks per step
-  constexpr int LDA = KS + 4;
+  // NSRC == 1: tiles go global -> LDS directly (global_load_lds, no VGPR round trip, no ds_write); the LDS image
+  // of a wave instruction is lane-linear, so A rows are unpadded and bank conflicts are removed by an XOR swizzle
+  // of the 16-byte chunks applied on the per-lane SOURCE address and again on the fragment read; three buffers
+  // (loads run two K-steps ahead).  NSRC > 1 (mean of the resblock branches) keeps the register-staged loader.
+  constexpr bool GLDS = (NSRC == 1);
+  constexpr int NBUF = GLDS ? 3 : 2;
+  constexpr int LDA = GLDS ? KS : KS + 4;
+  constexpr int CPR = KS / 4;                  // 16-byte chunks per A row
+  constexpr int RPI = 64 / CPR;                // A rows covered by one wave-wide 1 KiB load
+  constexpr int NA = TM / RPI / 4;             // A load instructions per loader wave per K-step
   constexpr int A_FLOATS = TM * LDA;
   constexpr int W_FLOATS = KS * TN;
   constexpr int RED_FLOATS = (WK > 1) ? (WK - 1) * WM * WN * RM * RN * 16 * 64 : 0;
-  constexpr int STAGE_FLOATS = 2 * (A_FLOATS + W_FLOATS);
+  constexpr int STAGE_FLOATS = NBUF * (A_FLOATS + W_FLOATS);
   constexpr int STAGE_FLOATS_TOTAL = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
   constexpr int EPI_LD = 36;                    // epilogue transpose patch: 32 rows x 36 floats per compute wave
   constexpr int LDS_FLOATS = STAGE_FLOATS_TOTAL + 4 * 32 * EPI_LD;
@@ -118,6 +127,73 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
 
   if (is_loader) {
     // ================================================================= loader waves
+    if constexpr (GLDS) {
+      const int lwave = __builtin_amdgcn_readfirstlane(ltid >> 6);
+      const int prow = lane / CPR;                     // row inside one wave instruction
+      const int pchunk = lane % CPR;                   // physical chunk written by this lane
+      const float* arowbase[NA];
+      int abrow[NA], acol[NA];
+      unsigned avalid = 0;
+      const bool xring = a.x[0].mode == 0;
+      {
+        const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
+        const long long xss = a.x[0].slot_stride;
+        const float* xb = a.x[0].base;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+          const int ml = (u * 4 + lwave) * RPI + prow;
+          int i, t, slot, pv;
+          rowmap(ml, i, t, slot, pv);
+          abrow[u] = (xring ? pv * xrate : 0) + xoff + t;
+          arowbase[u] = xb + (long long)(xring ? slot : i) * xss;
+          avalid |= ((m0 + ml) < Mtot ? 1u : 0u) << u;
+          const int sw = (KS == 32) ? ((ml >> 1) & 7) : (ml & 15);
+          acol[u] = (pchunk ^ sw) * 4;                 // logical channel offset inside the K-step
+        }
+      }
+      const int xC = a.x[0].C;
+      const int xmask = xring ? a.x[0].lmask : -1;
+      const int ci4n = a.Cin_alloc >> 2;
+      int woff[WV];
+#pragma unroll
+      for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
+      int jn = 0, cbn = 0;
+      auto issue = [&](int buf) __attribute__((always_inline)) {
+        const int j = jn, cb = cbn;
+        float* As = lds + buf * (A_FLOATS + W_FLOATS);
+        float* Ws = As + A_FLOATS;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+          const int r = (abrow[u] + j * dil) & xmask;
+          const int col = cb * KS + acol[u];
+          const bool ok = ((avalid >> u) & 1u) && col < Cin;
+          // rows past the tile and channels past Cin read a mapped address: their products are discarded
+          // (row never stored) or multiplied by the zero-padded weight rows
+          const float* p = ok ? arowbase[u] + r * xC + col : arowbase[u];
+          __builtin_amdgcn_global_load_lds(p, As + ((u * 4 + lwave) * RPI) * LDA, 16, 0, 0);
+        }
+        const float* wstep = wbase + ((long long)(j * ci4n + cb * (KS / 4)) * CoutP + n0) * 4;
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+          const int o = woff[v];
+          __builtin_amdgcn_global_load_lds(wstep + o, Ws + (v * 4 + lwave) * 256, 16, 0, 0);
+        }
+        if (++jn == ktaps) { jn = 0; ++cbn; }
+      };
+      constexpr int NPER = NA + WV;          // loads per wave per K-step
+      static_assert(NPER <= 31, "vmcnt budget");
+      issue(0);
+      if (nks > 1) issue(1);
+      for (int ks = 0; ks < nks; ++ks) {
+        // step ks must have landed; the loads of step ks+1 may stay in flight
+        if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // B(ks): tile ks visible; every matrix wave is done with tile ks-1
+        if (ks + 2 < nks) issue((ks + 2) % 3);   // overwrites the buffer of tile ks-1
+      }
+      if constexpr (WK > 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+      return;
+    } else {
     // per-thread A staging geometry (fixed over the K loop): rows arow + 32*q, channel quad ac4
     const int arow = ltid >> 3;
     const int ac4 = ltid & 7;
@@ -143,7 +219,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
     const long long d2 = (NSRC > 2) ? (a.x[2].base - a.x[0].base) : 0;
     const int xC = a.x[0].C;
     const int xmask = xring ? a.x[0].lmask : -1;
-    const int ci4n = a.Cin_pad >> 2;
+    const int ci4n = a.Cin_alloc >> 2;
     const float neg_mul = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
     static_assert(WV >= 1 && WV <= 8, "W staging vectors per thread");
     int woff[WV];      // per-thread W staging offsets (floats, relative to the K-step's tile base)
@@ -163,11 +239,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
 
 #define CK_W_ISSUE(S, V)                                                                                  \
     if constexpr (WV > V) {                                                                               \
-      int o = woff[V];                                                                                    \
-      if constexpr (KS == 128) { /* past Cin_pad: any mapped row; the A side is zero there */             \
-        const int kq4 = (ltid + 256 * V) / TN;                                                            \
-        if (cb * (KS / 4) + kq4 >= ci4n) o -= kq4 * CoutP * 4;                                            \
-      }                                                                                                   \
+      const int o = woff[V]; /* rows past Cin_pad exist (Cin_alloc) and are zero */                       \
       rw##S##V = *reinterpret_cast<const float4*>(wstep + o);                                             \
     }
 #define CK_ISSUE(S)                                                                                       \
@@ -238,6 +310,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
 #undef CK_W_ISSUE
     if constexpr (WK > 1) { __syncthreads(); __syncthreads(); }   // the compute waves' split-K reduction barriers
     return;
+    }  // register-staged loader
   }
 
   // ===================================================================== compute waves
@@ -249,17 +322,32 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
 
+  const float neg_mul_c = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
+  int bufc = 0;
   for (int ks = 0; ks < nks; ++ks) {
-    const float* As = lds + (ks & 1) * (A_FLOATS + W_FLOATS);
+    const float* As = lds + bufc * (A_FLOATS + W_FLOATS);
     const float* Ws = As + A_FLOATS;
-    __syncthreads();                         // step ks staged by the loader waves
+    if (++bufc == NBUF) bufc = 0;
+    if constexpr (GLDS) asm volatile("s_barrier" ::: "memory");   // B(ks): tile ks landed in LDS (clobber: no LDS read may move above it)
+    else __syncthreads();                                // step ks staged by the loader waves
 #pragma unroll
     for (int kc = 0; kc < NKQ / WK; ++kc) {
       const int kq = kc * WK + wk;      // fixed trip count: no divergent control flow around the MFMAs
       float4 af[RM], bf[RN];
 #pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
-        af[rm] = *reinterpret_cast<const float4*>(As + ((wm * RM + rm) * 32 + l31) * LDA + kq * 8 + lh * 4);
+      for (int rm = 0; rm < RM; ++rm) {
+        const int R = (wm * RM + rm) * 32 + l31;
+        if constexpr (GLDS) {
+          const int sw = (KS == 32) ? ((R >> 1) & 7) : (R & 15);
+          float4 v = *reinterpret_cast<const float4*>(As + R * LDA + (((kq * 2 + lh) ^ sw) * 4));
+          // the loader cannot transform on the way: LeakyReLU of the conv input is applied here
+          v.x *= v.x > 0.f ? 1.0f : neg_mul_c; v.y *= v.y > 0.f ? 1.0f : neg_mul_c;
+          v.z *= v.z > 0.f ? 1.0f : neg_mul_c; v.w *= v.w > 0.f ? 1.0f : neg_mul_c;
+          af[rm] = v;
+        } else {
+          af[rm] = *reinterpret_cast<const float4*>(As + R * LDA + kq * 8 + lh * 4);
+        }
+      }
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn)
         bf[rn] = *reinterpret_cast<const float4*>(Ws + ((kq * 2 + lh) * TN + (wn * RN + rn) * 32 + l31) * 4);
@@ -277,7 +365,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
 
   // ---- intra-block split-K reduction through LDS
   if constexpr (WK > 1) {
-    __syncthreads();
+    if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
     constexpr int PER_WAVE = RM * RN * 16 * 64;
     if (wk > 0) {
       float* dst = lds + ((wk - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
@@ -288,7 +376,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
 #pragma unroll
           for (int e = 0; e < 16; ++e) dst[((rm * RN + rn) * 16 + e) * 64 + lane] = acc[rm][rn][e];
     }
-    __syncthreads();
+    if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
     if (wk > 0) return;
 #pragma unroll
     for (int k2 = 1; k2 < WK; ++k2) {
@@ -487,11 +575,11 @@ static void launch_conv_n(const ConvGroup& g, int cfg, dim3 grid, hipStream_t st
     case CFG_128x64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
     case CFG_64x64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
     case CFG_128x32: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1, 32, NSRC>), grid, block, 0, st, g); break;
-    case CFG_32x64_K2: hipLaunchKernelGGL((conv_mfma_kernel<32, 64, 1, 2, 2, 128, NSRC>), grid, block, 0, st, g); break;
+    case CFG_32x64_K2: hipLaunchKernelGGL((conv_mfma_kernel<32, 64, 1, 2, 2, 64, NSRC>), grid, block, 0, st, g); break;
     case CFG_32x32_K4: hipLaunchKernelGGL((conv_mfma_kernel<32, 32, 1, 1, 4, 128, NSRC>), grid, block, 0, st, g); break;
     case CFG_64x32_K2: hipLaunchKernelGGL((conv_mfma_kernel<64, 32, 2, 1, 2, 32, NSRC>), grid, block, 0, st, g); break;
     case CFG_64x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 64, NSRC>), grid, block, 0, st, g); break;
-    case CFG_128x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 64, NSRC>), grid, block, 0, st, g); break;
+    case CFG_128x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
     case CFG_128x32_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1, 64, NSRC>), grid, block, 0, st, g); break;
     default: break;
   }

@@ -50,7 +50,8 @@ float* conan_ctx::vec(const std::string& name) const {
   return it->second;
 }
 
-// W is PyTorch Conv1d layout [Cout][Cin][k] (Linear: k = 1).  Packed: [k][Cin_pad/4][Cout_pad][4].
+// W is PyTorch Conv1d layout [Cout][Cin][k] (Linear: k = 1).  Packed: [k][Cin_alloc/4][Cout_pad][4] with Cin_alloc =
+// Cin rounded up to 128 (zero rows), so a 128-deep K-step may over-read past Cin_pad (= Cin rounded up to 32).
 // shuffle_r > 1: output channel c*r + j of the reference (hifigan_causal.py:186-188) is stored at
 // packed column j*(Cout/r) + c, which makes the pixel shuffle a plain row remap of the store.
 void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, const float* bias, int Cout, int Cin,
@@ -59,9 +60,10 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
   PackedConv pc;
   pc.Cin = Cin; pc.Cout = Cout; pc.k = k; pc.shuffle_r = shuffle_r;
   pc.Cin_pad = ch::round_up(Cin, 32);
+  pc.Cin_alloc = ch::round_up(Cin, 128);
   pc.Cout_pad = ch::round_up(Cout, 64);
   const int Cq = Cout / shuffle_r;
-  std::vector<float> P((size_t)k * (pc.Cin_pad / 4) * pc.Cout_pad * 4, 0.f);
+  std::vector<float> P((size_t)k * (pc.Cin_alloc / 4) * pc.Cout_pad * 4, 0.f);
   std::vector<float> B((size_t)pc.Cout_pad, 0.f);
   for (int co = 0; co < Cout; ++co) {
     int col = co;
@@ -69,7 +71,7 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
     if (bias) B[col] = bias[co];
     for (int ci = 0; ci < Cin; ++ci)
       for (int j = 0; j < k; ++j)
-        P[(((size_t)j * (pc.Cin_pad / 4) + ci / 4) * pc.Cout_pad + col) * 4 + (ci & 3)] = W[((size_t)co * Cin + ci) * k + j];
+        P[(((size_t)j * (pc.Cin_alloc / 4) + ci / 4) * pc.Cout_pad + col) * 4 + (ci & 3)] = W[((size_t)co * Cin + ci) * k + j];
   }
   pc.w = upload(P);
   pc.bias = upload(B);

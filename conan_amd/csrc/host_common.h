@@ -33,7 +33,7 @@ struct HostTensor {
 struct PackedConv {
   float* w = nullptr;
   float* bias = nullptr;   // [Cout_pad] (zeros when the layer has no bias)
-  int Cin = 0, Cin_pad = 0, Cout = 0, Cout_pad = 0, k = 1;
+  int Cin = 0, Cin_pad = 0, Cin_alloc = 0, Cout = 0, Cout_pad = 0, k = 1;
   int shuffle_r = 1;
 };
 

@@ -50,7 +50,7 @@ struct ConvArgs {
   int out_act;
   float out_scale, out_slope;
   int shuffle_r;
-  int ksplit_unused;
+  int Cin_alloc;        // packed rows per tap (Cin rounded up to 128, zero filled): K-steps may over-read safely
 };
 
 struct ConvGroup {      // up to 3 independent problems in one launch (blockIdx.z)

@@ -10,7 +10,7 @@ ConvArgs conan_streams::mk(const PackedConv& pc, const TRef& x, const TRef& y, i
   a.x[0] = x; a.x[1] = x; a.x[2] = x; a.nsrc = 1;
   a.y = y; a.res = ch::null_ref(); a.m1 = ch::null_ref(); a.m2 = ch::null_ref();
   a.w = pc.w; a.bias = pc.bias; a.bvec = nullptr; a.slots = d_slots; a.pos = pos; a.lens = nullptr;
-  a.Cin = pc.Cin; a.Cin_pad = pc.Cin_pad; a.Cout = pc.Cout; a.Cout_pad = pc.Cout_pad;
+  a.Cin = pc.Cin; a.Cin_pad = pc.Cin_pad; a.Cin_alloc = pc.Cin_alloc; a.Cout = pc.Cout; a.Cout_pad = pc.Cout_pad;
   a.ktaps = pc.k; a.dil = dil; a.pad_left = pad_left < 0 ? (pc.k - 1) * dil : pad_left;
   a.T = T; a.n = n; a.in_act = ck::ACT_NONE; a.in_slope = 0.f; a.out_act = ck::ACT_NONE; a.out_scale = 1.f; a.out_slope = 0.f;
   a.shuffle_r = pc.shuffle_r;

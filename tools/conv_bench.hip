@@ -36,8 +36,8 @@ int main(int argc, char** argv) {
     size_t xfl = (size_t)nslots * Lr * s.Cin, yfl = (size_t)nslots * Lr * s.Cout;
     float *x, *y, *w, *b; int *slots, *pos;
     CHECK(hipMalloc(&x, xfl * 4 * 3)); CHECK(hipMalloc(&y, yfl * 4 * 3));
-    int Cin_pad = (s.Cin + 31) / 32 * 32, Cout_pad = (s.Cout + 63) / 64 * 64;
-    size_t wfl = (size_t)s.k * Cin_pad * Cout_pad;
+    int Cin_pad = (s.Cin + 31) / 32 * 32, Cin_alloc = (s.Cin + 127) / 128 * 128, Cout_pad = (s.Cout + 63) / 64 * 64;
+    size_t wfl = (size_t)s.k * Cin_alloc * Cout_pad;
     CHECK(hipMalloc(&w, wfl * 4 * 3)); CHECK(hipMalloc(&b, Cout_pad * 4));
     CHECK(hipMemset(x, 0, xfl * 4 * 3)); CHECK(hipMemset(w, 0, wfl * 4 * 3)); CHECK(hipMemset(b, 0, Cout_pad * 4));
     std::vector<float> hx(xfl); for (auto& v : hx) v = (float)rand() / RAND_MAX - 0.5f;
@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
       ck::TRef yr = xr; yr.base = y + p * yfl; yr.slot_stride = (long long)Lr * s.Cout; yr.C = s.Cout;
       a.x[0] = a.x[1] = a.x[2] = xr; a.nsrc = 1; a.y = yr; a.res = xr; a.has_res = (s.Cin == s.Cout);
       a.w = w + p * wfl; a.bias = b; a.slots = slots; a.pos = pos;
-      a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cout = s.Cout; a.Cout_pad = Cout_pad; a.ktaps = s.k; a.dil = s.dil; a.pad_left = (s.k - 1) * s.dil;
+      a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cin_alloc = Cin_alloc; a.Cout = s.Cout; a.Cout_pad = Cout_pad; a.ktaps = s.k; a.dil = s.dil; a.pad_left = (s.k - 1) * s.dil;
       a.T = s.T; a.n = s.n; a.in_act = ck::ACT_LRELU; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1; a.ksplit_unused = ablate;
     }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
