@@ -45,8 +45,23 @@ __device__ __forceinline__ unsigned tref_row(const TRef& r, int slot, const int*
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+template <int TM, int TN, int WK, int KS, int NSRC>
+struct ConvLds {
+  static constexpr bool GLDS = (NSRC == 1);
+  static constexpr int NBUF = GLDS ? 3 : 2;
+  static constexpr int LDA = GLDS ? KS : KS + 4;
+  static constexpr int STAGE = NBUF * (TM * LDA + KS * TN);
+  static constexpr int EPI_LD = 36;                 // epilogue transpose patch: 32 rows x 36 floats per compute wave
+  static constexpr int PATCH = 4 * 32 * EPI_LD;
+  static constexpr int RED = (WK > 1) ? (WK - 1) * TM * TN : 0;   // split-K partial tiles of waves wk > 0
+  static constexpr int TOTAL = STAGE + PATCH + RED;
+};
+
+// One output tile (rows m0.., columns n0..) of one problem.  `gbuf` is the LDS ring position of the tile's first
+// K-step: it is carried from tile to tile so that a persistent block's loader waves can start the next tile's
+// loads while the matrix waves are still in the previous tile's epilogue.
 template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
-__global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(const ConvGroup g) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const int n0, float* lds, int& gbuf, const int tile) {
   static_assert(WM * WN * WK == 4, "4 compute waves per block");
   static_assert(KS == 32 || KS == 64 || KS == 128, "K-step");
   constexpr int RM = TM / WM / 32;
@@ -67,20 +82,15 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
   constexpr int NA = TM / RPI / 4;             // A load instructions per loader wave per K-step
   constexpr int A_FLOATS = TM * LDA;
   constexpr int W_FLOATS = KS * TN;
-  constexpr int RED_FLOATS = (WK > 1) ? (WK - 1) * WM * WN * RM * RN * 16 * 64 : 0;
-  constexpr int STAGE_FLOATS = NBUF * (A_FLOATS + W_FLOATS);
-  constexpr int STAGE_FLOATS_TOTAL = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
-  constexpr int EPI_LD = 36;                    // epilogue transpose patch: 32 rows x 36 floats per compute wave
-  constexpr int LDS_FLOATS = STAGE_FLOATS_TOTAL + 4 * 32 * EPI_LD;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  using L = ConvLds<TM, TN, WK, KS, NSRC>;
+  static_assert(L::RED == ((WK > 1) ? (WK - 1) * WM * WN * RM * RN * 16 * 64 : 0), "split-K reduction region");
+  constexpr int STAGE_FLOATS_TOTAL = L::STAGE;      // [staging ring | epilogue patches | split-K reduction]
+  constexpr int EPI_LD = L::EPI_LD;
+  float* const red = lds + L::STAGE + L::PATCH;
 
-  const ConvArgs& a = g.p[blockIdx.z];
   // ---- launch-uniform scalars, read once (keeps the K loop free of kernarg re-loads)
   const int T = a.T, nslot = a.n, ktaps = a.ktaps, dil = a.dil, Cin = a.Cin, CoutP = a.Cout_pad, Cout = a.Cout;
   const int Mtot = nslot * T;
-  const int m0 = blockIdx.x * TM;
-  const int n0 = blockIdx.y * TN;
-  if (m0 >= Mtot || n0 >= Cout) return;
   const int* __restrict__ slots = a.slots;
   const int* __restrict__ posp = a.pos;
   const float* __restrict__ wbase = a.w;
@@ -182,15 +192,31 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
       };
       constexpr int NPER = NA + WV;          // loads per wave per K-step
       static_assert(NPER <= 31, "vmcnt budget");
-      issue(0);
-      if (nks > 1) issue(1);
+#ifdef CK_STAMPS
+      unsigned long long l_vm = 0, l_bar = 0, l_iss = 0, lt = __builtin_amdgcn_s_memtime();
+#define CK_LSTAMP(acc) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - lt; lt = t_; }
+#else
+#define CK_LSTAMP(acc)
+#endif
+      const int g0 = gbuf;
+      gbuf = (gbuf + nks) % 3;
+      issue(g0);
+      if (nks > 1) issue((g0 + 1) % 3);
+      CK_LSTAMP(l_iss)
       for (int ks = 0; ks < nks; ++ks) {
         // step ks must have landed; the loads of step ks+1 may stay in flight
         if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CK_LSTAMP(l_vm)
         __builtin_amdgcn_s_barrier();        // B(ks): tile ks visible; every matrix wave is done with tile ks-1
-        if (ks + 2 < nks) issue((ks + 2) % 3);   // overwrites the buffer of tile ks-1
+        CK_LSTAMP(l_bar)
+        if (ks + 2 < nks) issue((g0 + ks + 2) % 3);   // overwrites the buffer of K-step ks-1
+        CK_LSTAMP(l_iss)
       }
+#ifdef CK_STAMPS
+      if (a.dbg && tile == 1 && ltid == 0) { a.dbg[8] = l_vm; a.dbg[9] = l_bar; a.dbg[10] = l_iss; }
+#endif
+#undef CK_LSTAMP
       if constexpr (WK > 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
       return;
     } else {
@@ -292,6 +318,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
       CK_W_STORE(S, 4) CK_W_STORE(S, 5) CK_W_STORE(S, 6) CK_W_STORE(S, 7)                                 \
     }
 
+    gbuf = (gbuf + nks) % 2;     // (register-staged build runs one tile per block: the ring always starts at 0)
     CK_ISSUE(P)
     if (nks > 1) CK_ISSUE(Q)
     for (int ks = 0; ks < nks; ks += 2) {
@@ -323,13 +350,23 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
       for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
 
   const float neg_mul_c = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
-  int bufc = 0;
+  int bufc = gbuf;
+  gbuf = (gbuf + nks) % NBUF;
+#ifdef CK_STAMPS
+  unsigned long long c_wait = 0, c_comp = 0, ct = __builtin_amdgcn_s_memtime();
+  const unsigned long long c_begin = ct;
+  const unsigned long long c_rt0 = __builtin_amdgcn_s_memrealtime();
+#define CK_CSTAMP(acc) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - ct; ct = t_; }
+#else
+#define CK_CSTAMP(acc)
+#endif
   for (int ks = 0; ks < nks; ++ks) {
     const float* As = lds + bufc * (A_FLOATS + W_FLOATS);
     const float* Ws = As + A_FLOATS;
     if (++bufc == NBUF) bufc = 0;
     if constexpr (GLDS) asm volatile("s_barrier" ::: "memory");   // B(ks): tile ks landed in LDS (clobber: no LDS read may move above it)
     else __syncthreads();                                // step ks staged by the loader waves
+    CK_CSTAMP(c_wait)
 #pragma unroll
     for (int kc = 0; kc < NKQ / WK; ++kc) {
       const int kq = kc * WK + wk;      // fixed trip count: no divergent control flow around the MFMAs
@@ -361,14 +398,21 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
           acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rm].w, bf[rn].w, acc[rm][rn], 0, 0, 0);
         }
     }
+#ifdef CK_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+#endif
+    CK_CSTAMP(c_comp)
   }
+#ifdef CK_STAMPS
+  const unsigned long long c_kend = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- intra-block split-K reduction through LDS
   if constexpr (WK > 1) {
     if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
     constexpr int PER_WAVE = RM * RN * 16 * 64;
     if (wk > 0) {
-      float* dst = lds + ((wk - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
+      float* dst = red + ((wk - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -380,7 +424,7 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
     if (wk > 0) return;
 #pragma unroll
     for (int k2 = 1; k2 < WK; ++k2) {
-      const float* src = lds + ((k2 - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
+      const float* src = red + ((k2 - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -561,6 +605,28 @@ __global__ __launch_bounds__(512, (KS == 128) ? 2 : 4) void conv_mfma_kernel(con
     case ACT_TANH: epilogue(std::integral_constant<int, ACT_TANH>{}); break;
     default: epilogue(std::integral_constant<int, ACT_NONE>{}); break;
   }
+#ifdef CK_STAMPS
+  if (a.dbg && tile == 1 && tid == 0) {
+    a.dbg[0] = c_wait; a.dbg[1] = c_comp; a.dbg[2] = (unsigned long long)nks; a.dbg[3] = c_kend - c_begin; a.dbg[4] = __builtin_amdgcn_s_memtime() - c_kend; a.dbg[5] = __builtin_amdgcn_s_memtime() - c_begin; a.dbg[6] = __builtin_amdgcn_s_memrealtime() - c_rt0;
+  }
+#endif
+#undef CK_CSTAMP
+}
+
+// Persistent launch: the grid is at most the number of co-resident blocks; every block walks the tile list
+// tile = blockIdx.x, blockIdx.x + gridDim.x, ...  Tiles are ordered problem by problem, longest K first (the three
+// resblock branches of a grouped launch have k = 11 / 7 / 3), n-tile fastest (neighbours share activation rows).
+template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
+__global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4 > 80 * 1024) ? 2 : 4) void conv_mfma_kernel(const ConvGroup g) {
+  __shared__ __attribute__((aligned(16))) float lds[ConvLds<TM, TN, WK, KS, NSRC>::TOTAL];
+  int gbuf = 0;
+  for (int tile = blockIdx.x; tile < g.tile_start[3]; tile += gridDim.x) {
+    const int p = (tile >= g.tile_start[1] ? 1 : 0) + (tile >= g.tile_start[2] ? 1 : 0);
+    const int local = tile - g.tile_start[p];
+    const int tn = g.tiles_n[p];
+    const int mt = local / tn, nt = local - mt * tn;
+    conv_tile<TM, TN, WM, WN, WK, KS, NSRC>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile);
+  }
 }
 
 static const int kTM[NUM_CFG] = {128, 64, 128, 32, 32, 64, 64, 128, 128};
@@ -568,37 +634,57 @@ static const int kTN[NUM_CFG] = {64, 64, 32, 64, 32, 32, 64, 64, 32};
 int conv_cfg_tm(int cfg) { return kTM[cfg]; }
 int conv_cfg_tn(int cfg) { return kTN[cfg]; }
 
+template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
+static void launch_one(const ConvGroup& g, int num_cu, hipStream_t st) {
+  constexpr int lds_bytes = ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4;
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  int grid = g.tile_start[3];
+  if (NSRC == 1 && grid > num_cu * per_cu) grid = num_cu * per_cu;     // persistent blocks (direct-to-LDS build only)
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, WK, KS, NSRC>), dim3(grid), dim3(512), 0, st, g);
+}
+
 template <int NSRC>
-static void launch_conv_n(const ConvGroup& g, int cfg, dim3 grid, hipStream_t st) {
-  dim3 block(512);
+static void launch_conv_n(const ConvGroup& g, int cfg, int num_cu, hipStream_t st) {
   switch (cfg) {
-    case CFG_128x64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
-    case CFG_64x64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
-    case CFG_128x32: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1, 32, NSRC>), grid, block, 0, st, g); break;
-    case CFG_32x64_K2: hipLaunchKernelGGL((conv_mfma_kernel<32, 64, 1, 2, 2, 64, NSRC>), grid, block, 0, st, g); break;
-    case CFG_32x32_K4: hipLaunchKernelGGL((conv_mfma_kernel<32, 32, 1, 1, 4, 128, NSRC>), grid, block, 0, st, g); break;
-    case CFG_64x32_K2: hipLaunchKernelGGL((conv_mfma_kernel<64, 32, 2, 1, 2, 32, NSRC>), grid, block, 0, st, g); break;
-    case CFG_64x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2, 1, 64, NSRC>), grid, block, 0, st, g); break;
-    case CFG_128x64_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 1, 32, NSRC>), grid, block, 0, st, g); break;
-    case CFG_128x32_KS64: hipLaunchKernelGGL((conv_mfma_kernel<128, 32, 4, 1, 1, 64, NSRC>), grid, block, 0, st, g); break;
+    case CFG_128x64: launch_one<128, 64, 2, 2, 1, 32, NSRC>(g, num_cu, st); break;
+    case CFG_64x64: launch_one<64, 64, 2, 2, 1, 32, NSRC>(g, num_cu, st); break;
+    case CFG_128x32: launch_one<128, 32, 4, 1, 1, 32, NSRC>(g, num_cu, st); break;
+    case CFG_32x64_K2: launch_one<32, 64, 1, 2, 2, 64, NSRC>(g, num_cu, st); break;
+    case CFG_32x32_K4: launch_one<32, 32, 1, 1, 4, 128, NSRC>(g, num_cu, st); break;
+    case CFG_64x32_K2: launch_one<64, 32, 2, 1, 2, 32, NSRC>(g, num_cu, st); break;
+    case CFG_64x64_KS64: launch_one<64, 64, 2, 2, 1, 64, NSRC>(g, num_cu, st); break;
+    case CFG_128x64_KS64: launch_one<128, 64, 2, 2, 1, 32, NSRC>(g, num_cu, st); break;
+    case CFG_128x32_KS64: launch_one<128, 32, 4, 1, 1, 64, NSRC>(g, num_cu, st); break;
     default: break;
   }
 }
 
-void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st) {
-  int maxM = 0, maxN = 0;
-  for (int p = 0; p < nprob; ++p) {
-    int M = g.p[p].n * g.p[p].T;
-    if (M > maxM) maxM = M;
-    if (g.p[p].Cout > maxN) maxN = g.p[p].Cout;
-  }
-  if (maxM == 0) return;
+void launch_conv(const ConvGroup& gin, int nprob, int cfg, hipStream_t st, int num_cu) {
+  ConvGroup g = gin;
   const int TM = kTM[cfg], TN = kTN[cfg];
-  dim3 grid((maxM + TM - 1) / TM, (maxN + TN - 1) / TN, nprob);
+  // longest-K problem first
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < nprob; ++i)
+    for (int j = i + 1; j < nprob; ++j) {
+      const long long ki = (long long)g.p[idx[i]].ktaps * g.p[idx[i]].Cin_pad, kj = (long long)g.p[idx[j]].ktaps * g.p[idx[j]].Cin_pad;
+      if (kj > ki) { int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+    }
+  int acc = 0;
+  for (int q = 0; q < 3; ++q) {
+    g.tile_start[q] = acc;
+    if (q < nprob) {
+      const ConvArgs& a = g.p[idx[q]];
+      const int tm = (a.n * a.T + TM - 1) / TM, tn = (a.Cout + TN - 1) / TN;
+      g.order[q] = idx[q]; g.tiles_n[q] = tn;
+      acc += tm * tn;
+    } else { g.order[q] = 0; g.tiles_n[q] = 1; }
+  }
+  g.tile_start[3] = acc;
+  if (acc == 0) return;
   const int nsrc = g.p[0].nsrc;
-  if (nsrc == 1) launch_conv_n<1>(g, cfg, grid, st);
-  else if (nsrc == 2) launch_conv_n<2>(g, cfg, grid, st);
-  else launch_conv_n<3>(g, cfg, grid, st);
+  if (nsrc == 1) launch_conv_n<1>(g, cfg, num_cu, st);
+  else if (nsrc == 2) launch_conv_n<2>(g, cfg, num_cu, st);
+  else launch_conv_n<3>(g, cfg, num_cu, st);
 }
 
 }  // namespace ck

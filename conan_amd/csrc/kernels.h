@@ -51,10 +51,16 @@ struct ConvArgs {
   float out_scale, out_slope;
   int shuffle_r;
   int Cin_alloc;        // packed rows per tap (Cin rounded up to 128, zero filled): K-steps may over-read safely
+#ifdef CK_STAMPS
+  unsigned long long* dbg;   // developer build only (tools/conv_bench -DCK_STAMPS): s_memtime stamps of block 1
+#endif
 };
 
-struct ConvGroup {      // up to 3 independent problems in one launch (blockIdx.z)
+struct ConvGroup {      // up to 3 independent problems in one launch
   ConvArgs p[3];
+  int tile_start[4];    // filled by launch_conv: first tile of the q-th scheduled problem; [3] = total tiles
+  int tiles_n[3];       // n-tiles of the q-th scheduled problem
+  int order[3];         // q-th scheduled problem -> index into p[] (longest K first)
 };
 
 // Tile configurations of conv_mfma (block = 256 threads = 4 waves).
@@ -62,7 +68,7 @@ enum ConvCfg { CFG_128x64 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_32x64_K2 = 3, 
                CFG_64x64_KS64 = 6, CFG_128x64_KS64 = 7, CFG_128x32_KS64 = 8, NUM_CFG };
 int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);
-void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
+void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num_cu = 256);
 
 // LayerNorm over the channel axis of each row:
 //   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])

@@ -116,12 +116,14 @@ void launch_embed(const EmbedArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------ Emformer attention
-// one block per slot, one wave per head; lanes own keys (rc | cached left context | utterance), each lane
-// keeps its key/value head-slice in registers and re-uses it for every query token; softmax and the
-// weighted value sum are 64-lane shuffle reductions.
+// one block per slot, one wave per head.  The slot's queries and this step's keys/values are staged into LDS with
+// one batch of loads; lanes own keys (rc | cached left context | utterance) and keep their key/value head-slice in
+// registers for all query tokens; softmax and the weighted value sum are 64-lane shuffle reductions.
 constexpr int EMF_MAX_DH = 16;
 constexpr int EMF_MAX_KPL = 2;   // keys per lane: up to 128 keys
+constexpr int EMF_MAX_QD = 16 * 512;
 __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float esm[];
   const int i = blockIdx.x;
   const int slot = a.slots[i];
   const int Q = a.R + a.U;
@@ -130,36 +132,53 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
   const int Lc = past < a.LC ? past : a.LC;
   const int nk = a.R + Lc + a.U;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sq = esm;                    // [Q][D]
+  float* skv = esm + Q * a.D;         // [Q][2D]
+  float* so = skv + Q * 2 * a.D;      // [Q][D]
   const float* kvb = a.kv + (long long)i * Q * 2 * a.D;
+  const float* qb = a.q + (long long)i * Q * a.D;
+  for (int e = threadIdx.x; e < Q * a.D; e += blockDim.x) sq[e] = qb[e] * a.scaling;
+  for (int e = threadIdx.x; e < Q * 2 * a.D; e += blockDim.x) skv[e] = kvb[e];
   const float* kr = a.kring + (long long)slot * a.ring_slot_stride;
   const float* vr = a.vring + (long long)slot * a.ring_slot_stride;
-  if (h < a.H) {
-    float kreg[EMF_MAX_KPL][EMF_MAX_DH], vreg[EMF_MAX_KPL][EMF_MAX_DH];
+  float kreg[EMF_MAX_KPL][EMF_MAX_DH], vreg[EMF_MAX_KPL][EMF_MAX_DH];
+  if (h < a.H) {     // cached left-context keys come straight from the rings (issued before the barrier)
 #pragma unroll
     for (int s = 0; s < EMF_MAX_KPL; ++s) {
       const int kk = lane + 64 * s;
-      const float *kp = kvb, *vp = kvb;
-      if (kk < a.R) { kp = kvb + (long long)kk * 2 * a.D; vp = kp + a.D; }
-      else if (kk < a.R + Lc) {
-        unsigned r = (unsigned)(past - Lc + (kk - a.R)) & (unsigned)a.lmask;
-        kp = kr + (long long)r * a.D; vp = vr + (long long)r * a.D;
-      } else if (kk < nk) { kp = kvb + (long long)(a.R + (kk - a.R - Lc)) * 2 * a.D; vp = kp + a.D; }
+      const bool cached = kk >= a.R && kk < a.R + Lc;
+      const unsigned r = (unsigned)(past - Lc + (kk - a.R)) & (unsigned)a.lmask;
+      const float* kp = kr + (long long)(cached ? r : 0) * a.D + h * dh;
+      const float* vp = vr + (long long)(cached ? r : 0) * a.D + h * dh;
 #pragma unroll
       for (int d = 0; d < EMF_MAX_DH; ++d) {
-        const bool ok = kk < nk && d < dh;
-        kreg[s][d] = ok ? kp[h * dh + d] : 0.f;
-        vreg[s][d] = ok ? vp[h * dh + d] : 0.f;
+        kreg[s][d] = (cached && d < dh) ? kp[d] : 0.f;
+        vreg[s][d] = (cached && d < dh) ? vp[d] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  if (h < a.H) {
+#pragma unroll
+    for (int s = 0; s < EMF_MAX_KPL; ++s) {   // this step's right-context / utterance keys from LDS
+      const int kk = lane + 64 * s;
+      int tok = -1;
+      if (kk < a.R) tok = kk;
+      else if (kk >= a.R + Lc && kk < nk) tok = a.R + (kk - a.R - Lc);
+      if (tok >= 0) {
+#pragma unroll
+        for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) { kreg[s][d] = skv[tok * 2 * a.D + h * dh + d]; vreg[s][d] = skv[tok * 2 * a.D + a.D + h * dh + d]; }
       }
     }
     for (int qi = 0; qi < Q; ++qi) {
-      const float* qp = a.q + ((long long)i * Q + qi) * a.D + h * dh;
+      const float* qp = sq + qi * a.D + h * dh;
       float sc[EMF_MAX_KPL];
       float mx = -INFINITY;
 #pragma unroll
       for (int s = 0; s < EMF_MAX_KPL; ++s) {
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) acc += (qp[d] * a.scaling) * kreg[s][d];
+        for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) acc += qp[d] * kreg[s][d];
         sc[s] = (lane + 64 * s) < nk ? acc : -INFINITY;
         mx = fmaxf(mx, sc[s]);
       }
@@ -169,7 +188,6 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
       for (int s = 0; s < EMF_MAX_KPL; ++s) { sc[s] = (lane + 64 * s) < nk ? expf(sc[s] - mx) : 0.f; sum += sc[s]; }
       sum = wave_sum(sum);
       const float inv = 1.0f / sum;
-      float* op = a.out + ((long long)i * Q + qi) * a.D + h * dh;
 #pragma unroll
       for (int d = 0; d < EMF_MAX_DH; ++d) {
         if (d < dh) {
@@ -177,26 +195,29 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
 #pragma unroll
           for (int s = 0; s < EMF_MAX_KPL; ++s) o += sc[s] * vreg[s][d];
           o = wave_sum(o);
-          if (lane == 0) op[d] = o * inv;
+          if (lane == 0) so[qi * a.D + h * dh + d] = o * inv;
         }
       }
     }
   }
   __syncthreads();
+  float* ob = a.out + (long long)i * Q * a.D;
+  for (int e = threadIdx.x; e < Q * a.D; e += blockDim.x) ob[e] = so[e];
   // append the U new utterance keys/values (rows past .. past+U-1; not read above)
   float* kw = a.kring + (long long)slot * a.ring_slot_stride;
   float* vw = a.vring + (long long)slot * a.ring_slot_stride;
   for (int e = threadIdx.x; e < a.U * a.D; e += blockDim.x) {
     const int u = e / a.D, c = e - u * a.D;
     const unsigned r = (unsigned)(past + u) & (unsigned)a.lmask;
-    const float* src = kvb + (long long)(a.R + u) * 2 * a.D;
-    kw[(long long)r * a.D + c] = src[c];
-    vw[(long long)r * a.D + c] = src[a.D + c];
+    kw[(long long)r * a.D + c] = skv[(a.R + u) * 2 * a.D + c];
+    vw[(long long)r * a.D + c] = skv[(a.R + u) * 2 * a.D + a.D + c];
   }
 }
 void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64 * a.H), 0, st, a);
+  const int Q = a.R + a.U;
+  const size_t smem = (size_t)Q * a.D * 4 * sizeof(float);
+  hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64 * a.H), smem, st, a);
 }
 
 // ------------------------------------------------------------------------------------ cross attention

@@ -19,12 +19,14 @@ ConvArgs conan_streams::mk(const PackedConv& pc, const TRef& x, const TRef& y, i
 }
 
 int conan_streams::pick_cfg(int M, int N, int nprob) const {
-  // largest tile that still gives every CU a block; below that the small-M (KS=128) shapes, and when even
-  // those cannot fill the chip the one with the most blocks (these problems are latency-bound).
-  const int wide[] = {ck::CFG_128x64, ck::CFG_64x64, ck::CFG_32x64_K2, ck::CFG_32x32_K4};
+  // Measured on MI355X (tools/conv_bench.hip): 64x64 tiles (2 persistent blocks per CU) beat 128x64 (1 block per CU:
+  // its 3-deep direct-to-LDS ring needs 92 KB) on every streaming layer; below one block per CU the small-M shapes
+  // with intra-block split-K take over, and when even those cannot fill the chip the one with the most blocks
+  // (those layers are latency-bound).
+  const int wide[] = {ck::CFG_64x64, ck::CFG_32x64_K2, ck::CFG_32x32_K4};
   const int narrow[] = {ck::CFG_128x32, ck::CFG_64x32_K2, ck::CFG_32x32_K4};
   const int* order = N <= 32 ? narrow : wide;
-  const int cnt = N <= 32 ? 3 : 4;
+  const int cnt = 3;
   long long need = ctx->num_cu;
   int best = order[cnt - 1];
   for (int k = 0; k < cnt; ++k) {
@@ -36,7 +38,7 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
 }
 
 void conan_streams::launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st) {
-  if (!prof_on) { ck::launch_conv(g, nprob, cfg, st); return; }
+  if (!prof_on) { ck::launch_conv(g, nprob, cfg, st, ctx->num_cu); return; }
   if (prof_used == prof_ev.size()) {
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
@@ -44,7 +46,7 @@ void conan_streams::launch_group(const ConvGroup& g, int nprob, int cfg, hipStre
   }
   auto& ev = prof_ev[prof_used++];
   HIP_CHECK(hipEventRecord(ev.first, st));
-  ck::launch_conv(g, nprob, cfg, st);
+  ck::launch_conv(g, nprob, cfg, st, ctx->num_cu);
   HIP_CHECK(hipEventRecord(ev.second, st));
   for (int p = 0; p < nprob; ++p)
     prof_flops += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;

@@ -15,6 +15,13 @@ int main(int argc, char** argv) {
   int ablate = argc > 1 ? atoi(argv[1]) : 0;
   std::vector<Shape> shapes = {
     {"stage1 rb (B64: M=2048,C=256,k7)", 64, 32, 256, 256, 7, 3, 3, ck::CFG_64x64},
+    {"stage1 mixed k=3/7/11 64x64", 64, 32, 256, 256, -1, 3, 3, ck::CFG_64x64},
+    {"stage1 mixed k 64x64 KS64", 64, 32, 256, 256, -1, 3, 3, ck::CFG_64x64_KS64},
+    {"stage1 mixed k 32x64 K2", 64, 32, 256, 256, -1, 3, 3, ck::CFG_32x64_K2},
+    {"stage2 mixed k 64x64", 64, 160, 128, 128, -1, 3, 3, ck::CFG_64x64},
+    {"stage3 mixed k 64x64", 64, 640, 64, 64, -1, 3, 3, ck::CFG_64x64},
+    {"stage3 mixed k 128x64", 64, 640, 64, 64, -1, 3, 3, ck::CFG_128x64},
+    {"stage4 mixed k 128x32", 64, 1280, 32, 32, -1, 3, 3, ck::CFG_128x32},
     {"stage2 rb (M=10240,C=128,k7)", 64, 160, 128, 128, 7, 3, 3, ck::CFG_128x64},
     {"stage2 rb 64x64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_64x64},
     {"stage2 rb 64x64 KS64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_64x64_KS64},
@@ -35,9 +42,13 @@ int main(int argc, char** argv) {
     int Lr = 1; while (Lr < s.T + 64) Lr <<= 1;
     size_t xfl = (size_t)nslots * Lr * s.Cin, yfl = (size_t)nslots * Lr * s.Cout;
     float *x, *y, *w, *b; int *slots, *pos;
+#ifdef CK_STAMPS
+    unsigned long long* dbg; CHECK(hipMalloc(&dbg, 128)); CHECK(hipMemset(dbg, 0, 128));
+#endif
     CHECK(hipMalloc(&x, xfl * 4 * 3)); CHECK(hipMalloc(&y, yfl * 4 * 3));
     int Cin_pad = (s.Cin + 31) / 32 * 32, Cin_alloc = (s.Cin + 127) / 128 * 128, Cout_pad = (s.Cout + 63) / 64 * 64;
-    size_t wfl = (size_t)s.k * Cin_alloc * Cout_pad;
+    const int kmax = s.k < 0 ? 11 : s.k;
+    size_t wfl = (size_t)kmax * Cin_alloc * Cout_pad;
     CHECK(hipMalloc(&w, wfl * 4 * 3)); CHECK(hipMalloc(&b, Cout_pad * 4));
     CHECK(hipMemset(x, 0, xfl * 4 * 3)); CHECK(hipMemset(w, 0, wfl * 4 * 3)); CHECK(hipMemset(b, 0, Cout_pad * 4));
     std::vector<float> hx(xfl); for (auto& v : hx) v = (float)rand() / RAND_MAX - 0.5f;
@@ -54,8 +65,12 @@ int main(int argc, char** argv) {
       ck::TRef yr = xr; yr.base = y + p * yfl; yr.slot_stride = (long long)Lr * s.Cout; yr.C = s.Cout;
       a.x[0] = a.x[1] = a.x[2] = xr; a.nsrc = 1; a.y = yr; a.res = xr; a.has_res = (s.Cin == s.Cout);
       a.w = w + p * wfl; a.bias = b; a.slots = slots; a.pos = pos;
-      a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cin_alloc = Cin_alloc; a.Cout = s.Cout; a.Cout_pad = Cout_pad; a.ktaps = s.k; a.dil = s.dil; a.pad_left = (s.k - 1) * s.dil;
-      a.T = s.T; a.n = s.n; a.in_act = ck::ACT_LRELU; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1; a.ksplit_unused = ablate;
+      a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cin_alloc = Cin_alloc; a.Cout = s.Cout; a.Cout_pad = Cout_pad; const int kk = s.k < 0 ? (p == 0 ? 3 : (p == 1 ? 7 : 11)) : s.k;
+      a.ktaps = kk; a.dil = s.dil; a.pad_left = (kk - 1) * s.dil;
+      a.T = s.T; a.n = s.n; a.in_act = ck::ACT_LRELU; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1;
+#ifdef CK_STAMPS
+      a.dbg = dbg;
+#endif
     }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int it = 0; it < 3; ++it) ck::launch_conv(g, s.nprob, s.cfg, 0);
@@ -65,8 +80,12 @@ int main(int argc, char** argv) {
     for (int it = 0; it < iters; ++it) ck::launch_conv(g, s.nprob, s.cfg, 0);
     CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-    double fl = 2.0 * s.n * s.T * (double)s.Cout * s.k * s.Cin * s.nprob;
+    double fl = 2.0 * s.n * s.T * (double)s.Cout * (s.k < 0 ? 21.0 / 3.0 : (double)s.k) * s.Cin * s.nprob;
     printf("%-40s cfg=%d  %8.1f us  %7.2f TFLOP/s (%.1f%% of 157.3)\n", s.name, s.cfg, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
+#ifdef CK_STAMPS
+    { unsigned long long h[16]; CHECK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost)); double n = (double)h[2];
+      printf("      [block 1] matrix wave: barrier-wait/step=%.0f mfma/step=%.0f kloop=%llu epilogue=%llu | loader: vmcnt-wait/step=%.0f barrier/step=%.0f issue/step=%.0f (cycles); in-kernel clock %.2f GHz\n", h[0] / n, h[1] / n, h[3], h[4], h[8] / n, h[9] / n, h[10] / n, (double)h[5] / (double)h[6] * 0.1); }
+#endif
     hipFree(x); hipFree(y); hipFree(w); hipFree(b); hipFree(slots); hipFree(pos);
   }
   return 0;
