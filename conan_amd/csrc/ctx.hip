@@ -89,25 +89,36 @@ void conan_ctx::pack_from_keys(const std::string& name, const std::string& wkey,
 
 // weight_norm fold: w = g * v / ||v||_2 per output channel (torch._weight_norm(v, g, 0));
 // accepts an already-folded '<prefix>.weight' (remove_weight_norm checkpoints, hifigan_causal.py:335).
-void conan_ctx::pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r) {
-  if (has(prefix + ".weight")) { pack_from_keys(name, prefix + ".weight", prefix + ".bias", shuffle_r); return; }
+void conan_ctx::fold_weightnorm(const std::string& prefix, std::vector<float>& W, std::vector<float>& bias, int& Cout, int& Cin, int& k) const {
+  if (has(prefix + ".weight")) {
+    const HostTensor& w = get(prefix + ".weight");
+    Cout = (int)w.shape[0]; Cin = (int)w.shape[1]; k = (int)w.shape[2];
+    W = w.data; bias = get(prefix + ".bias").data;
+    return;
+  }
   const HostTensor& v = get(prefix + ".weight_v");
   const HostTensor& g = get(prefix + ".weight_g");
   const HostTensor& b = get(prefix + ".bias");
-  int Cout = (int)v.shape[0], Cin = (int)v.shape[1], k = (int)v.shape[2];
+  Cout = (int)v.shape[0]; Cin = (int)v.shape[1]; k = (int)v.shape[2];
   if (g.numel() != Cout || b.numel() != Cout) throw Error(CONAN_ERR_SHAPE, "bad weight_g/bias: " + prefix);
-  std::vector<float> W(v.data.size());
+  W.resize(v.data.size());
+  bias = b.data;
   const size_t per = (size_t)Cin * k;
   for (int co = 0; co < Cout; ++co) {
-    // norm accumulated in fp32 like torch's norm kernel would round to; double accumulate then round keeps
-    // the fold within 1 ulp of torch._weight_norm
+    // ||v|| accumulated in double and rounded once: within 1 ulp of torch._weight_norm's fp32 norm
     double s = 0.0;
     for (size_t e = 0; e < per; ++e) { double x = v.data[co * per + e]; s += x * x; }
-    float nrm = (float)std::sqrt(s);
-    float gg = g.data[co];
+    const float nrm = (float)std::sqrt(s);
+    const float gg = g.data[co];
     for (size_t e = 0; e < per; ++e) W[co * per + e] = v.data[co * per + e] * (gg / nrm);
   }
-  pack_conv(name, W, b.data.data(), Cout, Cin, k, shuffle_r);
+}
+
+void conan_ctx::pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r) {
+  std::vector<float> W, b;
+  int Cout, Cin, k;
+  fold_weightnorm(prefix, W, b, Cout, Cin, k);
+  pack_conv(name, W, b.data(), Cout, Cin, k, shuffle_r);
 }
 
 void conan_ctx::upload_vec(const std::string& name, const std::string& key) { vecs[name] = upload(get(key).data); }
@@ -127,6 +138,17 @@ void conan_ctx::finalize_hifigan() {
       }
   }
   pack_weightnorm("voc.conv_post", P + "conv_post.conv");
+  {  // conv_post also as a [k][C] vector for the VALU kernel (Cout == 1)
+    std::vector<float> W, b;
+    int Cout, Cin, k;
+    fold_weightnorm(P + "conv_post.conv", W, b, Cout, Cin, k);
+    if (Cout != 1) throw Error(CONAN_ERR_SHAPE, "conv_post must have one output channel");
+    std::vector<float> T((size_t)k * Cin);
+    for (int ci = 0; ci < Cin; ++ci) for (int j = 0; j < k; ++j) T[(size_t)j * Cin + ci] = W[(size_t)ci * k + j];
+    vecs["voc.conv_post.w"] = upload(T);
+    scalars["voc.conv_post.b"] = b[0];
+    scalars["voc.conv_post.k"] = (float)k;
+  }
 }
 
 void conan_ctx::finalize_emformer() {

@@ -74,6 +74,7 @@ struct conan_ctx {
   std::map<std::string, ch::HostTensor> raw;
   std::map<std::string, ch::PackedConv> convs;
   std::map<std::string, float*> vecs;
+  std::map<std::string, float> scalars;
   std::vector<void*> allocs;
   int64_t weight_bytes = 0;
   int hop = 1;
@@ -89,6 +90,7 @@ struct conan_ctx {
                  int shuffle_r = 1);
   void pack_from_keys(const std::string& name, const std::string& wkey, const std::string& bkey, int shuffle_r = 1);
   void pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r = 1);
+  void fold_weightnorm(const std::string& prefix, std::vector<float>& W, std::vector<float>& bias, int& Cout, int& Cin, int& k) const;
   void upload_vec(const std::string& name, const std::string& key);
   void finalize_hifigan();
   void finalize_conan();

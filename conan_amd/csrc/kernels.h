@@ -145,6 +145,15 @@ struct PitchHeadArgs {
 };
 void launch_pitch_head(const PitchHeadArgs& a, hipStream_t st);
 
+// y = leaky_relu((x0 + x1 + x2) / nsrc): the MRF mean of HifiGanGenerator.forward (hifigan_causal.py:324-331) with the
+// following LeakyReLU, materialised once so that the consuming conv runs the single-source direct-to-LDS path.
+struct MeanActArgs { TRef x[3]; TRef y; const int* slots; const int* pos; int nsrc, T, n, C; float slope; };
+void launch_mean_act(const MeanActArgs& a, hipStream_t st);
+// conv_post (CausalConv1d(C -> 1, k) + tanh, hifigan_causal.py:331-333) as a VALU dot-product kernel: N = 1 would
+// waste 31/32 of an MFMA tile.  x is the already activated input ring; w is [k][C]; optional pre-tanh tap.
+struct ConvPostArgs { TRef x; const float* w; float bias; float* wav; float* pre; const int* slots; const int* pos; int T, n, C, k; };
+void launch_conv_post(const ConvPostArgs& a, hipStream_t st);
+
 struct ArgmaxArgs { const float* x; int* idx; int rows, C; };
 void launch_argmax(const ArgmaxArgs& a, hipStream_t st);
 

@@ -338,6 +338,81 @@ void launch_pitch_head(const PitchHeadArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(pitch_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a, (float)mn, (float)(mxx - mn));
 }
 
+// ------------------------------------------------------------------------------------ MRF mean + LeakyReLU
+__global__ __launch_bounds__(256) void mean_act_kernel(const MeanActArgs a) {
+  const int c4n = a.C >> 2;
+  const long long total = (long long)a.n * a.T * c4n;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    const long long m = e / c4n;
+    const int i = (int)(m / a.T), t = (int)(m - (long long)i * a.T);
+    const int slot = a.slots ? a.slots[i] : i;
+    float4 v = *reinterpret_cast<const float4*>(trowptr(a.x[0], i, slot, a.pos, t) + c4 * 4);
+    if (a.nsrc > 1) {
+      const float4 v1 = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
+      v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+      if (a.nsrc > 2) {
+        const float4 v2 = *reinterpret_cast<const float4*>(trowptr(a.x[2], i, slot, a.pos, t) + c4 * 4);
+        v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+      }
+      const float dn = (float)a.nsrc;      // xs / num_resblocks: true division like the reference
+      v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
+    }
+    v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+    v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+    *reinterpret_cast<float4*>(trowptr(a.y, i, slot, a.pos, t) + c4 * 4) = v;
+  }
+}
+void launch_mean_act(const MeanActArgs& a, hipStream_t st) {
+  const long long total = (long long)a.n * a.T * (a.C >> 2);
+  if (total <= 0) return;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(mean_act_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------ conv_post + tanh
+constexpr int CP_TILE = 256;
+__global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float cps[];     // [(CP_TILE + k - 1)][C + 1] then w[k][C]
+  const int tiles = (a.T + CP_TILE - 1) / CP_TILE;
+  const int i = blockIdx.x / tiles, tile = blockIdx.x - i * tiles;
+  const int slot = a.slots ? a.slots[i] : i;
+  const int t0 = tile * CP_TILE;
+  const int rows = CP_TILE + a.k - 1;
+  const int ld = a.C + 1;
+  float* sw = cps + rows * ld;
+  for (int e = threadIdx.x; e < a.k * a.C; e += blockDim.x) sw[e] = a.w[e];
+  const int c4n = a.C >> 2;
+  for (int e = threadIdx.x; e < rows * c4n; e += blockDim.x) {
+    const int r = e / c4n, c4 = e - r * c4n;
+    const int t = t0 + r - (a.k - 1);            // may be negative: ring history (zeros before stream start)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < a.T) v = *reinterpret_cast<const float4*>(trowptr(a.x, i, slot, a.pos, t) + c4 * 4);
+    float* d = cps + r * ld + c4 * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int t = t0 + threadIdx.x;
+  if (t >= a.T) return;
+  float acc = 0.f;
+  for (int j = 0; j < a.k; ++j) {
+    const float* xr = cps + (threadIdx.x + j) * ld;
+    const float* wr = sw + j * a.C;
+    for (int c = 0; c < a.C; ++c) acc += xr[c] * wr[c];
+  }
+  acc += a.bias;
+  const long long o = (long long)i * a.T + t;
+  if (a.pre) a.pre[o] = acc;
+  a.wav[o] = tanhf(acc);
+}
+void launch_conv_post(const ConvPostArgs& a, hipStream_t st) {
+  if (a.n * a.T <= 0) return;
+  const int tiles = (a.T + CP_TILE - 1) / CP_TILE;
+  const size_t smem = ((size_t)(CP_TILE + a.k - 1) * (a.C + 1) + (size_t)a.k * a.C) * sizeof(float);
+  hipLaunchKernelGGL(conv_post_kernel, dim3(a.n * tiles), dim3(256), smem, st, a);
+}
+
 // ------------------------------------------------------------------------------------ argmax
 __global__ __launch_bounds__(256) void argmax_kernel(const ArgmaxArgs a) {
   const int lane = threadIdx.x & 63;

@@ -15,6 +15,7 @@ constexpr int PADR = 16;   // zero rows before/after a reference utterance in th
 
 struct VocStage {
   Ring up;                                  // ups[i] output (pixel shuffled), also residual source
+  Ring xs;                                  // leaky_relu(mean of the branches): input of ups[i+1] / conv_post
   std::vector<std::vector<Ring>> xt, xo;    // [branch][dilation]
   int C = 0, rate = 1;
 };

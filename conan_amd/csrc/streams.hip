@@ -83,6 +83,7 @@ void conan_streams::build_vocoder() {
     s.C = ch_; s.rate = rate;
     s.up = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
     const int next_pad = (i + 1 < c.voc_num_ups) ? c.voc_up_kernels[i + 1] - 1 : 6;
+    s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
     s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks);
     for (int b = 0; b < c.voc_num_resblocks; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d) {
@@ -112,10 +113,9 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     VocStage& s = v_st[i];
     const int Tin = frames * (s.rate / c.voc_up_rates[i]);
     const int T = frames * s.rate;
-    {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322); stage input = mean of the branches
-      ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xo[0][ND - 1].ref(), s.up.ref(), n, Tin, pos);
-      if (i > 0) { a.nsrc = NB; for (int b = 0; b < NB; ++b) a.x[b] = v_st[i - 1].xo[b][ND - 1].ref(); }
-      a.in_act = ck::ACT_LRELU; a.in_slope = LR;
+    {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322); for i > 0 the activated branch mean is in xs
+      ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos);
+      if (i == 0) { a.in_act = ck::ACT_LRELU; a.in_slope = LR; }
       conv(a, st);
     }
     for (int d = 0; d < ND; ++d) {  // ResBlock1 (hifigan_causal.py:230-238), the NB branches as one grouped launch
@@ -135,21 +135,21 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       launch_group(g1, NB, cfg, st);
       launch_group(g2, NB, cfg, st);
     }
+    {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1] / conv_post
+      ck::MeanActArgs ma; memset(&ma, 0, sizeof(ma));
+      for (int b = 0; b < NB; ++b) ma.x[b] = s.xo[b][ND - 1].ref();
+      ma.y = s.xs.ref(); ma.slots = d_slots; ma.pos = pos; ma.nsrc = NB; ma.T = T; ma.n = n; ma.C = s.C; ma.slope = LR;
+      ck::launch_mean_act(ma, st);
+    }
     ridx += NB;
   }
-  {  // x = leaky_relu(xs / NB); conv_post; tanh   (hifigan_causal.py:329-333)
+  {  // conv_post + tanh on leaky_relu(xs / NB)   (hifigan_causal.py:329-333)
     VocStage& s = v_st.back();
     const int T = frames * s.rate;
-    if (pre_tanh) {
-      ConvArgs a = mk(ctx->conv("voc.conv_post"), s.xo[0][ND - 1].ref(), ch::lin_ref(pre_tanh, T, 1), n, T, pos);
-      a.nsrc = NB; for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref();
-      a.in_act = ck::ACT_LRELU; a.in_slope = LR;
-      conv(a, st);
-    }
-    ConvArgs a = mk(ctx->conv("voc.conv_post"), s.xo[0][ND - 1].ref(), ch::lin_ref(wav_out, T, 1), n, T, pos);
-    a.nsrc = NB; for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref();
-    a.in_act = ck::ACT_LRELU; a.in_slope = LR; a.out_act = ck::ACT_TANH;
-    conv(a, st);
+    ck::ConvPostArgs a; memset(&a, 0, sizeof(a));
+    a.x = s.xs.ref(); a.w = ctx->vec("voc.conv_post.w"); a.bias = ctx->scalars.at("voc.conv_post.b");
+    a.wav = wav_out; a.pre = pre_tanh; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.C = s.C; a.k = (int)ctx->scalars.at("voc.conv_post.k");
+    ck::launch_conv_post(a, st);
   }
   ck::launch_advance(pos_voc, d_slots, n, frames, st);
 }
