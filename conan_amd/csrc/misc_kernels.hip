@@ -135,6 +135,8 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
   float* sq = esm;                    // [Q][D]
   float* skv = esm + Q * a.D;         // [Q][2D]
   float* so = skv + Q * 2 * a.D;      // [Q][D]
+  float* sprob = so + Q * a.D;        // [H][Q][KPL*64] normalised attention weights
+  float* sval = sprob + a.H * Q * EMF_MAX_KPL * 64;   // [H][KPL*64][MAX_DH] values of each head
   const float* kvb = a.kv + (long long)i * Q * 2 * a.D;
   const float* qb = a.q + (long long)i * Q * a.D;
   for (int e = threadIdx.x; e < Q * a.D; e += blockDim.x) sq[e] = qb[e] * a.scaling;
@@ -170,6 +172,8 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
         for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) { kreg[s][d] = skv[tok * 2 * a.D + h * dh + d]; vreg[s][d] = skv[tok * 2 * a.D + a.D + h * dh + d]; }
       }
     }
+    // scores: lanes own keys; two shuffle reductions per query (max, normaliser); the probabilities go to LDS
+    float* sp = sprob + h * Q * EMF_MAX_KPL * 64;
     for (int qi = 0; qi < Q; ++qi) {
       const float* qp = sq + qi * a.D + h * dh;
       float sc[EMF_MAX_KPL];
@@ -189,15 +193,23 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
       sum = wave_sum(sum);
       const float inv = 1.0f / sum;
 #pragma unroll
-      for (int d = 0; d < EMF_MAX_DH; ++d) {
-        if (d < dh) {
-          float o = 0.f;
+      for (int s = 0; s < EMF_MAX_KPL; ++s) sp[(qi * EMF_MAX_KPL + s) * 64 + lane] = sc[s] * inv;
+    }
+    // this head's values to LDS, then lanes own (query, dim) pairs and sum over the keys (no cross-lane reduction)
+    float* sv = sval + h * EMF_MAX_KPL * 64 * EMF_MAX_DH;
 #pragma unroll
-          for (int s = 0; s < EMF_MAX_KPL; ++s) o += sc[s] * vreg[s][d];
-          o = wave_sum(o);
-          if (lane == 0) so[qi * a.D + h * dh + d] = o * inv;
-        }
+    for (int s = 0; s < EMF_MAX_KPL; ++s)
+#pragma unroll
+      for (int d = 0; d < EMF_MAX_DH; ++d) sv[(s * 64 + lane) * EMF_MAX_DH + d] = vreg[s][d];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int pair = lane; pair < Q * dh; pair += 64) {
+      const int qi = pair / dh, d = pair - qi * dh;
+      float o = 0.f;
+      for (int kk = 0; kk < nk; ++kk) {
+        const int s = kk >> 6, l = kk & 63;
+        o += sp[(qi * EMF_MAX_KPL + s) * 64 + l] * sv[(s * 64 + l) * EMF_MAX_DH + d];
       }
+      so[qi * a.D + h * dh + d] = o;
     }
   }
   __syncthreads();
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
 void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
   const int Q = a.R + a.U;
-  const size_t smem = (size_t)Q * a.D * 4 * sizeof(float);
+  const size_t smem = ((size_t)Q * a.D * 4 + (size_t)a.H * Q * EMF_MAX_KPL * 64 + (size_t)a.H * EMF_MAX_KPL * 64 * EMF_MAX_DH) * sizeof(float);
   hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64 * a.H), smem, st, a);
 }
 
