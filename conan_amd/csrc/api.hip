@@ -220,7 +220,7 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
 int conan_profile_begin(conan_streams* s) {
   return guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
-    s->prof_on = true; s->prof_used = 0; s->prof_flops = 0.0; s->prof_launches = 0;
+    s->prof_on = true; s->prof_used = 0; s->prof_flops = 0.0; s->prof_launches = 0; s->prof_rec.clear(); s->prof_kernels.clear();
   });
 }
 
@@ -234,11 +234,32 @@ int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int
       float t = 0.f;
       HIP_CHECK(hipEventElapsedTime(&t, s->prof_ev[i].first, s->prof_ev[i].second));
       ms += t;
+      const auto& r = s->prof_rec[i];
+      bool found = false;
+      for (auto& k : s->prof_kernels) if (k.cfg == r.cfg && k.nsrc == r.nsrc) { k.ms += t; k.flops += r.flops; k.n += 1; found = true; break; }
+      if (!found) s->prof_kernels.push_back({r.cfg, r.nsrc, (double)t, r.flops, 1});
     }
     if (conv_ms) *conv_ms = ms;
     if (conv_flops) *conv_flops = s->prof_flops;
     if (conv_launches) *conv_launches = s->prof_launches;
   });
+}
+
+int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, double* ms, double* flops, int64_t* launches) {
+  int found = 0;
+  int rc = guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    if (index < 0 || index >= (int)s->prof_kernels.size()) return;
+    static const char* shapes[] = {"128, 64, 2, 2, 1, 32", "64, 64, 2, 2, 1, 32", "128, 32, 4, 1, 1, 32", "32, 64, 1, 2, 2, 64", "32, 32, 1, 1, 4, 128",
+                                   "64, 32, 2, 1, 2, 32", "64, 64, 2, 2, 1, 64", "128, 64, 2, 2, 1, 32", "128, 32, 4, 1, 1, 64"};
+    const auto& k = s->prof_kernels[index];
+    if (name && name_cap > 0) snprintf(name, name_cap, "ck::conv_mfma_kernel<%s, %d>", shapes[k.cfg], k.nsrc);
+    if (ms) *ms = k.ms;
+    if (flops) *flops = k.flops;
+    if (launches) *launches = k.n;
+    found = 1;
+  });
+  return rc != CONAN_OK ? rc : found;
 }
 
 int conan_hop_size(const conan_ctx* ctx) { return ctx ? ctx->hop : 0; }

@@ -95,6 +95,10 @@ struct conan_streams {
   size_t prof_used = 0;
   double prof_flops = 0.0;
   long long prof_launches = 0;
+  struct ProfRec { int cfg, nsrc; double flops; };
+  std::vector<ProfRec> prof_rec;                 // one per recorded launch (same order as prof_ev)
+  struct ProfKernel { int cfg, nsrc; double ms, flops; long long n; };
+  std::vector<ProfKernel> prof_kernels;          // filled by conan_profile_end: per template instantiation
   void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
   void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;

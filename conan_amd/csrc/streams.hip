@@ -48,9 +48,11 @@ void conan_streams::launch_group(const ConvGroup& g, int nprob, int cfg, hipStre
   HIP_CHECK(hipEventRecord(ev.first, st));
   ck::launch_conv(g, nprob, cfg, st, ctx->num_cu);
   HIP_CHECK(hipEventRecord(ev.second, st));
-  for (int p = 0; p < nprob; ++p)
-    prof_flops += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
+  double fl = 0.0;
+  for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
+  prof_flops += fl;
   prof_launches += 1;
+  prof_rec.push_back({cfg, g.p[0].nsrc, fl});
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {

@@ -179,6 +179,18 @@ class Streams:
         _lib.check(self.lib.conan_profile_end(self.h, C.byref(ms), C.byref(fl), C.byref(nl)))
         return ms.value, fl.value, nl.value
 
+    def profile_kernels(self):
+        """Per kernel instantiation after profile_end(): list of (name, ms, flops, launches)."""
+        out, i = [], 0
+        while True:
+            buf = C.create_string_buffer(128)
+            ms, fl, nl = C.c_double(), C.c_double(), C.c_int64()
+            rc = _lib.check(self.lib.conan_profile_kernel(self.h, i, buf, 128, C.byref(ms), C.byref(fl), C.byref(nl)))
+            if rc == 0:
+                return out
+            out.append((buf.value.decode(), ms.value, fl.value, nl.value))
+            i += 1
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.conan_streams_destroy(self.h)

@@ -151,6 +151,9 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
  * unpadded) and the launch count. */
 int conan_profile_begin(conan_streams* s);
 int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int64_t* conv_launches);
+/* After conan_profile_end: the same totals per kernel template instantiation (index 0,1,...; returns 1 and fills the
+ * outputs, 0 past the last one).  `name` is the kernel name as rocprofv3 prints it. */
+int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, double* ms, double* flops, int64_t* launches);
 
 /* Introspection for tests / INTEGRATION.md. */
 int conan_hop_size(const conan_ctx* ctx);             /* prod(upsample_rates) */
