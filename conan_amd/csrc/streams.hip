@@ -37,7 +37,16 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
   return best;
 }
 
-void conan_streams::launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st) {
+void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipStream_t st) {
+  ConvGroup g = gin;
+  for (int p = 0; p < nprob; ++p) {
+    // layers that touch no per-slot ring need neither the slot table nor the position counters: dropping them
+    // removes two dependent global loads from the prologue and from the epilogue of these latency-bound launches
+    ConvArgs& a = g.p[p];
+    bool ring = a.y.mode == 0 || (a.has_res && a.res.mode == 0) || (a.has_m1 && a.m1.mode == 0) || (a.has_m2 && a.m2.mode == 0) || a.bvec != nullptr;
+    for (int q = 0; q < a.nsrc; ++q) ring = ring || a.x[q].mode == 0;
+    if (!ring) { a.slots = nullptr; a.pos = nullptr; }
+  }
   if (!prof_on) { ck::launch_conv(g, nprob, cfg, st, ctx->num_cu); return; }
   if (prof_used == prof_ev.size()) {
     hipEvent_t a, b;
