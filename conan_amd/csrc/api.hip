@@ -113,6 +113,8 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       s->d_slots = (int*)s->alloc(max_slots); s->d_ident = (int*)s->alloc(max_slots); s->d_zero = (int*)s->alloc(max_slots);
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
+      s->sk_slab_floats = 8ll << 20; s->sk_slab = s->alloc((size_t)s->sk_slab_floats);
+      s->sk_max_tiles = 4096; s->sk_counters = (int*)s->alloc(s->sk_max_tiles);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
       std::vector<int> id(max_slots);
       for (int i = 0; i < max_slots; ++i) id[i] = i;

@@ -54,14 +54,15 @@ struct ConvLds {
   static constexpr int EPI_LD = 36;                 // epilogue transpose patch: 32 rows x 36 floats per compute wave
   static constexpr int PATCH = 4 * 32 * EPI_LD;
   static constexpr int RED = (WK > 1) ? (WK - 1) * TM * TN : 0;   // split-K partial tiles of waves wk > 0
-  static constexpr int TOTAL = STAGE + PATCH + RED;
+  static constexpr int TOTAL = STAGE + PATCH + RED + 4;   // + the split-K "reducer" flag
 };
 
 // One output tile (rows m0.., columns n0..) of one problem.  `gbuf` is the LDS ring position of the tile's first
 // K-step: it is carried from tile to tile so that a persistent block's loader waves can start the next tile's
 // loads while the matrix waves are still in the previous tile's epilogue.
 template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
-__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const int n0, float* lds, int& gbuf, const int tile) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const int n0, float* lds, int& gbuf, const int tile,
+                                          const int kslice, const int nslices, float* slab, int* counter) {
   static_assert(WM * WN * WK == 4, "4 compute waves per block");
   static_assert(KS == 32 || KS == 64 || KS == 128, "K-step");
   constexpr int RM = TM / WM / 32;
@@ -133,7 +134,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 
   const int ncb32 = a.Cin_pad >> 5;                 // 32-channel blocks per tap
   const int ncb = (ncb32 + SB - 1) / SB;            // K-steps per tap
-  const int nks = ktaps * ncb;
+  const int nks_all = ktaps * ncb;
+  constexpr bool SK = (TM == 32);                  // inter-block split-K is compiled into the small-M shapes only
+  // inter-block split-K: this block owns K-steps [ks_lo, ks_lo + nks) of the tile; the partial tiles are combined by the
+  // last-arriving block (ticket counter), in slice order, so the sum is reproducible
+  const int ks_lo = SK ? (int)((long long)nks_all * kslice / nslices) : 0;
+  const int nks = SK ? (int)((long long)nks_all * (kslice + 1) / nslices) - ks_lo : nks_all;
+  int* const sflag = reinterpret_cast<int*>(lds + L::STAGE + L::PATCH + L::RED);
+  auto block_barrier = [&]() __attribute__((always_inline)) {
+    if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
+  };
+  // every wave of the block takes part in the two barriers of the split-K hand-off (X1: partial tiles written,
+  // X2: "this block is the reducer" flag published through LDS)
+  auto splitk_idle = [&]() __attribute__((always_inline)) {
+    if constexpr (SK) { if (nslices > 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); block_barrier(); block_barrier(); } }
+  };
 
   if (is_loader) {
     // ================================================================= loader waves
@@ -167,7 +182,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       int woff[WV];
 #pragma unroll
       for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
-      int jn = 0, cbn = 0;
+      int jn = ks_lo % ktaps, cbn = ks_lo / ktaps;
       auto issue = [&](int buf) __attribute__((always_inline)) {
         const int j = jn, cb = cbn;
         float* As = lds + buf * (A_FLOATS + W_FLOATS);
@@ -218,6 +233,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #endif
 #undef CK_LSTAMP
       if constexpr (WK > 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+      splitk_idle();
       return;
     } else {
     // per-thread A staging geometry (fixed over the K loop): rows arow + 32*q, channel quad ac4
@@ -251,7 +267,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
     int woff[WV];      // per-thread W staging offsets (floats, relative to the K-step's tile base)
 #pragma unroll
     for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
-    int jn = 0, cbn = 0;   // (tap, channel block) of the next K-step to issue; tap index fastest so that
+    int jn = ks_lo % ktaps, cbn = ks_lo / ktaps;   // (tap, channel block) of the next K-step to issue; tap index fastest so that
                            // consecutive steps re-touch the same activation rows (L1/L2 hits)
 
     // two register sets (P, Q): loads are issued TWO K-steps ahead of their LDS store
@@ -336,6 +352,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #undef CK_ISSUE
 #undef CK_W_ISSUE
     if constexpr (WK > 1) { __syncthreads(); __syncthreads(); }   // the compute waves' split-K reduction barriers
+    splitk_idle();
     return;
     }  // register-staged loader
   }
@@ -421,10 +438,55 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
           for (int e = 0; e < 16; ++e) dst[((rm * RN + rn) * 16 + e) * 64 + lane] = acc[rm][rn][e];
     }
     if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
-    if (wk > 0) return;
+    if (wk > 0) { splitk_idle(); return; }
 #pragma unroll
     for (int k2 = 1; k2 < WK; ++k2) {
       const float* src = red + ((k2 - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[rm][rn][e] += src[((rm * RN + rn) * 16 + e) * 64 + lane];
+    }
+  }
+
+  // ---- inter-block split-K hand-off (MI355X: per-XCD L2s are not coherent -> agent-scope release / acquire)
+  if (SK && nslices > 1) {
+    constexpr int PER_WAVE = RM * RN * 16 * 64;
+    constexpr int PER_TILE = WM * WN * PER_WAVE;
+    float* mine = slab + (long long)kslice * PER_TILE + (wm * WN + wn) * PER_WAVE;
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[((rm * RN + rn) * 16 + e) * 64 + lane] = acc[rm][rn][e];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
+    block_barrier();                                       // X1
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == nslices - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+      }
+      *sflag = last;
+    }
+    block_barrier();                                       // X2
+    if (*sflag == 0) return;
+    // reducer: sum the partial tiles in slice order (own slice from memory too: identical bits, fixed order)
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
+    for (int q = 0; q < nslices; ++q) {
+      const float* src = slab + (long long)q * PER_TILE + (wm * WN + wn) * PER_WAVE;
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -620,12 +682,15 @@ template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
 __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4 > 80 * 1024) ? 2 : 4) void conv_mfma_kernel(const ConvGroup g) {
   __shared__ __attribute__((aligned(16))) float lds[ConvLds<TM, TN, WK, KS, NSRC>::TOTAL];
   int gbuf = 0;
-  for (int tile = blockIdx.x; tile < g.tile_start[3]; tile += gridDim.x) {
+  const int S = g.ksplit;
+  for (int item = blockIdx.x; item < g.tile_start[3] * S; item += gridDim.x) {
+    const int tile = item / S, kslice = item - tile * S;      // slices of a tile are adjacent: they finish together
     const int p = (tile >= g.tile_start[1] ? 1 : 0) + (tile >= g.tile_start[2] ? 1 : 0);
     const int local = tile - g.tile_start[p];
     const int tn = g.tiles_n[p];
     const int mt = local / tn, nt = local - mt * tn;
-    conv_tile<TM, TN, WM, WN, WK, KS, NSRC>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile);
+    conv_tile<TM, TN, WM, WN, WK, KS, NSRC>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, S,
+                                            g.slab + (long long)tile * S * (TM * TN), g.counters + tile);
   }
 }
 
@@ -638,7 +703,7 @@ template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
 static void launch_one(const ConvGroup& g, int num_cu, hipStream_t st) {
   constexpr int lds_bytes = ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4;
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
-  int grid = g.tile_start[3];
+  int grid = g.tile_start[3] * g.ksplit;
   if (NSRC == 1 && grid > num_cu * per_cu) grid = num_cu * per_cu;     // persistent blocks (direct-to-LDS build only)
   hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, WK, KS, NSRC>), dim3(grid), dim3(512), 0, st, g);
 }
@@ -661,6 +726,7 @@ static void launch_conv_n(const ConvGroup& g, int cfg, int num_cu, hipStream_t s
 
 void launch_conv(const ConvGroup& gin, int nprob, int cfg, hipStream_t st, int num_cu) {
   ConvGroup g = gin;
+  if (g.ksplit < 1 || !g.slab || !g.counters || kTM[cfg] != 32) g.ksplit = 1;
   const int TM = kTM[cfg], TN = kTN[cfg];
   // longest-K problem first
   int idx[3] = {0, 1, 2};

@@ -61,6 +61,13 @@ struct ConvGroup {      // up to 3 independent problems in one launch
   int tile_start[4];    // filled by launch_conv: first tile of the q-th scheduled problem; [3] = total tiles
   int tiles_n[3];       // n-tiles of the q-th scheduled problem
   int order[3];         // q-th scheduled problem -> index into p[] (longest K first)
+  // inter-block split-K (latency-bound layers with few tiles): K-steps of a tile are divided over `ksplit` blocks;
+  // partial tiles go to `slab` ([tile][slice][TM*TN] floats), `counters` ([tile] ints, zero between launches)
+  // elects the last-arriving block as the reducer.
+  float* slab;
+  int* counters;
+  int ksplit;
+  int pad_;
 };
 
 // Tile configurations of conv_mfma (block = 256 threads = 4 waves).

@@ -33,6 +33,10 @@ struct conan_streams {
   int* d_lens = nullptr;    // [max_slots] per-batch lengths (style pass)
   int* d_lens2 = nullptr;
   int* d_codes = nullptr;   // [max_slots][max_frames] codes scratch for the fused step
+  float* sk_slab = nullptr; // inter-block split-K partial tiles
+  int* sk_counters = nullptr;
+  long long sk_slab_floats = 0;
+  int sk_max_tiles = 0;
   std::vector<int> h_slots;
   int* pos_emf = nullptr; int* pos_dec = nullptr; int* pos_voc = nullptr;
 

@@ -47,6 +47,22 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     for (int q = 0; q < a.nsrc; ++q) ring = ring || a.x[q].mode == 0;
     if (!ring) { a.slots = nullptr; a.pos = nullptr; }
   }
+  // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
+  g.slab = sk_slab; g.counters = sk_counters; g.ksplit = 1;
+  if (nprob == 1 && ck::conv_cfg_tm(cfg) == 32) {
+    const ConvArgs& a = g.p[0];
+    const int TM = ck::conv_cfg_tm(cfg), TN = ck::conv_cfg_tn(cfg);
+    const int KS = (cfg == ck::CFG_32x64_K2) ? 64 : 128;
+    const long long tiles = (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
+    const int nks = a.ktaps * ((a.Cin_pad + KS - 1) / KS);
+    int S = tiles > 0 ? (int)(ctx->num_cu / tiles) : 1;
+    if (S > nks / 2) S = nks / 2;
+    if (S > 16) S = 16;
+    while (S > 1 && tiles * S * TM * TN > sk_slab_floats) --S;
+    // the hand-off (partial-tile stores, agent-scope release/acquire, ticket) costs about as much as ~6 K-steps:
+    // split only when it removes at least a dozen steps from the critical path
+    if (S >= 2 && tiles <= sk_max_tiles && nks - nks / S >= 12) g.ksplit = S;
+  }
   if (!prof_on) { ck::launch_conv(g, nprob, cfg, st, ctx->num_cu); return; }
   if (prof_used == prof_ev.size()) {
     hipEvent_t a, b;
