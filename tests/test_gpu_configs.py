@@ -1,0 +1,99 @@
+"""GPU tests of the other BASELINE.json configurations through size-independent properties and the oracle:
+batch=64 full-size streams (slot independence), windowed mode (reset + ctx+chunk frames),
+40 ms chunks (seg=2), and stream re-use after reset."""
+import numpy as np
+import pytest
+import torch
+
+from conan_amd import configs, synth
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _full_ctx(chp=None):
+    from conan_amd.runtime import Context
+    chp = chp or configs.conan_hparams()
+    vhp = configs.hifigan_hparams()
+    ctx = Context(chp, vhp, 0)
+    ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0))
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    return ctx, chp, vhp
+
+
+def test_batch64_full_size_streams_are_independent():
+    """configs[2]: 64 concurrent full-size streams.  A stream's output must not depend on which other streams share
+    the batch or on its slot: stream k inside the batch of 64 == the same stream run alone (different tile shapes,
+    split-K and launch grouping, so equality is up to fp32 re-association)."""
+    from conan_amd.engine import StreamingVoiceConversionEngine
+    ctx, chp, vhp = _full_ctx()
+    B, T, Tr = 64, 12, 40
+    src = torch.from_numpy(np.concatenate([synth.mel(T, 1234 + s) for s in range(B)])).cuda()
+    ref = torch.from_numpy(np.concatenate([synth.mel(Tr, 4321 + s) for s in range(B)])).cuda()
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=64)
+    wav, mel, codes = eng.infer(src, ref)
+    assert wav.shape == (B, T * 320) and mel.shape == (B, T, 80) and codes.shape == (B, T)
+    assert torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+    solo = StreamingVoiceConversionEngine(ctx, 1, max_ref_frames=64)
+    for k in (0, 37, 63):
+        w1, m1, c1 = solo.infer(src[k:k + 1], ref[k:k + 1])
+        assert torch.equal(c1, codes[k:k + 1])
+        np.testing.assert_allclose(m1.cpu().numpy(), mel[k:k + 1].cpu().numpy(), atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(w1.cpu().numpy(), wav[k:k + 1].cpu().numpy(), atol=2e-5, rtol=0)
+    # re-running the same utterances after reset reproduces the result bit for bit (state fully re-initialised)
+    wav2, mel2, _ = eng.infer(src, ref)
+    assert torch.equal(wav, wav2) and torch.equal(mel, mel2)
+    eng.st.close(); solo.st.close(); ctx.close()
+
+
+def test_windowed_mode_matches_reference_windows():
+    """configs[1]/[4] windowed mode = state reset + (ctx + chunk) frames in one step, emit the last chunk.  Oracle:
+    the reference module fed the same window (golden mel_out_win{8,16,32}, tools/make_goldens.py)."""
+    ctx, chp, vhp = _full_ctx()
+    g = load_golden("conan_full.npz")
+    content = torch.from_numpy(g["content"]).int().cuda()
+    T = content.shape[1]
+    st = ctx.streams(1, max_frames=36, max_ref_frames=160)
+    st.set_reference([0], torch.from_numpy(g["ref"]).cuda())
+    for c in (8, 16, 32):
+        st.reset([0], which=2)
+        mel = st.decoder_step([0], content[:, T - c - 4:])
+        np.testing.assert_allclose(mel[:, -4:].cpu().numpy(), g[f"mel_out_win{c}"], atol=1e-4, rtol=1e-4)
+    # and the vocoder in windowed mode: reset + 12 frames == the first 12 frames of a stateful run
+    gv = load_golden("hifigan_full.npz")
+    mel12 = torch.from_numpy(gv["mel_12"]).transpose(1, 2).contiguous().cuda()
+    st.reset([0], which=4)
+    wav = st.hifigan_step([0], mel12)
+    np.testing.assert_allclose(wav[0].cpu().numpy(), gv["wav_12"], atol=1e-4, rtol=0)
+    st.close(); ctx.close()
+
+
+def test_40ms_chunks_seg2():
+    """configs[4]: chunk_size 40 -> Emformer segment 2 (+ right context 2), decoder / vocoder steps of 2 frames."""
+    from oracle import emformer as oemf
+    from oracle import loop as oloop
+    from oracle.common import to_torch_sd
+    chp = dict(configs.conan_hparams(), chunk_size=40)
+    ctx, chp, vhp = _full_ctx(chp)
+    assert ctx.cfg.emf_segment == 2
+    sds = {"emformer": to_torch_sd(synth.emformer_state_dict(chp, 0)), "conan": to_torch_sd(synth.conan_state_dict(chp, 0)),
+           "hifigan": to_torch_sd(synth.hifigan_state_dict(vhp, 0))}
+    cfg = oemf.EmformerCfg(chp)
+    B, T, Tr = 2, 11, 40
+    src, ref = synth.mel(T, 1234, B), synth.mel(Tr, 4321, B)
+    st = ctx.streams(B, max_frames=2, max_ref_frames=64)
+    slots = [0, 1]
+    st.reset(slots)
+    st.set_reference(slots, torch.from_numpy(ref).cuda())
+    wavs, mels = [], []
+    for pos, emit, chunk in oemf.chunk_iter(torch.from_numpy(src), 2, 2):
+        _, m, w = st.step(slots, chunk.cuda().contiguous(), emit=emit)
+        wavs.append(w.cpu()); mels.append(m.cpu())
+    wav, mel = torch.cat(wavs, 1), torch.cat(mels, 1)
+    for b in range(B):
+        w_ref, m_ref, _ = oloop.infer_once_stateful(sds["emformer"], cfg, sds["conan"], chp, sds["hifigan"], vhp, src[b], ref[b])
+        np.testing.assert_allclose(mel[b].numpy(), m_ref, atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(wav[b].numpy(), w_ref, atol=1e-4, rtol=0)
+    st.close(); ctx.close()
