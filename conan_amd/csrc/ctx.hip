@@ -169,6 +169,43 @@ void conan_ctx::finalize_emformer() {
     upload_vec(n + ".ln_out.b", p + ".layer_norm_output.bias");
   }
   if (c.emf_output_dim != c.emf_input_dim) pack_from_keys("emf.proj", "emformer.proj.weight", "emformer.proj.bias");
+  // Second copy of the Linear weights for the fused step (emformer_fused.hip), fragment-major: fragment (ntile, kq)
+  // is the 64-lane x float4 MFMA B operand {W[ntile*16 + (lane&15)][kq*16 + (lane>>4)*4 + e]} stored as 1 KiB, and
+  // fragments are ordered the way a wave consumes them, so each wave streams its weights sequentially.
+  const int D = c.emf_input_dim, F = c.emf_ffn_dim;
+  if (D % 16 || F % 64) return;   // the fused step does not cover such shapes (streams.hip falls back per op)
+  auto frags = [&](const std::vector<float>& W, int N, int K, size_t nfr, auto index) {
+    std::vector<float> out(nfr * 256, 0.f);
+    const int nt = (N + 15) / 16, kqs = K / 16;
+    for (int t = 0; t < nt; ++t)
+      for (int kq = 0; kq < kqs; ++kq) {
+        float* f = out.data() + index(t, kq) * 256;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int n = t * 16 + (lane & 15), k = kq * 16 + (lane >> 4) * 4 + e;
+            f[lane * 4 + e] = n < N ? W[(size_t)n * K + k] : 0.f;
+          }
+      }
+    return out;
+  };
+  const int KQ = D / 16;
+  for (int l = 0; l < c.emf_layers; ++l) {
+    std::string p = "emformer.emformer.emformer_layers." + std::to_string(l);
+    std::string n = "emf." + std::to_string(l);
+    std::vector<float> qkv = get(p + ".attention.emb_to_query.weight").data;          // [D][D] then [2D][D]
+    const std::vector<float>& kv = get(p + ".attention.emb_to_key_value.weight").data;
+    qkv.insert(qkv.end(), kv.begin(), kv.end());
+    vecs[n + ".fqkv"] = upload(frags(qkv, 3 * D, D, (size_t)(3 * D / 16) * KQ, [&](int t, int kq) { return (size_t)t * KQ + kq; }));
+    vecs[n + ".fo"] = upload(frags(get(p + ".attention.out_proj.weight").data, D, D, (size_t)KQ * KQ, [&](int t, int kq) { return (size_t)t * KQ + kq; }));
+    // FF1: units of 4 tiles (64 hidden columns = one wave's share of a chunk), [unit][kq][tile in unit]
+    vecs[n + ".f1"] = upload(frags(get(p + ".pos_ff.1.weight").data, F, D, (size_t)(F / 16) * KQ, [&](int t, int kq) { return ((size_t)(t / 4) * KQ + kq) * 4 + (t % 4); }));
+    // FF2: k-group major, [kq][tile]
+    vecs[n + ".f2"] = upload(frags(get(p + ".pos_ff.4.weight").data, D, F, (size_t)(F / 16) * KQ, [&](int t, int kq) { return (size_t)kq * KQ + t; }));
+  }
+  if (c.emf_output_dim != D) {
+    const int nt = (c.emf_output_dim + 15) / 16;
+    vecs["emf.fproj"] = upload(frags(get("emformer.proj.weight").data, c.emf_output_dim, D, (size_t)nt * KQ, [&](int t, int kq) { return (size_t)t * KQ + kq; }));
+  }
 }
 
 void conan_ctx::finalize_conan() {

@@ -1,0 +1,555 @@
+// emformer_fused: one launch for the whole streaming Emformer step (torchaudio Emformer.infer: all layers, then the
+// output projection and arg-max), replacing ~60 latency-bound launches of the generic kernels.
+//
+// A step touches only Q = R+U (= 6) tokens per stream and streams are independent, so a block owns G = 16/Q streams
+// as one 16-row tile and walks all layers without leaving the chip.  Activations live in LDS; weights stream from L2
+// straight into MFMA B-fragments (the packed [k/4][n][4] layout is lane-contiguous: 16 columns x 4 k-groups = 1 KiB
+// per wave-wide load) and are prefetched one phase ahead into registers - the block runs one wave per SIMD, so it
+// has the whole 512-entry register file for that; barriers are raw s_barrier so those loads stay in flight across
+// them.  GEMMs use v_mfma_f32_16x16x4_f32 (exact fp32).  Per layer:
+//   LN -> [q|k|v] GEMM (k, v land directly in the per-stream key tables [rc | cached left context | utterance] next
+//   to the ring rows prefetched at the top of the layer; the U new rows are appended to the rings) -> attention with
+//   16-lane rows per (stream, head) -> out_proj + residual -> LN -> FFN in 512-wide hidden chunks (FF1 -> ReLU ->
+//   LDS -> FF2 accumulate, K split over the 4 waves) -> + residual -> LN.
+// Token order inside a stream is [right context | utterance] like torchaudio's _EmformerLayer.infer.
+#include "kernels.h"
+
+namespace ck {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int EF_ROWS = 16;
+constexpr int EF_HCHUNK = 256;    // FFN hidden chunk
+constexpr int EF_CR = 8;          // ring-prefetch units per thread (one K and one V float4 each)
+constexpr int EF_PP = 4;          // float4 parameter-prefetch registers per thread (11 D + F <= 4096 floats)
+constexpr int EF_MAXJ = 4;        // keys per lane in a 16-lane row -> <= 64 keys
+
+#ifndef EF_NOLOAD
+#define EF_NOLOAD 0   // experiment: skip the FFN weight refills (wrong results, isolates the MFMA time)
+#endif
+#ifdef EF_STAMPS
+#define EF_STAMP(i) do { if (tid == 0 && blockIdx.x == 0 && l == 1) a.dbg[i] = __builtin_readcyclecounter(); } while (0)
+#define EF_STAMPC(i) do { if (c0 == EF_HCHUNK) EF_STAMP(i); } while (0)
+#else
+#define EF_STAMP(i) do { } while (0)
+#define EF_STAMPC(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void ef_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CTRL>
+__device__ __forceinline__ float ef_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int ef_dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+// reductions over a 16-lane row: quad xor 1, quad xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float ef_row_sum(float v) {
+  v += ef_dpp<0xB1>(v); v += ef_dpp<0x4E>(v); v += ef_dpp<0x141>(v); v += ef_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float ef_row_max(float v) {
+  v = fmaxf(v, ef_dpp<0xB1>(v)); v = fmaxf(v, ef_dpp<0x4E>(v)); v = fmaxf(v, ef_dpp<0x141>(v)); v = fmaxf(v, ef_dpp<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ int ef_row_min(int v) {
+  v = min(v, ef_dppi<0xB1>(v)); v = min(v, ef_dppi<0x4E>(v)); v = min(v, ef_dppi<0x141>(v)); v = min(v, ef_dppi<0x140>(v));
+  return v;
+}
+
+// one fragment-major B operand: 1 KiB per fragment, lane-contiguous (scalar base + the lane's 16-byte slot)
+__device__ __forceinline__ float4 ef_frag(const float* __restrict__ w, int idx, unsigned lane16) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w) + (long long)idx * 1024 + lane16);
+}
+// acc += A[16][acol0 .. acol0+16*KQ) (LDS) x B
+template <int KQ>
+__device__ __forceinline__ f32x4 ef_mma(f32x4 acc, const float4 (&b)[KQ], const float* A, int lda, int acol0, int lane) {
+  const float* ap = A + (lane & 15) * lda + acol0 + (lane >> 4) * 4;
+#pragma unroll
+  for (int kq = 0; kq < KQ; ++kq) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + kq * 16);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[kq].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[kq].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[kq].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[kq].w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// NT independent 16-column tiles sharing the A rows: one LDS fragment read per k-group, MFMAs of different tiles
+// interleaved so no instruction waits on the previous one's accumulator
+template <int NT, int KQ>
+__device__ __forceinline__ void ef_mma_tiles(f32x4 (&acc)[NT], const float4 (&b)[NT][KQ], const float* A, int lda, int acol0, int lane) {
+  const float* ap = A + (lane & 15) * lda + acol0 + (lane >> 4) * 4;
+#pragma unroll
+  for (int kq = 0; kq < KQ; ++kq) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + kq * 16);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t][kq].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t][kq].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t][kq].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t][kq].w, acc[t], 0, 0, 0);
+  }
+}
+
+// Same, refilling each k-group's B fragments in place as soon as its MFMAs are issued (refill(kq) loads the
+// fragments the same tiles need two phases later): the loads are spread through the MFMA stream, so the matrix and
+// memory pipes run concurrently, and every load has a full phase of lead time.
+template <int NT, int KQ, class F>
+__device__ __forceinline__ void ef_mma_tiles_refill(f32x4 (&acc)[NT], float4 (&b)[NT][KQ], const float* A, int lda, int acol0, int lane, F&& refill) {
+  const float* ap = A + (lane & 15) * lda + acol0 + (lane >> 4) * 4;
+#pragma unroll
+  for (int kq = 0; kq < KQ; ++kq) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + kq * 16);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[t][kq].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[t][kq].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[t][kq].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[t][kq].w, acc[t], 0, 0, 0);
+    refill(kq);
+  }
+}
+// LayerNorm over D = 16*KQD channels: a 16-lane row per activation row, 4 rows per wave
+template <int KQD>
+__device__ __forceinline__ void ef_layernorm(const float* src, float* dst, int ld, const float* gamma, const float* beta, int tid) {
+  const int r = tid >> 4, c0 = tid & 15;
+  constexpr float invD = 1.0f / (16 * KQD);
+  float v[KQD], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < KQD; ++i) { v[i] = src[r * ld + c0 + 16 * i]; s += v[i]; }
+  const float mean = ef_row_sum(s) * invD;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < KQD; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+  const float rstd = 1.0f / sqrtf(ef_row_sum(q) * invD + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < KQD; ++i) dst[r * ld + c0 + 16 * i] = v[i] * rstd * gamma[c0 + 16 * i] + beta[c0 + 16 * i];
+}
+
+// streams per block: 16 GEMM rows and 16 attention rows (one per (stream, head)) bound it
+__host__ __device__ inline int ef_streams_per_block(int Q, int H) { const int g1 = EF_ROWS / Q, g2 = 16 / H; return g1 < g2 ? g1 : g2; }
+
+// floats of the multi-purpose region: FFN hidden chunk | FF2 partial sums | logits
+__host__ __device__ inline int ef_scratch_floats(int D, int K) {
+  int m = EF_ROWS * (EF_HCHUNK + 4);
+  if (4 * EF_ROWS * (D + 4) > m) m = 4 * EF_ROWS * (D + 4);
+  if (EF_ROWS * (K + 4) > m) m = EF_ROWS * (K + 4);
+  return (m + 3) & ~3;
+}
+
+}  // namespace
+
+template <int KQD, int DH>
+__global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int D = 16 * KQD;
+  constexpr int ld = D + 4, ldk = D + 2, ldh = EF_HCHUNK + 4;
+  constexpr int TQ = (3 * KQD + 3) / 4;     // [q|k|v] tiles per wave
+  constexpr int TO = (KQD + 3) / 4;         // out_proj tiles per wave
+  constexpr int T1 = EF_HCHUNK / 64;        // FF1 tiles per wave per chunk
+  constexpr int KQ2 = EF_HCHUNK / 4 / 16;   // FF2 k-groups per wave per chunk
+  // per-layer small parameters, staged in LDS one layer ahead (EmfLayerW::params)
+  constexpr int PB_BQ = 0, PB_BKV = D, PB_BO = 3 * D, PB_B2 = 4 * D, PB_LNIN = 5 * D, PB_LNFF = 7 * D, PB_LNOUT = 9 * D, PB_B1 = 11 * D;
+  static_assert(DH % 2 == 0 && DH <= 16, "head dim");
+  const int R = a.R, U = a.U, Q = R + U, H = a.H, G = ef_streams_per_block(Q, H);
+  const int nkmax = R + a.LC + U;
+  const int par = PB_B1 + a.F;           // floats per layer parameter block (multiple of 4)
+  float* X = sm;                         // [16][ld] layer input / residual
+  float* Y = X + EF_ROWS * ld;           // [16][ld] LN output
+  float* Qb = Y + EF_ROWS * ld;          // [16][ld] scaled queries
+  float* ATT = Qb + EF_ROWS * ld;        // [16][ld]
+  float* R1 = ATT + EF_ROWS * ld;        // [16][ld]
+  float* Hb = R1 + EF_ROWS * ld;         // [16][ldh] FFN hidden chunk; also FF2 partial sums and the logits
+  float* PB = Hb + ef_scratch_floats(D, a.K);      // [2][par]
+  float* KB = PB + 2 * par;              // [G][nkmax][ldk] keys:  rc | cached | utt
+  float* VB = KB + G * nkmax * ldk;      // [G][nkmax][ldk] values
+  float* RED = Hb;                       // [4][16][ld]
+
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const unsigned lane16 = (unsigned)lane * 16;
+  const int i0 = blockIdx.x * G;
+  const int ng = (a.n - i0) < G ? (a.n - i0) : G;      // streams in this block
+  const int nrows = ng * Q;
+
+  // ---- everything that depends on slots / past is computed once: no global loads other than the prefetches below
+  // happen inside the layer loop (vmcnt retires in order, so a late small load would wait for the prefetches)
+  // (a) this lane's GEMM output rows r = (lane>>4)*4 + r4: key-table row offset and ring append offset
+  int tab_off[4], ring_off[4];
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const int r = (lane >> 4) * 4 + r4, g = r / Q, tok = r - g * Q;
+    tab_off[r4] = -1; ring_off[r4] = -1;
+    if (g < ng) {
+      const int slot = a.slots[i0 + g], past = a.past[slot], Lc = past < a.LC ? past : a.LC;
+      tab_off[r4] = (g * nkmax + (tok < R ? tok : R + Lc + (tok - R))) * ldk;
+      if (tok >= R) ring_off[r4] = (int)(slot * a.ring_slot_stride) + (int)((unsigned)(past + tok - R) & (unsigned)a.lmask) * D;
+    }
+  }
+  // (b) attention: a 16-lane row per (stream, head)
+  const int pr = tid >> 4, l16 = tid & 15;
+  const bool pok = pr < ng * H;
+  const int pg = pok ? pr / H : 0, ph = pok ? pr - pg * H : 0;
+  int nk = 0;
+  if (pok) { const int past = a.past[a.slots[i0 + pg]]; nk = R + (past < a.LC ? past : a.LC) + U; }
+  // (c) cached-row prefetch plan (shared by K and V): unit e -> (g, j, c4); ring byte offset (-1: none), table offset
+  constexpr int f4 = D / 4;
+  int soff[EF_CR], doff[EF_CR];
+  {
+    const int per_g = (a.LC > 0 ? a.LC : 1) * f4;
+#pragma unroll
+    for (int i = 0; i < EF_CR; ++i) {
+      const int e = tid + 256 * i;
+      const int g = __umulhi(e, a.magic_per_g), rem = e - g * per_g, j = rem / f4, c4 = rem - j * f4;
+      soff[i] = -1; doff[i] = 0;
+      if (g < ng) {
+        const int slot = a.slots[i0 + g], past = a.past[slot], Lc = past < a.LC ? past : a.LC;
+        if (j < Lc) {
+          soff[i] = ((int)(slot * a.ring_slot_stride) + (int)((unsigned)(past - Lc + j) & (unsigned)a.lmask) * D + c4 * 4) * 4;
+          doff[i] = (g * nkmax + R + j) * ldk + c4 * 4;
+        }
+      }
+    }
+  }
+
+  // ---- load the chunk (token order [rc | utt]; the chunk is [utt(U) | rc(R)] per stream) and layer 0's parameters
+  for (int e = tid; e < EF_ROWS * ld; e += 256) {
+    const int r = e / ld, c = e - r * ld, g = r / Q, tok = r - g * Q;
+    float v = 0.f;
+    if (r < nrows && c < D) v = a.chunk[((long long)(i0 + g) * Q + (tok < R ? U + tok : tok - R)) * D + c];
+    X[e] = v; Y[e] = 0.f; Qb[e] = 0.f; ATT[e] = 0.f; R1[e] = 0.f;
+  }
+  for (int e = tid; e < par / 4; e += 256) reinterpret_cast<float4*>(PB)[e] = reinterpret_cast<const float4*>(a.layers[0].params)[e];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ef_barrier();
+
+  for (int l = 0; l < a.L; ++l) {
+    const EmfLayerW& w = a.layers[l];
+    const float* pb = PB + (l & 1) * par;
+    EF_STAMP(0);
+    // ---- prefetch: cached left-context rows of this layer's rings, [q|k|v] weights
+    float4 crk[EF_CR], crv[EF_CR];
+    {
+      const char* kbase = reinterpret_cast<const char*>(a.kring[l]);
+      const char* vbase = reinterpret_cast<const char*>(a.vring[l]);
+#pragma unroll
+      for (int i = 0; i < EF_CR; ++i) {
+        crk[i] = make_float4(0.f, 0.f, 0.f, 0.f); crv[i] = crk[i];
+        if (soff[i] >= 0) { crk[i] = *reinterpret_cast<const float4*>(kbase + (unsigned)soff[i]); crv[i] = *reinterpret_cast<const float4*>(vbase + (unsigned)soff[i]); }
+      }
+    }
+    float4 bqkv[TQ][KQD];
+#pragma unroll
+    for (int i = 0; i < TQ; ++i) {
+      const int t = wave + 4 * i;
+      if (t < 3 * KQD) {
+#pragma unroll
+        for (int kq = 0; kq < KQD; ++kq) bqkv[i][kq] = ef_frag(w.wqkv, t * KQD + kq, lane16);
+      } else {
+#pragma unroll
+        for (int kq = 0; kq < KQD; ++kq) bqkv[i][kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // 1. layer_norm_input
+    ef_layernorm<KQD>(X, Y, ld, pb + PB_LNIN, pb + PB_LNIN + D, tid);
+    ef_barrier();
+    EF_STAMP(1);
+    // 2. [q | k | v] = Y x [Wq | Wkv] + b : q (scaled) -> Qb, k / v -> key tables (+ ring append for utterance rows)
+    {
+      f32x4 accq[TQ];
+#pragma unroll
+      for (int i = 0; i < TQ; ++i) accq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ef_mma_tiles<TQ, KQD>(accq, bqkv, Y, ld, 0, lane);
+#pragma unroll
+      for (int i = 0; i < TQ; ++i) {
+        const int t = wave + 4 * i;
+        if (t < 3 * KQD) {
+          const int cl = lane & 15;
+          if (t < KQD) {
+            const float bias = pb[PB_BQ + t * 16 + cl];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) Qb[((lane >> 4) * 4 + r4) * ld + t * 16 + cl] = (accq[i][r4] + bias) * a.scaling;
+          } else {
+            const int ckv = (t - KQD) * 16 + cl;          // column in [k | v]
+            const float bias = pb[PB_BKV + ckv];
+            const bool isv = (t - KQD) >= KQD;            // wave-uniform (D is a multiple of 16)
+            const int c = isv ? ckv - D : ckv;
+            float* tab = isv ? VB : KB;
+            float* ring = isv ? a.vring[l] : a.kring[l];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float v = accq[i][r4] + bias;
+              if (tab_off[r4] >= 0) tab[tab_off[r4] + c] = v;
+              if (ring_off[r4] >= 0) ring[ring_off[r4] + c] = v;
+            }
+          }
+        }
+      }
+    }
+    // cached rows -> key tables
+#pragma unroll
+    for (int i = 0; i < EF_CR; ++i)
+      if (soff[i] >= 0) {
+        float* dk = KB + doff[i];
+        float* dv = VB + doff[i];
+        *reinterpret_cast<float2*>(dk) = make_float2(crk[i].x, crk[i].y);
+        *reinterpret_cast<float2*>(dk + 2) = make_float2(crk[i].z, crk[i].w);
+        *reinterpret_cast<float2*>(dv) = make_float2(crv[i].x, crv[i].y);
+        *reinterpret_cast<float2*>(dv + 2) = make_float2(crv[i].z, crv[i].w);
+      }
+    float4 bo[TO][KQD];
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+      const int t = wave + 4 * i;
+      if (t < KQD) {
+#pragma unroll
+        for (int kq = 0; kq < KQD; ++kq) bo[i][kq] = ef_frag(w.wo, t * KQD + kq, lane16);
+      }
+    }
+    ef_barrier();
+    EF_STAMP(2);
+    // 3. attention: a lane owns keys kk = lane16 + 16 j, keeps their K and V rows in registers, and the softmax /
+    //    P.V sums are DPP reductions over the 16-lane row (no LDS round trip)
+    {
+      const float* kb = KB + pg * nkmax * ldk + ph * DH;
+      const float* vb = VB + pg * nkmax * ldk + ph * DH;
+      const int jmax = (nkmax + 15) >> 4;               // block-uniform
+      float2 kreg[EF_MAXJ][DH / 2], vreg[EF_MAXJ][DH / 2];
+#pragma unroll
+      for (int j = 0; j < EF_MAXJ; ++j) {
+        if (j < jmax) {
+          const int kk = l16 + 16 * j;
+          const bool ok = kk < nk;
+#pragma unroll
+          for (int d = 0; d < DH / 2; ++d) {
+            kreg[j][d] = ok ? *reinterpret_cast<const float2*>(kb + kk * ldk + 2 * d) : make_float2(0.f, 0.f);
+            vreg[j][d] = ok ? *reinterpret_cast<const float2*>(vb + kk * ldk + 2 * d) : make_float2(0.f, 0.f);
+          }
+        }
+      }
+      for (int qi = 0; qi < Q; ++qi) {
+        const float* qp = Qb + (pg * Q + qi) * ld + ph * DH;
+        float2 q2[DH / 2];
+#pragma unroll
+        for (int d = 0; d < DH / 2; ++d) q2[d] = *reinterpret_cast<const float2*>(qp + 2 * d);
+        float sc[EF_MAXJ], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < EF_MAXJ; ++j) {
+          sc[j] = -INFINITY;
+          if (j < jmax) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int d = 0; d < DH / 2; ++d) { s0 += q2[d].x * kreg[j][d].x; s0 += q2[d].y * kreg[j][d].y; }
+            sc[j] = (l16 + 16 * j) < nk ? s0 : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+          }
+        }
+        mx = ef_row_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < EF_MAXJ; ++j) { sc[j] = (j < jmax && (l16 + 16 * j) < nk) ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+        const float inv = 1.0f / ef_row_sum(sum);
+        float o[DH];
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < EF_MAXJ; ++j)
+          if (j < jmax) {
+#pragma unroll
+            for (int d = 0; d < DH / 2; ++d) { o[2 * d] += sc[j] * vreg[j][d].x; o[2 * d + 1] += sc[j] * vreg[j][d].y; }
+          }
+        float mine = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) { const float t = ef_row_sum(o[d]); if (l16 == d) mine = t; }
+        if (pok && l16 < DH) ATT[(pg * Q + qi) * ld + ph * DH + l16] = mine * inv;
+      }
+    }
+    ef_barrier();
+    EF_STAMP(3);
+    // 4. out_proj + residual with the un-normalised layer input -> R1
+#pragma unroll
+    for (int i = 0; i < TO; ++i) {
+      const int t = wave + 4 * i;
+      if (t < KQD) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = ef_mma<KQD>(acc, bo[i], ATT, ld, 0, lane);
+        const int col = t * 16 + (lane & 15);
+        const float bias = pb[PB_BO + col];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) { const int r = (lane >> 4) * 4 + r4; R1[r * ld + col] = acc[r4] + bias + X[r * ld + col]; }
+      }
+    }
+    // 5. pos_ff: LN -> Linear(D, F) -> ReLU -> Linear(F, D); hidden in EF_HCHUNK-wide chunks, weights one phase ahead
+    float4 b1[T1][KQD];
+#pragma unroll
+    for (int t = 0; t < T1; ++t)
+#pragma unroll
+      for (int kq = 0; kq < KQD; ++kq) b1[t][kq] = ef_frag(w.w1, (wave * KQD + kq) * T1 + t, lane16);
+    ef_barrier();
+    EF_STAMP(4);
+    ef_layernorm<KQD>(R1, Y, ld, pb + PB_LNFF, pb + PB_LNFF + D, tid);
+    ef_barrier();
+    EF_STAMP(5);
+    f32x4 acc2[KQD];
+#pragma unroll
+    for (int t = 0; t < KQD; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 b2[KQD][KQ2];
+#pragma unroll
+    for (int kq = 0; kq < KQ2; ++kq)
+#pragma unroll
+      for (int t = 0; t < KQD; ++t) b2[t][kq] = ef_frag(w.w2, (wave * KQ2 + kq) * KQD + t, lane16);
+    for (int c0 = 0; c0 < a.F; c0 += EF_HCHUNK) {
+      const bool more = c0 + EF_HCHUNK < a.F;
+      const int un = (c0 + EF_HCHUNK) / 64 + wave;               // this wave's 64 hidden columns in the next chunk
+      EF_STAMPC(15);
+      EF_STAMPC(9);
+      // FF1: this wave's quarter of the chunk's hidden columns
+      {
+        f32x4 acc1[T1];
+#pragma unroll
+        for (int t = 0; t < T1; ++t) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ef_mma_tiles_refill<T1, KQD>(acc1, b1, Y, ld, 0, lane, [&](int kq) {
+          if (more && !EF_NOLOAD) {
+#pragma unroll
+            for (int t = 0; t < T1; ++t) b1[t][kq] = ef_frag(w.w1, (un * KQD + kq) * T1 + t, lane16);
+          }
+        });
+#pragma unroll
+        for (int t = 0; t < T1; ++t) {
+          const int nl = wave * (EF_HCHUNK / 4) + t * 16;
+          const float bias = pb[PB_B1 + c0 + nl + (lane & 15)];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) { const float v = acc1[t][r4] + bias; Hb[((lane >> 4) * 4 + r4) * ldh + nl + (lane & 15)] = v > 0.f ? v : 0.f; }
+        }
+      }
+      EF_STAMPC(10);
+      ef_barrier();
+      EF_STAMPC(11);
+      EF_STAMPC(12);
+      // FF2: all D output columns, this wave's quarter of the chunk's K
+      ef_mma_tiles_refill<KQD, KQ2>(acc2, b2, Hb, ldh, wave * (EF_HCHUNK / 4), lane, [&](int kq) {
+        if (more && !EF_NOLOAD) {
+#pragma unroll
+          for (int t = 0; t < KQD; ++t) b2[t][kq] = ef_frag(w.w2, (un * KQ2 + kq) * KQD + t, lane16);
+        }
+      });
+      EF_STAMPC(13);
+      ef_barrier();
+      EF_STAMPC(14);
+    }
+    EF_STAMP(6);
+    // next layer's parameters: in flight during the tail of this layer, parked in the other LDS parameter block
+    float4 np[EF_PP];
+    if (l + 1 < a.L) {
+      const float4* src = reinterpret_cast<const float4*>(a.layers[l + 1].params);
+#pragma unroll
+      for (int i = 0; i < EF_PP; ++i) { const int e = tid + 256 * i; np[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (e < par / 4) np[i] = src[e]; }
+    }
+#pragma unroll
+    for (int t = 0; t < KQD; ++t)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) RED[(wave * EF_ROWS + (lane >> 4) * 4 + r4) * ld + t * 16 + (lane & 15)] = acc2[t][r4];
+    ef_barrier();
+    EF_STAMP(7);
+    // + bias + residual -> ATT (reused as the pre-LN buffer), then layer_norm_output -> X
+    for (int e = tid; e < EF_ROWS * D; e += 256) {
+      const int r = e / D, c = e - r * D;
+      ATT[r * ld + c] = ((RED[(0 * EF_ROWS + r) * ld + c] + RED[(1 * EF_ROWS + r) * ld + c]) + (RED[(2 * EF_ROWS + r) * ld + c] + RED[(3 * EF_ROWS + r) * ld + c])) + pb[PB_B2 + c] + R1[r * ld + c];
+    }
+    ef_barrier();
+    ef_layernorm<KQD>(ATT, X, ld, pb + PB_LNOUT, pb + PB_LNOUT + D, tid);
+    if (l + 1 < a.L) {
+      float4* dst = reinterpret_cast<float4*>(PB + ((l + 1) & 1) * par);
+#pragma unroll
+      for (int i = 0; i < EF_PP; ++i) { const int e = tid + 256 * i; if (e < par / 4) dst[e] = np[i]; }
+    }
+    ef_barrier();
+    EF_STAMP(8);
+  }
+
+  // ---- outputs: utterance rows
+  if (a.out)
+    for (int e = tid; e < ng * U * D; e += 256) {
+      const int g = e / (U * D), rem = e - g * U * D, u = rem / D, c = rem - u * D;
+      a.out[((long long)(i0 + g) * U + u) * D + c] = X[(g * Q + R + u) * ld + c];
+    }
+  if (a.logits || a.codes) {
+    float* LG = Hb;                       // [16][K + 4]
+    const int ldl = a.K + 4;
+    if (a.wp) {
+      for (int t = wave; t < (a.K + 15) / 16; t += 4) {
+        float4 b[KQD];
+#pragma unroll
+        for (int kq = 0; kq < KQD; ++kq) b[kq] = ef_frag(a.wp, t * KQD + kq, lane16);
+        const int col = t * 16 + (lane & 15);
+        const float bias = col < a.K ? a.bp[col] : 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = ef_mma<KQD>(acc, b, X, ld, 0, lane);
+        if (col < a.K) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) LG[((lane >> 4) * 4 + r4) * ldl + col] = acc[r4] + bias;
+        }
+      }
+    } else {
+      for (int e = tid; e < EF_ROWS * D; e += 256) { const int r = e / D, c = e - r * D; LG[r * ldl + c] = X[r * ld + c]; }
+    }
+    ef_barrier();
+    // a 16-lane row per utterance token: copy out + first-index arg-max
+    for (int ru = tid >> 4; ru < G * U; ru += 16) {
+      const int g = ru / U, u = ru - g * U;
+      const bool ok = g < ng;
+      const float* row = LG + (g * Q + R + u) * ldl;
+      const long long orow = (long long)(i0 + g) * U + u;
+      float best = -INFINITY; int bi = 0x7fffffff;
+      for (int c = l16; c < a.K; c += 16) {
+        const float v = row[c];
+        if (ok && a.logits) a.logits[orow * a.K + c] = v;
+        if (v > best) { best = v; bi = c; }
+      }
+      const float m = ef_row_max(best);
+      bi = ef_row_min(best == m ? bi : 0x7fffffff);
+      if (ok && l16 == 0 && a.codes) a.codes[orow] = bi;
+    }
+  }
+  ef_barrier();
+  if (tid < ng) a.past[a.slots[i0 + tid]] += U;     // past_length += segment (torchaudio _pack_state)
+}
+
+size_t emformer_fused_smem(const EmfFusedArgs& a) {
+  const int D = a.D, Q = a.R + a.U, G = ef_streams_per_block(Q, a.H);
+  const int ld = D + 4, ldk = D + 2, nkmax = a.R + a.LC + a.U;
+  return (size_t)(EF_ROWS * ld * 5 + ef_scratch_floats(D, a.K) + 2 * (11 * D + a.F) + 2 * G * nkmax * ldk) * sizeof(float);
+}
+
+bool emformer_fused_supported(const EmfFusedArgs& a) {
+  const int Q = a.R + a.U;
+  if (Q < 1 || Q > EF_ROWS || a.H < 1 || a.H > 16) return false;
+  const int G = ef_streams_per_block(Q, a.H), nkmax = a.R + a.LC + a.U, dh = a.D / a.H;
+  return ((a.D == 80 && dh == 10) || (a.D == 64 && dh == 8)) && a.D % a.H == 0 && a.F % EF_HCHUNK == 0 && a.F >= EF_HCHUNK &&
+         11 * a.D + a.F <= EF_PP * 256 * 4 && nkmax <= 16 * EF_MAXJ && G * a.LC * (a.D / 4) <= EF_CR * 256 && a.L >= 1 && a.L <= EMF_MAX_LAYERS &&
+         (a.wp != nullptr || a.K == a.D) && emformer_fused_smem(a) <= 160 * 1024;
+}
+
+template <int KQD, int DH>
+static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
+  const int G = ef_streams_per_block(a.R + a.U, a.H);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)emformer_fused_kernel<KQD, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH>), dim3((a.n + G - 1) / G), dim3(256), emformer_fused_smem(a), st, a);
+}
+
+// instantiated shapes: (input_dim, head_dim) = (80, 10) is modules/Emformer/emformer.py's only configuration
+void launch_emformer_fused(const EmfFusedArgs& a, hipStream_t st) {
+  if (a.n <= 0) return;
+  if (a.D == 80 && a.D / a.H == 10) launch_ef<5, 10>(a, st);
+  else if (a.D == 64 && a.D / a.H == 8) launch_ef<4, 8>(a, st);
+}
+
+}  // namespace ck

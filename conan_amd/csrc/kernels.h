@@ -124,6 +124,34 @@ struct EmfAttnArgs {
 };
 void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st);
 
+// Whole streaming Emformer step in one launch (emformer_fused.hip): all layers + projection + arg-max.
+constexpr int EMF_MAX_LAYERS = 12;
+struct EmfLayerW {
+  // fragment-major weights (ctx.hip finalize_emformer): 1 KiB per (16-column tile, 16-row k-group) MFMA B operand
+  const float *wqkv, *wo, *w1, *w2;
+  // [bq D | bkv 2D | bo D | b2 D | ln_in g,b | ln_ff g,b | ln_out g,b | b1 F]: one contiguous block per layer
+  const float* params;
+};
+struct EmfFusedArgs {
+  EmfLayerW layers[EMF_MAX_LAYERS];
+  float* kring[EMF_MAX_LAYERS]; float* vring[EMF_MAX_LAYERS];          // [slot][LR][D]
+  long long ring_slot_stride;
+  const float* chunk;      // [n][U+R][D]  (utterance rows first, then the right context)
+  float* out;              // optional [n][U][D]
+  float* logits;           // optional [n][U][K]
+  int* codes;              // optional [n][U]
+  const float* wp; const float* bp;    // output projection, fragment-major (nullptr when output_dim == input_dim)
+  const int* slots; int* past;         // past[slot] is advanced by U at the end of the launch
+  int n, L, R, U, D, H, LC, lmask, F, K;
+#ifdef EF_STAMPS
+  unsigned long long* dbg;
+#endif
+  unsigned magic_per_g;   // ceil(2^32 / (max(LC,1) * D/4)): exact e / per_g for the prefetch units
+  float scaling;
+};
+bool emformer_fused_supported(const EmfFusedArgs& a);
+void launch_emformer_fused(const EmfFusedArgs& a, hipStream_t st);
+
 // Cross attention of the prosody aligner (nn.MultiheadAttention, 2 heads) against cached K/V.
 struct XAttnArgs {
   TRef q;              // [i][t][E]   already scaled by 1/sqrt(dh)

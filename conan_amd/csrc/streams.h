@@ -46,6 +46,8 @@ struct conan_streams {
   // --- emformer
   std::vector<Ring> e_k, e_v;
   Lin e_x[2], e_ln, e_q, e_kv, e_att, e_r1, e_ffn, e_h, e_r2, e_logits;
+  bool emf_fused = false;
+  ck::EmfFusedArgs emf_fused_args;
   // --- conan decoder
   Ring c_emb, c_pin2, c_uvh[4], c_lastr;
   std::vector<Ring> c_lnrs;     // post-LN rings, one per (block, sub-layer)

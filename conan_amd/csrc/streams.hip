@@ -194,11 +194,48 @@ void conan_streams::build_emformer() {
   e_x[0] = mk_lin(Q, D); e_x[1] = mk_lin(Q, D); e_ln = mk_lin(Q, D); e_q = mk_lin(Q, D); e_kv = mk_lin(Q, 2 * D);
   e_att = mk_lin(Q, D); e_r1 = mk_lin(Q, D); e_ffn = mk_lin(Q, D); e_h = mk_lin(Q, c.emf_ffn_dim); e_r2 = mk_lin(Q, D);
   e_logits = mk_lin(c.emf_segment, c.emf_output_dim);
+  // plan of the fused step; the per-op path below stays for shapes it does not cover (and CONAN_EMF_UNFUSED=1)
+  ck::EmfFusedArgs& a = emf_fused_args; memset(&a, 0, sizeof(a));
+  if (c.emf_layers <= ck::EMF_MAX_LAYERS) {
+    for (int l = 0; l < c.emf_layers; ++l) {
+      const std::string nm = "emf." + std::to_string(l);
+      ck::EmfLayerW& w = a.layers[l];
+      const ch::PackedConv &q = ctx->conv(nm + ".q"), &kv = ctx->conv(nm + ".kv"), &o = ctx->conv(nm + ".out"), &f1 = ctx->conv(nm + ".ff1"), &f2 = ctx->conv(nm + ".ff2");
+      if (D % 16 || c.emf_ffn_dim % 64) return;   // no fragment-major copies for such shapes: per-op path
+      w.wqkv = ctx->vec(nm + ".fqkv"); w.wo = ctx->vec(nm + ".fo"); w.w1 = ctx->vec(nm + ".f1"); w.w2 = ctx->vec(nm + ".f2");
+      {  // the layer's biases and LayerNorm vectors as one block (EmfLayerW::params)
+        const int F = c.emf_ffn_dim;
+        float* pb = alloc((size_t)11 * D + F);
+        auto put = [&](int off, const float* src, int n) { HIP_CHECK(hipMemcpy(pb + off, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice)); };
+        put(0, q.bias, D); put(D, kv.bias, 2 * D); put(3 * D, o.bias, D); put(4 * D, f2.bias, D);
+        put(5 * D, ctx->vec(nm + ".ln_in.g"), D); put(6 * D, ctx->vec(nm + ".ln_in.b"), D);
+        put(7 * D, ctx->vec(nm + ".ln_ff.g"), D); put(8 * D, ctx->vec(nm + ".ln_ff.b"), D);
+        put(9 * D, ctx->vec(nm + ".ln_out.g"), D); put(10 * D, ctx->vec(nm + ".ln_out.b"), D);
+        put(11 * D, f1.bias, F);
+        w.params = pb;
+      }
+      a.kring[l] = e_k[l].base; a.vring[l] = e_v[l].base;
+    }
+    a.ring_slot_stride = e_k[0].slot_stride; a.lmask = e_k[0].L - 1;
+    if (c.emf_output_dim != D) { a.wp = ctx->vec("emf.fproj"); a.bp = ctx->conv("emf.proj").bias; }
+    a.slots = d_slots; a.past = pos_emf;
+    a.L = c.emf_layers; a.R = c.emf_right_context; a.U = c.emf_segment; a.D = D; a.H = c.emf_heads; a.LC = c.emf_left_context;
+    a.F = c.emf_ffn_dim; a.K = c.emf_output_dim; a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
+    { const unsigned long long per_g = (unsigned long long)std::max(c.emf_left_context, 1) * (D / 4); a.magic_per_g = (unsigned)(((1ull << 32) + per_g - 1) / per_g); }
+    const char* off = getenv("CONAN_EMF_UNFUSED");
+    emf_fused = ck::emformer_fused_supported(a) && !(off && off[0] == '1');
+  }
 }
 
 void conan_streams::emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st) {
   const conan_cfg& c = ctx->cfg;
   const int D = c.emf_input_dim, R = c.emf_right_context, U = c.emf_segment, Q = R + U;
+  if (emf_fused) {   // whole step in one launch (emformer_fused.hip)
+    ck::EmfFusedArgs a = emf_fused_args;
+    a.chunk = chunk; a.out = out; a.logits = logits; a.codes = codes; a.n = n;
+    ck::launch_emformer_fused(a, st);
+    return;
+  }
   // token order inside the layers is [right_context | utterance] (torchaudio _EmformerLayer.infer): reorder the chunk
   {
     ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
