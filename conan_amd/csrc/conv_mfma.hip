@@ -19,6 +19,12 @@
 // longer K-step amortises the per-step load latency and barrier.
 #include <type_traits>
 
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <queue>
+#include <vector>
+
 #include "kernels.h"
 
 namespace ck {
@@ -90,7 +96,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   float* const red = lds + L::STAGE + L::PATCH;
 
   // ---- launch-uniform scalars, read once (keeps the K loop free of kernarg re-loads)
-  const int T = a.T, nslot = a.n, ktaps = a.ktaps, dil = a.dil, Cin = a.Cin, CoutP = a.Cout_pad, Cout = a.Cout;
+  const int T = a.T, nslot = a.n, ktaps = a.ktaps, dil = a.dil, Cin = a.Cin, Cout = a.Cout;
   const int Mtot = nslot * T;
   const int* __restrict__ slots = a.slots;
   const int* __restrict__ posp = a.pos;
@@ -179,9 +185,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       const int xC = a.x[0].C;
       const int xmask = xring ? a.x[0].lmask : -1;
       const int ci4n = a.Cin_alloc >> 2;
+      // weights are packed per group of 64 output columns: [n/64][tap][Cin_alloc/4][64][4] (1 KiB rows)
+      const float* wgrp = wbase + ((long long)(n0 >> 6) * ktaps * ci4n * 64 + (n0 & 63)) * 4;
       int woff[WV];
 #pragma unroll
-      for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
+      for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * 64 + co) * 4; }
       int jn = ks_lo % ktaps, cbn = ks_lo / ktaps;
       auto issue = [&](int buf) __attribute__((always_inline)) {
         const int j = jn, cb = cbn;
@@ -197,7 +205,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
           const float* p = ok ? arowbase[u] + r * xC + col : arowbase[u];
           __builtin_amdgcn_global_load_lds(p, As + ((u * 4 + lwave) * RPI) * LDA, 16, 0, 0);
         }
-        const float* wstep = wbase + ((long long)(j * ci4n + cb * (KS / 4)) * CoutP + n0) * 4;
+        const float* wstep = wgrp + (long long)(j * ci4n + cb * (KS / 4)) * 256;
 #pragma unroll
         for (int v = 0; v < WV; ++v) {
           const int o = woff[v];
@@ -262,11 +270,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
     const int xC = a.x[0].C;
     const int xmask = xring ? a.x[0].lmask : -1;
     const int ci4n = a.Cin_alloc >> 2;
+    const float* wgrp = wbase + ((long long)(n0 >> 6) * ktaps * ci4n * 64 + (n0 & 63)) * 4;
     const float neg_mul = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
     static_assert(WV >= 1 && WV <= 8, "W staging vectors per thread");
     int woff[WV];      // per-thread W staging offsets (floats, relative to the K-step's tile base)
 #pragma unroll
-    for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * CoutP + co) * 4; }
+    for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * 64 + co) * 4; }
     int jn = ks_lo % ktaps, cbn = ks_lo / ktaps;   // (tap, channel block) of the next K-step to issue; tap index fastest so that
                            // consecutive steps re-touch the same activation rows (L1/L2 hits)
 
@@ -301,7 +310,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
           ok##S |= (ok ? 1u : 0u) << (q * SB + sb);                                                       \
         }                                                                                                 \
       }                                                                                                   \
-      const float* wstep = wbase + ((long long)(j * ci4n + cb * (KS / 4)) * CoutP + n0) * 4;              \
+      const float* wstep = wgrp + (long long)(j * ci4n + cb * (KS / 4)) * 256;                            \
       CK_W_ISSUE(S, 0) CK_W_ISSUE(S, 1) CK_W_ISSUE(S, 2) CK_W_ISSUE(S, 3)                                 \
       CK_W_ISSUE(S, 4) CK_W_ISSUE(S, 5) CK_W_ISSUE(S, 6) CK_W_ISSUE(S, 7)                                 \
       if (++jn == ktaps) { jn = 0; ++cbn; }                                                               \
@@ -377,49 +386,73 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #else
 #define CK_CSTAMP(acc)
 #endif
-  for (int ks = 0; ks < nks; ++ks) {
-    const float* As = lds + bufc * (A_FLOATS + W_FLOATS);
-    const float* Ws = As + A_FLOATS;
-    if (++bufc == NBUF) bufc = 0;
-    if constexpr (GLDS) asm volatile("s_barrier" ::: "memory");   // B(ks): tile ks landed in LDS (clobber: no LDS read may move above it)
-    else __syncthreads();                                // step ks staged by the loader waves
-    CK_CSTAMP(c_wait)
-#pragma unroll
-    for (int kc = 0; kc < NKQ / WK; ++kc) {
-      const int kq = kc * WK + wk;      // fixed trip count: no divergent control flow around the MFMAs
-      float4 af[RM], bf[RN];
-#pragma unroll
-      for (int rm = 0; rm < RM; ++rm) {
-        const int R = (wm * RM + rm) * 32 + l31;
-        if constexpr (GLDS) {
-          const int sw = (KS == 32) ? ((R >> 1) & 7) : (R & 15);
-          float4 v = *reinterpret_cast<const float4*>(As + R * LDA + (((kq * 2 + lh) ^ sw) * 4));
+  // The direct-to-LDS loader cannot transform on the way, so a LeakyReLU on the conv input has to be applied to the A
+  // fragments here - a dozen VALU ops per k-group that cost a quarter of the matrix rate (tools/kloop_rate).  The
+  // loop is therefore compiled twice and the hot layers are fed pre-activated tensors (ConvArgs::y2_base).
+  auto kloop = [&](auto xf_tag) __attribute__((always_inline)) {
+    constexpr bool XF = decltype(xf_tag)::value;
+    for (int ks = 0; ks < nks; ++ks) {
+      const float* As = lds + bufc * (A_FLOATS + W_FLOATS);
+      const float* Ws = As + A_FLOATS;
+      if (++bufc == NBUF) bufc = 0;
+      if constexpr (GLDS) asm volatile("s_barrier" ::: "memory");   // B(ks): tile ks landed in LDS (clobber: no LDS read may move above it)
+      else __syncthreads();                                // step ks staged by the loader waves
+      CK_CSTAMP(c_wait)
+      // Fragments are double-buffered by hand: the ds_reads of k-group kc+1 are issued before the MFMAs of k-group kc,
+      // so only the first read after the barrier is exposed (left to itself the compiler reuses one register set and
+      // every k-group starts with a full LDS round trip - a third of the step time).
+      constexpr int NKC = NKQ / WK;
+      float4 af[2][RM], bf[2][RN];
+      auto load_frag = [&](const int kc, float4 (&fa)[RM], float4 (&fb)[RN]) __attribute__((always_inline)) {
+        const int kq = kc * WK + wk;      // fixed trip count: no divergent control flow around the MFMAs
+  #pragma unroll
+        for (int rm = 0; rm < RM; ++rm) {
+          const int R = (wm * RM + rm) * 32 + l31;
+          if constexpr (GLDS) {
+            const int sw = (KS == 32) ? ((R >> 1) & 7) : (R & 15);
+            fa[rm] = *reinterpret_cast<const float4*>(As + R * LDA + (((kq * 2 + lh) ^ sw) * 4));
+          } else {
+            fa[rm] = *reinterpret_cast<const float4*>(As + R * LDA + kq * 8 + lh * 4);
+          }
+        }
+  #pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+          fb[rn] = *reinterpret_cast<const float4*>(Ws + ((kq * 2 + lh) * TN + (wn * RN + rn) * 32 + l31) * 4);
+      };
+      load_frag(0, af[0], bf[0]);
+  #pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        if (kc + 1 < NKC) load_frag(kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above this k-group's MFMAs
+        float4 (&fa)[RM] = af[kc & 1];
+        float4 (&fb)[RN] = bf[kc & 1];
+        if constexpr (GLDS && XF) {
           // the loader cannot transform on the way: LeakyReLU of the conv input is applied here
-          v.x *= v.x > 0.f ? 1.0f : neg_mul_c; v.y *= v.y > 0.f ? 1.0f : neg_mul_c;
-          v.z *= v.z > 0.f ? 1.0f : neg_mul_c; v.w *= v.w > 0.f ? 1.0f : neg_mul_c;
-          af[rm] = v;
-        } else {
-          af[rm] = *reinterpret_cast<const float4*>(As + R * LDA + kq * 8 + lh * 4);
+  #pragma unroll
+          for (int rm = 0; rm < RM; ++rm) {
+            float4 v = fa[rm];
+            v.x *= v.x > 0.f ? 1.0f : neg_mul_c; v.y *= v.y > 0.f ? 1.0f : neg_mul_c;
+            v.z *= v.z > 0.f ? 1.0f : neg_mul_c; v.w *= v.w > 0.f ? 1.0f : neg_mul_c;
+            fa[rm] = v;
+          }
         }
+  #pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+  #pragma unroll
+          for (int rn = 0; rn < RN; ++rn) {
+            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].x, fb[rn].x, acc[rm][rn], 0, 0, 0);
+            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].y, fb[rn].y, acc[rm][rn], 0, 0, 0);
+            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].z, fb[rn].z, acc[rm][rn], 0, 0, 0);
+            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].w, fb[rn].w, acc[rm][rn], 0, 0, 0);
+          }
       }
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
-        bf[rn] = *reinterpret_cast<const float4*>(Ws + ((kq * 2 + lh) * TN + (wn * RN + rn) * 32 + l31) * 4);
-#pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
-#pragma unroll
-        for (int rn = 0; rn < RN; ++rn) {
-          acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rm].x, bf[rn].x, acc[rm][rn], 0, 0, 0);
-          acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rm].y, bf[rn].y, acc[rm][rn], 0, 0, 0);
-          acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rm].z, bf[rn].z, acc[rm][rn], 0, 0, 0);
-          acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rm].w, bf[rn].w, acc[rm][rn], 0, 0, 0);
-        }
+  #ifdef CK_STAMPS
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+  #endif
+      CK_CSTAMP(c_comp)
     }
-#ifdef CK_STAMPS
-    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
-#endif
-    CK_CSTAMP(c_comp)
-  }
+  };
+  if (GLDS && a.in_act == ACT_LRELU) kloop(std::true_type{}); else kloop(std::false_type{});
 #ifdef CK_STAMPS
   const unsigned long long c_kend = __builtin_amdgcn_s_memtime();
 #endif
@@ -511,6 +544,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   const int yC = a.y.C, ymask = yring ? a.y.lmask : -1, yrate = a.y.rate, yoff = a.y.off;
   const long long yss = a.y.slot_stride;
   float* const ybase0 = a.y.base;
+  float* const y2base0 = a.y2_base;      // activated copy (vectorised layouts only; launch_conv checks)
+  const float y2slope = a.y2_slope;
   const bool has_res = a.has_res != 0, has_bvec = a.bvec != nullptr;
   const bool vec_ok = ((Cout & 3) == 0) && ((yC & 3) == 0) && ((Cq & 3) == 0);
   float* patch = lds + STAGE_FLOATS_TOTAL + wave * (32 * EPI_LD);
@@ -644,7 +679,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
             float* ybase = ybase0 + (long long)(yring ? rslot[gq] : ri[gq]) * yss;
             const int yrow = ((yring ? rpos[gq] * yrate : 0) + yoff + rt[gq] * shuf + jj) & ymask;
             float* dst = ybase + yrow * yC + ocol;
-            if (vec_ok) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            if (vec_ok) {
+              *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+              if (y2base0) {
+                float* dst2 = y2base0 + (dst - ybase0);
+                *reinterpret_cast<float4*>(dst2) = make_float4(o[0] > 0.f ? o[0] : o[0] * y2slope, o[1] > 0.f ? o[1] : o[1] * y2slope,
+                                                               o[2] > 0.f ? o[2] : o[2] * y2slope, o[3] > 0.f ? o[3] : o[3] * y2slope);
+              }
+            }
             else {
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
@@ -683,15 +725,29 @@ __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4 > 80
   __shared__ __attribute__((aligned(16))) float lds[ConvLds<TM, TN, WK, KS, NSRC>::TOTAL];
   int gbuf = 0;
   const int S = g.ksplit;
-  for (int item = blockIdx.x; item < g.tile_start[3] * S; item += gridDim.x) {
-    const int tile = item / S, kslice = item - tile * S;      // slices of a tile are adjacent: they finish together
+  const int total = g.tile_start[3] * S;
+#ifdef CK_STAMPS
+  if (g.p[0].dbg && threadIdx.x == 0 && blockIdx.x < 512) g.p[0].dbg[32 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // Work items: round-robin over the grid, or - for persistent launches - the list launch_conv balanced on the host
+  // (the three branches of a grouped resblock launch have k = 11 / 7 / 3, so equal tile counts are unequal work).
+  const int* const assign = g.assign ? g.assign + (long long)blockIdx.x * g.assign_per : nullptr;
+  int i = 0;
+  int cur = assign ? assign[0] : (int)blockIdx.x;
+  while (cur >= 0 && cur < total) {
+    const int tile = cur / S, kslice = cur - tile * S;        // slices of a tile are adjacent: they finish together
     const int p = (tile >= g.tile_start[1] ? 1 : 0) + (tile >= g.tile_start[2] ? 1 : 0);
     const int local = tile - g.tile_start[p];
     const int tn = g.tiles_n[p];
     const int mt = local / tn, nt = local - mt * tn;
     conv_tile<TM, TN, WM, WN, WK, KS, NSRC>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, S,
                                             g.slab + (long long)tile * S * (TM * TN), g.counters + tile);
+    ++i;
+    cur = assign ? (i < g.assign_per ? assign[i] : -1) : cur + (int)gridDim.x;
   }
+#ifdef CK_STAMPS
+  if (g.p[0].dbg && threadIdx.x == 0 && blockIdx.x < 512) g.p[0].dbg[32 + blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 static const int kTM[NUM_CFG] = {128, 64, 128, 32, 32, 64, 64, 128, 128};
@@ -699,12 +755,54 @@ static const int kTN[NUM_CFG] = {64, 64, 32, 64, 32, 32, 64, 64, 32};
 int conv_cfg_tm(int cfg) { return kTM[cfg]; }
 int conv_cfg_tn(int cfg) { return kTN[cfg]; }
 
+// Balanced schedule of a persistent launch: longest-processing-time-first assignment of the (already longest-first)
+// item list to the grid's blocks; cost of an item = its K-steps + a constant for prologue/epilogue.  Cached per launch
+// shape in device memory (a handful of shapes per model; never freed).
+static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int* per_out) {
+  struct Key { int v[9]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
+  static std::map<Key, std::pair<const int*, int>> cache;
+  int nks[3];
+  for (int q = 0; q < 3; ++q) { const ConvArgs& a = g.p[g.order[q]]; nks[q] = a.ktaps * ((a.Cin_pad + KS - 1) / KS); }
+  Key k = {{grid, g.tile_start[1], g.tile_start[2], g.tile_start[3], nks[0], nks[1], nks[2], KS, 0}};
+  auto it = cache.find(k);
+  if (it != cache.end()) { *per_out = it->second.second; return it->second.first; }
+  const int total = g.tile_start[3];
+  std::vector<std::vector<int>> lists(grid);
+  std::priority_queue<std::pair<long long, int>, std::vector<std::pair<long long, int>>, std::greater<std::pair<long long, int>>> heap;
+  for (int b = 0; b < grid; ++b) heap.push({0, b});
+  for (int item = 0; item < total; ++item) {
+    const int q = (item >= g.tile_start[1] ? 1 : 0) + (item >= g.tile_start[2] ? 1 : 0);
+    auto top = heap.top(); heap.pop();
+    lists[top.second].push_back(item);
+    heap.push({top.first + nks[q] + 3, top.second});
+  }
+  // The two blocks that share a CU (b and b + grid/2 under in-order dispatch) would otherwise walk equal-length
+  // tiles in lockstep and reach their epilogues - where the matrix pipe idles - together: run the second half's lists
+  // shortest-first so one block's epilogue overlaps the other's K loop.
+  for (int b = grid / 2; b < grid; ++b) std::reverse(lists[b].begin(), lists[b].end());
+  size_t per = 1;
+  for (auto& l : lists) per = std::max(per, l.size() + 1);
+  std::vector<int> flat((size_t)grid * per, -1);
+  for (int b = 0; b < grid; ++b) std::copy(lists[b].begin(), lists[b].end(), flat.begin() + (size_t)b * per);
+  int* dev = nullptr;
+  if (hipMalloc(&dev, flat.size() * sizeof(int)) != hipSuccess) { *per_out = 0; return nullptr; }
+  (void)hipMemcpy(dev, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice);
+  cache[k] = {dev, (int)per};
+  *per_out = (int)per;
+  return dev;
+}
+
 template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
-static void launch_one(const ConvGroup& g, int num_cu, hipStream_t st) {
+static void launch_one(const ConvGroup& gin, int num_cu, hipStream_t st) {
   constexpr int lds_bytes = ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4;
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  ConvGroup g = gin;
+  g.assign = nullptr; g.assign_per = 0;
   int grid = g.tile_start[3] * g.ksplit;
-  if (NSRC == 1 && grid > num_cu * per_cu) grid = num_cu * per_cu;     // persistent blocks (direct-to-LDS build only)
+  if (NSRC == 1 && grid > num_cu * per_cu) {     // persistent blocks (direct-to-LDS build only)
+    grid = num_cu * per_cu;
+    if (g.ksplit == 1) g.assign = balanced_assignment(g, grid, KS, &g.assign_per);
+  }
   hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, WK, KS, NSRC>), dim3(grid), dim3(512), 0, st, g);
 }
 

@@ -71,7 +71,7 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
     if (bias) B[col] = bias[co];
     for (int ci = 0; ci < Cin; ++ci)
       for (int j = 0; j < k; ++j)
-        P[(((size_t)j * (pc.Cin_alloc / 4) + ci / 4) * pc.Cout_pad + col) * 4 + (ci & 3)] = W[((size_t)co * Cin + ci) * k + j];
+        P[((((size_t)(col / 64) * k + j) * (pc.Cin_alloc / 4) + ci / 4) * 64 + (col % 64)) * 4 + (ci & 3)] = W[((size_t)co * Cin + ci) * k + j];
   }
   pc.w = upload(P);
   pc.bias = upload(B);

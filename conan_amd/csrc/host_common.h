@@ -29,7 +29,9 @@ struct HostTensor {
   int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
 };
 
-// A conv / linear weight repacked for conv_mfma: [taps][Cin_pad/4][Cout_pad][4], zero padded.
+// A conv / linear weight repacked for conv_mfma: [Cout_pad/64][taps][Cin_alloc/4][64][4], zero padded: per group of
+// 64 output columns the K rows are 1 KiB apart whatever Cout is (a [K][Cout_pad] layout makes a W tile touch one
+// page per row when Cout is large).
 struct PackedConv {
   float* w = nullptr;
   float* bias = nullptr;   // [Cout_pad] (zeros when the layer has no bias)

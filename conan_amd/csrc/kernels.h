@@ -51,6 +51,10 @@ struct ConvArgs {
   float out_scale, out_slope;
   int shuffle_r;
   int Cin_alloc;        // packed rows per tap (Cin rounded up to 128, zero filled): K-steps may over-read safely
+  // optional second output: LeakyReLU(y2_slope) of the stored value, written to a tensor with y's geometry (only the
+  // base differs).  The consumer then reads pre-activated rows and its K loop needs no input transform.
+  float* y2_base;
+  float y2_slope;
 #ifdef CK_STAMPS
   unsigned long long* dbg;   // developer build only (tools/conv_bench -DCK_STAMPS): s_memtime stamps of block 1
 #endif
@@ -66,8 +70,11 @@ struct ConvGroup {      // up to 3 independent problems in one launch
   // elects the last-arriving block as the reducer.
   float* slab;
   int* counters;
+  // balanced static schedule (filled by launch_conv for persistent launches): block b runs items
+  // assign[b * assign_per + i], i = 0 .. until -1.  nullptr = round-robin over the grid.
+  const int* assign;
+  int assign_per;
   int ksplit;
-  int pad_;
 };
 
 // Tile configurations of conv_mfma (block = 256 threads = 4 waves).

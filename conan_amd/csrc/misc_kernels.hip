@@ -121,7 +121,6 @@ void launch_embed(const EmbedArgs& a, hipStream_t st) {
 // registers for all query tokens; softmax and the weighted value sum are 64-lane shuffle reductions.
 constexpr int EMF_MAX_DH = 16;
 constexpr int EMF_MAX_KPL = 2;   // keys per lane: up to 128 keys
-constexpr int EMF_MAX_QD = 16 * 512;
 __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float esm[];
   const int i = blockIdx.x;

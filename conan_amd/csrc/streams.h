@@ -15,8 +15,10 @@ constexpr int PADR = 16;   // zero rows before/after a reference utterance in th
 
 struct VocStage {
   Ring up;                                  // ups[i] output (pixel shuffled), also residual source
+  Ring upa;                                 // leaky_relu(up): c1 operand
   Ring xs;                                  // leaky_relu(mean of the branches): input of ups[i+1] / conv_post
-  std::vector<std::vector<Ring>> xt, xo;    // [branch][dilation]
+  std::vector<std::vector<Ring>> xt, xo;    // [branch][dilation]; xt is stored activated
+  std::vector<std::vector<Ring>> xa;        // leaky_relu(xo) for the outputs that feed another c1
   int C = 0, rate = 1;
 };
 

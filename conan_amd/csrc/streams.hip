@@ -46,6 +46,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     bool ring = a.y.mode == 0 || (a.has_res && a.res.mode == 0) || (a.has_m1 && a.m1.mode == 0) || (a.has_m2 && a.m2.mode == 0) || a.bvec != nullptr;
     for (int q = 0; q < a.nsrc; ++q) ring = ring || a.x[q].mode == 0;
     if (!ring) { a.slots = nullptr; a.pos = nullptr; }
+    if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
   g.slab = sk_slab; g.counters = sk_counters; g.ksplit = 1;
@@ -111,13 +112,17 @@ void conan_streams::build_vocoder() {
     s.up = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
     const int next_pad = (i + 1 < c.voc_num_ups) ? c.voc_up_kernels[i + 1] - 1 : 6;
     s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
-    s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks);
+    // LeakyReLU'd twins of `up` and of the resblock outputs that feed another c1: the producer's epilogue writes both
+    // (ConvArgs::y2_base), c1 reads the activated copy, the residual add reads the raw one
+    s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
+    s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks); s.xa.resize(c.voc_num_resblocks);
     for (int b = 0; b < c.voc_num_resblocks; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d) {
         const int k = c.voc_rb_kernels[b];
         s.xt[b].push_back(mk_ring(ch_, rate, k - 1, &voc_state));
         const int h = (d + 1 < c.voc_rb_num_dil) ? (k - 1) * c.voc_rb_dilations[b][d + 1] : next_pad;
         s.xo[b].push_back(mk_ring(ch_, rate, h, &voc_state));
+        if (d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
       }
   }
 }
@@ -132,7 +137,11 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     ca.slots = d_slots; ca.pos = pos; ca.lens = nullptr; ca.T = frames; ca.n = n; ca.C = c.num_mels;
     ck::launch_copy_rows(ca, st);
   }
-  conv(mk(ctx->conv("voc.conv_pre"), v_mel.ref(), v_pre.ref(), n, frames, pos), st);
+  {  // conv_pre; its only consumer is leaky_relu -> ups[0] (hifigan_causal.py:319-322), so the activation is stored
+    ConvArgs a = mk(ctx->conv("voc.conv_pre"), v_mel.ref(), v_pre.ref(), n, frames, pos);
+    a.out_act = ck::ACT_LRELU; a.out_slope = LR;
+    conv(a, st);
+  }
   const int NB = c.voc_num_resblocks, ND = c.voc_rb_num_dil;
   if (NB > kMaxBranches) throw Error(CONAN_ERR_UNSUPPORTED, "more than 3 resblock branches");
   int ridx = 0;
@@ -140,22 +149,25 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     VocStage& s = v_st[i];
     const int Tin = frames * (s.rate / c.voc_up_rates[i]);
     const int T = frames * s.rate;
-    {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322); for i > 0 the activated branch mean is in xs
+    {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322): the input (v_pre / branch mean xs) is stored
+       // activated; the output goes out raw (residual operand) and activated (c1 operand)
       ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos);
-      if (i == 0) { a.in_act = ck::ACT_LRELU; a.in_slope = LR; }
+      a.y2_base = s.upa.base; a.y2_slope = LR;
       conv(a, st);
     }
     for (int d = 0; d < ND; ++d) {  // ResBlock1 (hifigan_causal.py:230-238), the NB branches as one grouped launch
       ConvGroup g1, g2;
       for (int b = 0; b < NB; ++b) {
+        // xt = c1(leaky_relu(x)); x = c2(leaky_relu(xt)) + x: both activations are applied where the tensor is written
         const TRef xin = d == 0 ? s.up.ref() : s.xo[b][d - 1].ref();
+        const TRef xin_act = d == 0 ? s.upa.ref() : s.xa[b][d - 1].ref();
         std::string base = "voc.rb." + std::to_string(ridx + b);
-        ConvArgs a1 = mk(ctx->conv(base + ".c1." + std::to_string(d)), xin, s.xt[b][d].ref(), n, T, pos, c.voc_rb_dilations[b][d]);
-        a1.in_act = ck::ACT_LRELU; a1.in_slope = LR;
+        ConvArgs a1 = mk(ctx->conv(base + ".c1." + std::to_string(d)), xin_act, s.xt[b][d].ref(), n, T, pos, c.voc_rb_dilations[b][d]);
+        a1.out_act = ck::ACT_LRELU; a1.out_slope = LR;
         g1.p[b] = a1;
         ConvArgs a2 = mk(ctx->conv(base + ".c2." + std::to_string(d)), s.xt[b][d].ref(), s.xo[b][d].ref(), n, T, pos, 1);
-        a2.in_act = ck::ACT_LRELU; a2.in_slope = LR;
         a2.res = xin; a2.has_res = 1;
+        if (d + 1 < ND) { a2.y2_base = s.xa[b][d].base; a2.y2_slope = LR; }
         g2.p[b] = a2;
       }
       const int cfg = pick_cfg(n * T, s.C, NB);

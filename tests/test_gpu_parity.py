@@ -89,7 +89,7 @@ def test_hifigan_long_steps_and_ragged_frames(env):
     st.close()
 
 
-def test_emformer_stream_vs_oracle(env):
+def _emformer_stream_vs_oracle(env):
     from oracle import emformer as oemf
     tag, ctx, chp, vhp, sds = env
     cfg = oemf.EmformerCfg(chp)
@@ -109,6 +109,17 @@ def test_emformer_stream_vs_oracle(env):
         safe = (top2[..., 0] - top2[..., 1]) > 1e-3
         assert torch.equal(codes.cpu().long()[safe], codes_ref[safe])
     st.close()
+
+
+def test_emformer_stream_vs_oracle(env):
+    """The fused whole-step kernel (emformer_fused.hip): 3 streams on 2 blocks, 18 chunks (the K/V rings wrap)."""
+    _emformer_stream_vs_oracle(env)
+
+
+def test_emformer_per_op_path_vs_oracle(env, monkeypatch):
+    """The per-op launch plan that covers shapes the fused kernel does not (CONAN_EMF_UNFUSED=1 selects it)."""
+    monkeypatch.setenv("CONAN_EMF_UNFUSED", "1")
+    _emformer_stream_vs_oracle(env)
 
 
 def test_conan_decoder_vs_oracle_and_golden(env):

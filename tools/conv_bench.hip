@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "kernels.h"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -43,7 +44,7 @@ int main(int argc, char** argv) {
     size_t xfl = (size_t)nslots * Lr * s.Cin, yfl = (size_t)nslots * Lr * s.Cout;
     float *x, *y, *w, *b; int *slots, *pos;
 #ifdef CK_STAMPS
-    unsigned long long* dbg; CHECK(hipMalloc(&dbg, 128)); CHECK(hipMemset(dbg, 0, 128));
+    unsigned long long* dbg; CHECK(hipMalloc(&dbg, (32 + 1024) * 8)); CHECK(hipMemset(dbg, 0, (32 + 1024) * 8));
 #endif
     CHECK(hipMalloc(&x, xfl * 4 * 3)); CHECK(hipMalloc(&y, yfl * 4 * 3));
     int Cin_pad = (s.Cin + 31) / 32 * 32, Cin_alloc = (s.Cin + 127) / 128 * 128, Cout_pad = (s.Cout + 63) / 64 * 64;
@@ -85,6 +86,16 @@ int main(int argc, char** argv) {
 #ifdef CK_STAMPS
     { unsigned long long h[16]; CHECK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost)); double n = (double)h[2];
       printf("      [block 1] matrix wave: barrier-wait/step=%.0f mfma/step=%.0f kloop=%llu epilogue=%llu | loader: vmcnt-wait/step=%.0f barrier/step=%.0f issue/step=%.0f (cycles); in-kernel clock %.2f GHz\n", h[0] / n, h[1] / n, h[3], h[4], h[8] / n, h[9] / n, h[10] / n, (double)h[5] / (double)h[6] * 0.1); }
+    { std::vector<unsigned long long> h(32 + 1024); CHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> st, en; unsigned long long t0 = ~0ull;
+      for (int b = 0; b < 512; ++b) if (h[32 + 2 * b]) t0 = std::min(t0, h[32 + 2 * b]);
+      for (int b = 0; b < 512; ++b) if (h[32 + 2 * b]) { st.push_back((h[32 + 2 * b] - t0) * 0.01); en.push_back((h[33 + 2 * b] - t0) * 0.01); }
+      if (!st.empty()) { std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); const size_t n = st.size();
+        { double byx[8] = {0}; int nx[8] = {0}; double byq[8] = {0}; int nq[8] = {0};
+          for (int b = 0; b < 512; ++b) if (h[32 + 2 * b]) { const double e = (h[33 + 2 * b] - t0) * 0.01; byx[b % 8] += e; nx[b % 8]++; byq[b / 64] += e; nq[b / 64]++; }
+          printf("      mean end by blockIdx%%8:"); for (int i = 0; i < 8; ++i) printf(" %.1f", nx[i] ? byx[i] / nx[i] : 0.0);
+          printf(" | by blockIdx/64:"); for (int i = 0; i < 8; ++i) printf(" %.1f", nq[i] ? byq[i] / nq[i] : 0.0); printf("\n"); }
+        printf("      block timeline (us, %zu blocks): start p50 %.1f p90 %.1f max %.1f | end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f\n", n, st[n / 2], st[n * 9 / 10], st[n - 1], en[0], en[n / 10], en[n / 2], en[n * 9 / 10], en[n - 1]); } }
 #endif
     hipFree(x); hipFree(y); hipFree(w); hipFree(b); hipFree(slots); hipFree(pos);
   }
