@@ -162,29 +162,34 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       const int lwave = __builtin_amdgcn_readfirstlane(ltid >> 6);
       const int prow = lane / CPR;                     // row inside one wave instruction
       const int pchunk = lane % CPR;                   // physical chunk written by this lane
-      const float* arowbase[NA];
-      int abrow[NA], acol[NA];
-      unsigned avalid = 0;
+      // Per-lane address state is 32-bit float offsets from the (uniform) tensor base, so a load is "scalar base +
+      // VGPR offset" and a K-step costs ~5 vector instructions per A load: the loader waves share their SIMD's issue
+      // slots with MFMA-saturated matrix waves, and every VALU instruction here shows up in the step time.
+      int abrow[NA], aoff[NA], amask[NA], amask_last[NA];     // masks: all ones for lanes that load, 0 otherwise
       const bool xring = a.x[0].mode == 0;
+      const float* const xb = a.x[0].base;
       {
         const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
         const long long xss = a.x[0].slot_stride;
-        const float* xb = a.x[0].base;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
           const int ml = (u * 4 + lwave) * RPI + prow;
           int i, t, slot, pv;
           rowmap(ml, i, t, slot, pv);
           abrow[u] = (xring ? pv * xrate : 0) + xoff + t;
-          arowbase[u] = xb + (long long)(xring ? slot : i) * xss;
-          avalid |= ((m0 + ml) < Mtot ? 1u : 0u) << u;
           const int sw = (KS == 32) ? ((ml >> 1) & 7) : (ml & 15);
-          acol[u] = (pchunk ^ sw) * 4;                 // logical channel offset inside the K-step
+          const int acol = (pchunk ^ sw) * 4;          // logical channel offset inside the K-step
+          aoff[u] = ((int)((long long)(xring ? slot : i) * xss) + acol) * 4;      // bytes
+          // rows past the tile and (when Cin is not a multiple of the K-step) channels past Cin read offset 0: their
+          // products are discarded (row never stored) or multiplied by the zero-padded weight rows
+          amask[u] = (m0 + ml) < Mtot ? -1 : 0;
+          amask_last[u] = ((Cin % KS) != 0 && acol >= (Cin % KS)) ? 0 : amask[u];
         }
       }
-      const int xC = a.x[0].C;
+      const int xC4 = a.x[0].C * 4;
       const int xmask = xring ? a.x[0].lmask : -1;
       const int ci4n = a.Cin_alloc >> 2;
+      const int cb_last = (Cin % KS) != 0 ? Cin / KS : 0x7fffffff;
       // weights are packed per group of 64 output columns: [n/64][tap][Cin_alloc/4][64][4] (1 KiB rows)
       const float* wgrp = wbase + ((long long)(n0 >> 6) * ktaps * ci4n * 64 + (n0 & 63)) * 4;
       int woff[WV];
@@ -195,15 +200,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
         const int j = jn, cb = cbn;
         float* As = lds + buf * (A_FLOATS + W_FLOATS);
         float* Ws = As + A_FLOATS;
+        const int jd = j * dil, cbk4 = cb * KS * 4;
+        const bool lastcb = cb >= cb_last;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-          const int r = (abrow[u] + j * dil) & xmask;
-          const int col = cb * KS + acol[u];
-          const bool ok = ((avalid >> u) & 1u) && col < Cin;
-          // rows past the tile and channels past Cin read a mapped address: their products are discarded
-          // (row never stored) or multiplied by the zero-padded weight rows
-          const float* p = ok ? arowbase[u] + r * xC + col : arowbase[u];
-          __builtin_amdgcn_global_load_lds(p, As + ((u * 4 + lwave) * RPI) * LDA, 16, 0, 0);
+          const int r = (abrow[u] + jd) & xmask;
+          const unsigned off = (unsigned)((__mul24(r, xC4) + aoff[u] + cbk4) & (lastcb ? amask_last[u] : amask[u]));
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(reinterpret_cast<const char*>(xb) + off), As + ((u * 4 + lwave) * RPI) * LDA, 16, 0, 0);
         }
         const float* wstep = wgrp + (long long)(j * ci4n + cb * (KS / 4)) * 256;
 #pragma unroll

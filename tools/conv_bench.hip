@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
       a.w = w + p * wfl; a.bias = b; a.slots = slots; a.pos = pos;
       a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cin_alloc = Cin_alloc; a.Cout = s.Cout; a.Cout_pad = Cout_pad; const int kk = s.k < 0 ? (p == 0 ? 3 : (p == 1 ? 7 : 11)) : s.k;
       a.ktaps = kk; a.dil = s.dil; a.pad_left = (kk - 1) * s.dil;
-      a.T = s.T; a.n = s.n; a.in_act = ck::ACT_LRELU; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1;
+      a.T = s.T; a.n = s.n; a.in_act = getenv("CB_INACT") ? ck::ACT_LRELU : ck::ACT_NONE; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1;
 #ifdef CK_STAMPS
       a.dbg = dbg;
 #endif
