@@ -32,7 +32,13 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
   for (int k = 0; k < cnt; ++k) {
     int c = order[k];
     long long blocks = (long long)((M + ck::conv_cfg_tm(c) - 1) / ck::conv_cfg_tm(c)) * ((N + ck::conv_cfg_tn(c) - 1) / ck::conv_cfg_tn(c)) * nprob;
-    if (blocks >= need) { best = c; break; }
+    if (blocks >= need) {
+      best = c;
+      // too few 64x64 tiles for two blocks per CU (stage-1 resblocks at 64 streams: 384 tiles): the K-step-64 build runs
+      // one persistent block per CU over a balanced tile list instead of leaving a third of the CUs half empty
+      if (c == ck::CFG_64x64 && blocks < 2 * need) best = ck::CFG_64x64_KS64;
+      break;
+    }
   }
   return best;
 }
