@@ -136,6 +136,7 @@ int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which
     if (!s || !slots) throw Error(CONAN_ERR_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
     s->set_slots(slots, n, st);
     const int models = s->ctx->cfg.models & which;
     auto zero = [&](std::vector<std::pair<float*, long long>>& v, int* pos) {
@@ -155,6 +156,7 @@ int conan_set_reference(conan_streams* s, const int32_t* slots, int n, const flo
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
     if (n < 1 || n > s->max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
     HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
     s->set_reference(slots, n, ref_mel_dev, ref_len, max_len, (hipStream_t)stream);
   });
 }
@@ -165,6 +167,7 @@ int conan_emformer_step(conan_streams* s, const int32_t* slots, int n, const flo
     if (!s || !slots || !chunk_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_EMFORMER)) throw Error(CONAN_ERR_STATE, "context holds no Emformer model");
     HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->emformer_step(n, chunk_dev, out_dev, logits_dev, codes_dev, (hipStream_t)stream);
   });
@@ -177,6 +180,7 @@ int conan_decoder_step(conan_streams* s, const int32_t* slots, int n, int frames
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
     if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
     HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->decoder_step(n, frames, codes_dev, mel_out_dev, uv_pred_dev, f0_dev, bins_dev, decoder_inp_dev, (hipStream_t)stream);
   });
@@ -189,6 +193,7 @@ int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames
     if (!(s->ctx->cfg.models & CONAN_MODEL_HIFIGAN)) throw Error(CONAN_ERR_STATE, "context holds no HiFi-GAN model");
     if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
     HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->hifigan_step(n, frames, mel_dev, wav_out_dev, pre_tanh_dev, (hipStream_t)stream);
   });
@@ -204,6 +209,7 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
     if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
     hipStream_t st = (hipStream_t)stream;
     HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
     s->set_slots(slots, n, st);
     int* codes_seg = codes_dev ? codes_dev : s->d_codes;
     s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, st);
@@ -216,6 +222,60 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
     float* mel = mel_out_dev ? mel_out_dev : s->c_mel.base;
     s->decoder_step(n, emit, codes_emit, mel, nullptr, nullptr, nullptr, nullptr, st);
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, st);
+  });
+}
+
+// Pipelined variant of conan_step.  Within one stream-set the three stages of a chunk are strictly ordered, but the
+// front-end of the next chunk depends only on front-end state, so it runs on its own HIP stream while the vocoder of
+// this chunk is still busy on another: the ~60 latency-bound front-end launches fill the gaps of the vocoder's large
+// kernels instead of adding to the step time.
+int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, const float* mel_chunk_dev, int32_t* codes_dev,
+                     float* mel_out_dev, float* wav_out_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !mel_chunk_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    const int all = CONAN_MODEL_EMFORMER | CONAN_MODEL_CONAN | CONAN_MODEL_HIFIGAN;
+    if ((s->ctx->cfg.models & all) != all) throw Error(CONAN_ERR_STATE, "conan_step_async needs all three models in the context");
+    const int seg = s->ctx->cfg.emf_segment;
+    if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
+    if (s->prof_on) throw Error(CONAN_ERR_STATE, "profiling is not available for pipelined steps");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->async_init();
+    const long long t = s->async_steps;
+    const int p = (int)(t & 1);
+    // inputs are ready in the caller's stream order
+    HIP_CHECK(hipEventRecord(s->ev_in, (hipStream_t)stream));
+    HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_in, 0));
+    // the hand-off buffer of this parity is free once the vocoder of step t-2 has copied it into its ring
+    if (t >= 2) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p], 0));
+    // a changed slot list rewrites the table the in-flight vocoder still reads: drain it first
+    bool same = (int)s->h_slots.size() == n;
+    for (int i = 0; same && i < n; ++i) same = s->h_slots[i] == slots[i];
+    if (!same && t >= 1) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p ^ 1], 0));
+    s->set_slots(slots, n, s->st_front);
+    int* codes_seg = codes_dev ? codes_dev : s->d_codes;
+    s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_front);
+    const int* codes_emit = codes_seg;
+    if (emit != seg && n > 1) {
+      int* compact = s->d_codes + (size_t)s->max_slots * s->max_frames;
+      ck::launch_copy_int_rows(compact, codes_seg, n, emit, seg, s->st_front);
+      codes_emit = compact;
+    }
+    float* mel = s->mel_hand[p];
+    s->decoder_step(n, emit, codes_emit, mel, nullptr, nullptr, nullptr, nullptr, s->st_front);
+    if (mel_out_dev) HIP_CHECK(hipMemcpyAsync(mel_out_dev, mel, (size_t)n * emit * s->ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, s->st_front));
+    HIP_CHECK(hipEventRecord(s->ev_front[p], s->st_front));
+    HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_front[p], 0));
+    s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, s->st_voc);
+    HIP_CHECK(hipEventRecord(s->ev_voc[p], s->st_voc));
+    s->async_steps = t + 1;
+  });
+}
+
+int conan_streams_join(conan_streams* s, void* stream) {
+  return guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
   });
 }
 

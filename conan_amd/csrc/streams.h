@@ -87,7 +87,19 @@ struct conan_streams {
     l.base = alloc((size_t)(nb < 0 ? max_slots : nb) * rows * C);
     return l;
   }
+  // --- pipelined stepping (conan_step_async): front-end (Emformer + decoder) and vocoder on two internal streams
+  hipStream_t st_front = nullptr, st_voc = nullptr;
+  hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_voc[2] = {nullptr, nullptr};
+  float* mel_hand[2] = {nullptr, nullptr};     // mel hand-off buffers [max_slots][max_frames][num_mels]
+  long long async_steps = 0;                   // steps enqueued since creation
+  void async_init();
+  void join(hipStream_t st);                   // make `st` wait for everything enqueued by conan_step_async
+
   ~conan_streams() {
+    if (st_front) (void)hipStreamDestroy(st_front);
+    if (st_voc) (void)hipStreamDestroy(st_voc);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    for (int i = 0; i < 2; ++i) { if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }

@@ -100,6 +100,27 @@ void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
   HIP_CHECK(hipMemcpyAsync(d_slots, h_slots.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
 }
 
+// ------------------------------------------------------------------------------------------------ pipelined stepping
+
+void conan_streams::async_init() {
+  if (st_front) return;
+  HIP_CHECK(hipStreamCreateWithFlags(&st_front, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&st_voc, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    HIP_CHECK(hipEventCreateWithFlags(&ev_front[i], hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_voc[i], hipEventDisableTiming));
+    mel_hand[i] = alloc((size_t)max_slots * max_frames * ctx->cfg.num_mels);
+  }
+}
+
+void conan_streams::join(hipStream_t st) {
+  if (async_steps == 0) return;
+  const int last = (int)((async_steps - 1) & 1);       // both internal streams are in-order: the last step covers all
+  HIP_CHECK(hipStreamWaitEvent(st, ev_front[last], 0));
+  HIP_CHECK(hipStreamWaitEvent(st, ev_voc[last], 0));
+}
+
 // ------------------------------------------------------------------------------------------------ vocoder
 
 void conan_streams::build_vocoder() {

@@ -92,6 +92,7 @@ class Streams:
         self.max_slots, self.max_frames, self.max_ref_frames = max_slots, max_frames, max_ref_frames
         h = C.c_void_p()
         _lib.check(self.lib.conan_streams_create(ctx.h, max_slots, max_frames, max_ref_frames, C.byref(h)))
+        self._keep = []   # buffers of pipelined steps in flight (released by join())
         self.h = h
         self.dev = torch.device("cuda", ctx.device)
         c = ctx.cfg
@@ -169,6 +170,23 @@ class Streams:
             wav_out = torch.empty(n, emit * hop, device=self.dev)
         _lib.check(self.lib.conan_step(self.h, p, n, emit, _ptr(mel_chunk), _ptr(codes), _ptr(mel_out), _ptr(wav_out), _stream()))
         return codes, mel_out, wav_out
+
+    def step_async(self, slots, mel_chunk, wav_out, emit=None, codes=None, mel_out=None):
+        """Pipelined chunk step (conan_step_async): returns at once; the front-end of the next call overlaps this
+        call's vocoder.  `wav_out` (and the optional outputs) must be caller-owned tensors kept alive until join()."""
+        a, p = _i32(slots)
+        n = len(a)
+        emit = self.seg if emit is None else int(emit)
+        mel_chunk = mel_chunk.to(self.dev, torch.float32).contiguous()
+        assert mel_chunk.shape == (n, self.seg + self.rc, self.ctx.cfg.emf_input_dim), mel_chunk.shape
+        assert wav_out.is_cuda and wav_out.is_contiguous() and wav_out.numel() >= n * emit * self.ctx.hop
+        self._keep.append((mel_chunk, wav_out, codes, mel_out))
+        _lib.check(self.lib.conan_step_async(self.h, p, n, emit, _ptr(mel_chunk), _ptr(codes), _ptr(mel_out), _ptr(wav_out), _stream()))
+
+    def join(self):
+        """Make the current torch stream wait for every pipelined step enqueued so far."""
+        _lib.check(self.lib.conan_streams_join(self.h, _stream()))
+        self._keep.clear()
 
     def profile_begin(self):
         _lib.check(self.lib.conan_profile_begin(self.h))

@@ -144,6 +144,17 @@ int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames
 int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const float* mel_chunk_dev,
                int32_t* codes_dev, float* mel_out_dev, float* wav_out_dev, void* stream);
 
+/* Pipelined conan_step: same arguments, same results bit for bit.  The Emformer + decoder of this call run on an
+ * internal HIP stream and the vocoder on a second one, so the front-end of chunk t+1 overlaps the vocoder of chunk t
+ * (in the reference the three stages of consecutive chunks are strictly serial, inference/Conan.py:95-156).
+ * `stream` is the caller's stream: the inputs are taken as ready in its order at call time.  Outputs are complete in
+ * the order of a stream that has passed conan_streams_join(); every buffer handed to a pipelined step must stay valid
+ * until then.  All other stream-ordered entry points join pending pipelined work first, so the two styles can be mixed. */
+int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, const float* mel_chunk_dev,
+                     int32_t* codes_dev, float* mel_out_dev, float* wav_out_dev, void* stream);
+/* Make `stream` wait (device side, non-blocking for the host) for every step enqueued by conan_step_async. */
+int conan_streams_join(conan_streams* s, void* stream);
+
 /* Measurement hook (replaces the reference's Timer('hifigan') around the vocoder forward,
  * utils/commons/meters.py:21-42, tasks/tts/vocoder_infer/hifigan.py:28): between begin and end every
  * launch of the conv_mfma kernel family is bracketed by HIP events on its launch stream.  end() waits
