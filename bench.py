@@ -222,8 +222,21 @@ def main():
         name, k_ms, k_fl, k_n = max(eng.st.profile_kernels(), key=lambda r: r[1])
         ach = k_fl / (k_ms * 1e-3) / 1e12
         fam = conv_flops / (conv_ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the benchmark, so the figure
+        # comes from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_b64_pmc_hbm.json")
+        if os.path.exists(pmc):
+            try:
+                kern = json.load(open(pmc))["kernels"]
+                hit = [v for k, v in kern.items() if name in k]
+                if hit:
+                    traffic = hit[0]["fetch"] + hit[0]["write"]
+                    traffic_src = "profiles/r1_b64_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+            except (OSError, ValueError, KeyError):
+                pass
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": name, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
                 "gflop_per_launch": k_fl / k_n / 1e9, "share_of_step_time": (k_ms / nprof) / (dt / args.steps * 1e3),
                 "all_conv_kernels": {"achieved": fam, "frac": fam / PEAK_F32_MFMA_TFLOPS, "launches_per_step": conv_launches / nprof,

@@ -94,13 +94,27 @@ class StreamingVoiceConversionEngine:
             pos += emit
 
     @torch.no_grad()
-    def infer(self, src_mel, ref_mel, ref_len=None):
-        """src_mel [B,T,80], ref_mel [B,Tr,80] (cuda) -> wav [B, T*hop], mel [B,T,80], codes [B,T]."""
+    def infer(self, src_mel, ref_mel, ref_len=None, pipelined=True):
+        """src_mel [B,T,80], ref_mel [B,Tr,80] (cuda) -> wav [B, T*hop], mel [B,T,80], codes [B,T].
+
+        The whole source is available here, so by default the chunks are issued as pipelined steps
+        (conan_step_async): the Emformer + decoder of chunk t+1 overlap the vocoder of chunk t.  The
+        results are bit-identical to the blocking loop (pipelined=False)."""
         self.start(ref_mel, ref_len)
+        B = src_mel.shape[0]
+        hop, nm = self.ctx.hop, self.ctx.cfg.num_mels
         wavs, mels, codes = [], [], []
         for pos, emit, chunk in self.chunks(src_mel):
-            c, m, w = self.st.step(self.slots, chunk, emit=emit)
+            if pipelined:
+                c = torch.empty(B, self.seg, dtype=torch.int32, device=src_mel.device)
+                m = torch.empty(B, emit, nm, device=src_mel.device)
+                w = torch.empty(B, emit * hop, device=src_mel.device)
+                self.st.step_async(self.slots, chunk, w, emit=emit, codes=c, mel_out=m)
+            else:
+                c, m, w = self.st.step(self.slots, chunk, emit=emit)
             wavs.append(w)
             mels.append(m)
             codes.append(c[:, :emit])
+        if pipelined:
+            self.st.join()
         return torch.cat(wavs, 1), torch.cat(mels, 1), torch.cat(codes, 1)

@@ -45,6 +45,9 @@ def test_batch64_full_size_streams_are_independent():
     # re-running the same utterances after reset reproduces the result bit for bit (state fully re-initialised)
     wav2, mel2, _ = eng.infer(src, ref)
     assert torch.equal(wav, wav2) and torch.equal(mel, mel2)
+    # ... and the pipelined schedule (default) is bit-identical to the blocking chunk loop
+    wav3, mel3, codes3 = eng.infer(src, ref, pipelined=False)
+    assert torch.equal(wav, wav3) and torch.equal(mel, mel3) and torch.equal(codes, codes3)
     eng.st.close(); solo.st.close(); ctx.close()
 
 
