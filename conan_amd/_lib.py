@@ -59,6 +59,8 @@ _PROTOS = {
     "conan_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_hifigan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "conan_decoder_step_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "conan_get_style": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_streams_join": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -107,6 +109,12 @@ def check(rc):
     if rc < 0:
         raise ConanError(rc, lib().conan_last_error().decode("utf-8", "replace"))
     return rc
+
+
+class DecoderTaps(C.Structure):
+    """conan_decoder_taps (include/conan_hip.h)."""
+    _fields_ = [("uv_pred", C.c_void_p), ("f0_denorm_pred", C.c_void_p), ("pitch_bins", C.c_void_p), ("decoder_inp", C.c_void_p),
+                ("content_embed_proj", C.c_void_p), ("attn", C.c_void_p * 2)]
 
 
 def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=True):

@@ -182,7 +182,40 @@ int conan_decoder_step(conan_streams* s, const int32_t* slots, int n, int frames
     HIP_CHECK(hipSetDevice(s->ctx->device));
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
-    s->decoder_step(n, frames, codes_dev, mel_out_dev, uv_pred_dev, f0_dev, bins_dev, decoder_inp_dev, (hipStream_t)stream);
+    conan_decoder_taps taps; memset(&taps, 0, sizeof(taps));
+    taps.uv_pred = uv_pred_dev; taps.f0_denorm_pred = f0_dev; taps.pitch_bins = bins_dev; taps.decoder_inp = decoder_inp_dev;
+    s->decoder_step(n, frames, codes_dev, mel_out_dev, taps, (hipStream_t)stream);
+  });
+}
+
+int conan_decoder_step_taps(conan_streams* s, const int32_t* slots, int n, int frames, const int32_t* codes_dev, float* mel_out_dev,
+                            const conan_decoder_taps* taps, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !codes_dev || !mel_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
+    if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
+    s->set_slots(slots, n, (hipStream_t)stream);
+    conan_decoder_taps none; memset(&none, 0, sizeof(none));
+    s->decoder_step(n, frames, codes_dev, mel_out_dev, taps ? *taps : none, (hipStream_t)stream);
+  });
+}
+
+int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_dev, int32_t* max_tokens_out, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !style_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
+    if (!s->has_ref) throw Error(CONAN_ERR_STATE, "conan_get_style before conan_set_reference");
+    if (n < 1 || n > s->max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
+    const int H = s->ctx->cfg.hidden_size;
+    for (int i = 0; i < n; ++i) {
+      if (slots[i] < 0 || slots[i] >= s->max_slots) throw Error(CONAN_ERR_INVALID, "slot index out of range");
+      HIP_CHECK(hipMemcpyAsync(style_dev + (size_t)i * H, s->c_style + (size_t)slots[i] * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    if (max_tokens_out) *max_tokens_out = s->S_max;
   });
 }
 
@@ -220,7 +253,7 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
       codes_emit = compact;
     }
     float* mel = mel_out_dev ? mel_out_dev : s->c_mel.base;
-    s->decoder_step(n, emit, codes_emit, mel, nullptr, nullptr, nullptr, nullptr, st);
+    { conan_decoder_taps none; memset(&none, 0, sizeof(none)); s->decoder_step(n, emit, codes_emit, mel, none, st); }
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, st);
   });
 }
@@ -261,7 +294,7 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
       codes_emit = compact;
     }
     float* mel = s->mel_hand[p];
-    s->decoder_step(n, emit, codes_emit, mel, nullptr, nullptr, nullptr, nullptr, s->st_front);
+    { conan_decoder_taps none; memset(&none, 0, sizeof(none)); s->decoder_step(n, emit, codes_emit, mel, none, s->st_front); }
     if (mel_out_dev) HIP_CHECK(hipMemcpyAsync(mel_out_dev, mel, (size_t)n * emit * s->ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, s->st_front));
     HIP_CHECK(hipEventRecord(s->ev_front[p], s->st_front));
     HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_front[p], 0));

@@ -8,8 +8,9 @@ static ck::LNArgs mk_ln(const TRef& x, const TRef& y, float* g, float* b, const 
   return a;
 }
 
-void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_out, float* uv_pred, float* f0, int32_t* bins,
-                                 float* dec_inp, hipStream_t st) {
+void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st) {
+  float* const uv_pred = taps.uv_pred; float* const f0 = taps.f0_denorm_pred; int32_t* const bins = taps.pitch_bins;
+  float* const dec_inp = taps.decoder_inp;
   const conan_cfg& c = ctx->cfg;
   const int H = c.hidden_size;
   const int* pos = pos_dec;
@@ -26,6 +27,11 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     ConvArgs a = mk(ctx->conv("conan.content_proj"), c_emb.ref(), c_pin.ref(), n, T, pos);
     a.out_act = ck::ACT_LRELU; a.out_slope = 0.01f; a.bvec = c_style; a.bvec_stride = H;
     conv(a, st);
+    if (taps.content_embed_proj) {   // the tap is the same conv without the fused "+ style" (exact, tap mode only)
+      ConvArgs t = mk(ctx->conv("conan.content_proj"), c_emb.ref(), ch::lin_ref(taps.content_embed_proj, T, H), n, T, pos);
+      t.out_act = ck::ACT_LRELU; t.out_slope = 0.01f;
+      conv(t, st);
+    }
   }
   // ProsodyAligner: 2 x CrossAttenLayer, post-LN (prosody_util.py:119-126)
   const int nh = 2, dh = H / nh;
@@ -36,7 +42,7 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     {
       ck::XAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = c_q.ref(); a.out = c_att.ref(); a.kv = c_kv + (size_t)l * S_max * 2 * H; a.kv_slot_stride = (long long)2 * S_max * 2 * H;
-      a.kmask = c_kmask; a.slen = c_slen; a.attn_avg = nullptr; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.E = H; a.H = nh; a.S_max = S_max;
+      a.kmask = c_kmask; a.slen = c_slen; a.attn_avg = taps.attn[l]; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.E = H; a.H = nh; a.S_max = S_max;
       ck::launch_xattn(a, st);
     }
     { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }

@@ -125,8 +125,7 @@ struct conan_streams {
 
   void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st);
   void emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st);
-  void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, float* uv_pred, float* f0, int32_t* bins,
-                    float* dec_inp, hipStream_t st);
+  void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st);
   void set_reference(const int32_t* slots, int n, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st);
   void conv_blocks_noncausal(const std::string& name, int nblocks, int k, int C, Lin* x, Lin& ln, Lin& h, Lin& blkm, const TRef& npm,
                              const int* lens, int n, int T, int& cur, hipStream_t st);

@@ -67,15 +67,22 @@ class Conan(_tree.ParamTree):
         st.reset(slots, which=2)
         st.set_reference(slots, ref.float().contiguous())
         codes = content.to(torch.int32).contiguous()
-        mels, taps = [], {"uv_pred": [], "f0_denorm_pred": [], "pitch_bins": [], "decoder_inp": []}
+        mels, taps = [], {"uv_pred": [], "f0_denorm_pred": [], "pitch_bins": [], "decoder_inp": [], "content_embed_proj": []}
+        attn = [[], []]
         for p in range(0, T, self.STEP_FRAMES):
             m, tp = st.decoder_step(slots, codes[:, p:p + self.STEP_FRAMES], taps=True)
             mels.append(m)
             for k in taps:
                 taps[k].append(tp[k])
+            for l in range(2):
+                attn[l].append(tp["attn"][l])
         ret = {"content": content, "mel_out": torch.cat(mels, 1), "tgt_nonpadding": (content != -1).float()[:, :, None], "fdiff": 0.0,
                "vq_loss": None, "ppl": None, "gloss": None}
         for k in taps:
             ret[k] = torch.cat(taps[k], 1)
+        # style_embed [B,1,H] (Conan.py:158) and the ProsodyAligner attention list, [B,1,T,S] per layer (prosody_util.py:119-126)
+        ret["style_embed"] = st.style_embed(slots).unsqueeze(1)
+        S = (Tr + 3) // 4
+        ret["attn"] = [torch.cat(a, 1)[:, :, :S].unsqueeze(1) for a in attn]
         ret["ref_upsample"] = (torch.arange(Tr, device=content.device) // 4 + 1).unsqueeze(0).expand(B, -1)
         return ret

@@ -135,14 +135,28 @@ class Streams:
         codes = codes.to(self.dev, torch.int32).contiguous()
         T = codes.shape[1]
         mel = torch.empty(n, T, c.num_mels, device=self.dev)
-        uv = f0 = bins = dinp = None
-        if taps:
-            uv = torch.empty(n, T, 2, device=self.dev)
-            f0 = torch.empty(n, T, device=self.dev)
-            bins = torch.empty(n, T, dtype=torch.int32, device=self.dev)
-            dinp = torch.empty(n, T, c.hidden_size, device=self.dev)
-        _lib.check(self.lib.conan_decoder_step(self.h, p, n, T, _ptr(codes), _ptr(mel), _ptr(uv), _ptr(f0), _ptr(bins), _ptr(dinp), _stream()))
-        return (mel, {"uv_pred": uv, "f0_denorm_pred": f0, "pitch_bins": bins, "decoder_inp": dinp}) if taps else mel
+        if not taps:
+            _lib.check(self.lib.conan_decoder_step(self.h, p, n, T, _ptr(codes), _ptr(mel), None, None, None, None, _stream()))
+            return mel
+        S = (self.max_ref_frames + 3) // 4 if self.max_ref_frames >= 4 else 1
+        out = {"uv_pred": torch.empty(n, T, 2, device=self.dev), "f0_denorm_pred": torch.empty(n, T, device=self.dev),
+               "pitch_bins": torch.empty(n, T, dtype=torch.int32, device=self.dev),
+               "decoder_inp": torch.empty(n, T, c.hidden_size, device=self.dev),
+               "content_embed_proj": torch.empty(n, T, c.hidden_size, device=self.dev),
+               "attn": [torch.empty(n, T, S, device=self.dev) for _ in range(2)]}
+        t = _lib.DecoderTaps()
+        t.uv_pred, t.f0_denorm_pred, t.pitch_bins = out["uv_pred"].data_ptr(), out["f0_denorm_pred"].data_ptr(), out["pitch_bins"].data_ptr()
+        t.decoder_inp, t.content_embed_proj = out["decoder_inp"].data_ptr(), out["content_embed_proj"].data_ptr()
+        t.attn[0], t.attn[1] = out["attn"][0].data_ptr(), out["attn"][1].data_ptr()
+        _lib.check(self.lib.conan_decoder_step_taps(self.h, p, n, T, _ptr(codes), _ptr(mel), C.byref(t), _stream()))
+        return mel, out
+
+    def style_embed(self, slots):
+        """style_embed [n, H] of the slots' current reference (Conan.encode_spk_embed, cached by set_reference)."""
+        a, p = _i32(slots)
+        out = torch.empty(len(a), self.ctx.cfg.hidden_size, device=self.dev)
+        _lib.check(self.lib.conan_get_style(self.h, p, len(a), _ptr(out), None, _stream()))
+        return out
 
     def hifigan_step(self, slots, mel, want_pre_tanh=False, out=None):
         """mel: cuda float32 [n, frames, 80] -> wav [n, frames*hop]."""

@@ -132,6 +132,27 @@ int conan_decoder_step(conan_streams* s, const int32_t* slots, int n, int frames
                        float* mel_out_dev, float* uv_pred_dev, float* f0_dev, int32_t* bins_dev,
                        float* decoder_inp_dev, void* stream);
 
+/* The remaining entries of the dict Conan.forward returns (modules/Conan/Conan.py:170-198; SURVEY.md §8b seam 3) as
+ * optional device outputs of a decoder step; any pointer may be NULL.
+ *   content_embed_proj[n][frames][H]   content_proj(content_embedding(content))              (Conan.py:140-142)
+ *   attn[l][n][frames][max_tokens]     head-averaged cross-attention weights of ProsodyAligner layer l = 0, 1 over
+ *                                      the slot's prosody tokens (prosody_util.py:119-161; the list in ret['attn']);
+ *                                      max_tokens = ceil(max_ref_frames / 4) as given to conan_streams_create
+ *                                      (conan_get_style reports it), entries past the slot's token count are 0 */
+typedef struct conan_decoder_taps {
+  float* uv_pred;               /* [n][frames][2] */
+  float* f0_denorm_pred;        /* [n][frames] */
+  int32_t* pitch_bins;          /* [n][frames] */
+  float* decoder_inp;           /* [n][frames][H] */
+  float* content_embed_proj;    /* [n][frames][H] */
+  float* attn[2];               /* per aligner layer: [n][frames][max_tokens] */
+} conan_decoder_taps;
+int conan_decoder_step_taps(conan_streams* s, const int32_t* slots, int n, int frames, const int32_t* codes_dev,
+                            float* mel_out_dev, const conan_decoder_taps* taps, void* stream);
+/* style_embed of the slots' current reference (encode_spk_embed, Conan.py:200-219, cached by conan_set_reference):
+ * style_dev[n][H].  max_tokens_out (may be NULL) receives the attn row width of conan_decoder_taps. */
+int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_dev, int32_t* max_tokens_out, void* stream);
+
 /* `frames` new mel rows per slot -> frames*hop samples: HifiGanGenerator.forward restricted to the
  * new frames (hifigan_causal.py:314-333).  mel_dev[n][frames][num_mels]; wav_out_dev[n][frames*hop];
  * pre_tanh_dev optional. */

@@ -45,6 +45,13 @@ def test_conan_forward_matches_reference_golden():
     np.testing.assert_allclose(ret["decoder_inp"].cpu().numpy(), g["decoder_inp"], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(ret["mel_out"].cpu().numpy(), g["mel_out"], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(ret["f0_denorm_pred"].cpu().numpy(), g["f0_denorm_pred"], atol=2e-2, rtol=1e-4)
+    # the remaining dict entries of SURVEY.md §8b seam (3)
+    assert ret["style_embed"].shape == (1, 1, 256) and ret["content_embed_proj"].shape == (1, 150, 256)
+    np.testing.assert_allclose(ret["style_embed"].cpu().numpy(), g["style_embed"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(ret["content_embed_proj"].cpu().numpy(), g["content_embed_proj"], atol=1e-5, rtol=1e-5)
+    assert len(ret["attn"]) == 2 and ret["attn"][0].shape == (1, 1, 150, 38)
+    np.testing.assert_allclose(ret["attn"][0].cpu().numpy(), g["attn0"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(ret["attn"][1].sum(-1).cpu().numpy(), 1.0, atol=1e-5)
 
 
 def test_emformer_module_streaming_api():
