@@ -61,6 +61,7 @@ _PROTOS = {
     "conan_hifigan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_decoder_step_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_get_style": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "conan_wav2mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_streams_join": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -109,6 +110,13 @@ def check(rc):
     if rc < 0:
         raise ConanError(rc, lib().conan_last_error().decode("utf-8", "replace"))
     return rc
+
+
+class MelCfg(C.Structure):
+    """conan_mel_cfg (include/conan_hip.h)."""
+    _fields_ = [("fft_size", C.c_int32), ("hop_size", C.c_int32), ("win_length", C.c_int32), ("num_mels", C.c_int32),
+                ("sample_rate", C.c_int32), ("fmin", C.c_float), ("fmax", C.c_float), ("eps", C.c_float),
+                ("vmin", C.c_float), ("vmax", C.c_float)]
 
 
 class DecoderTaps(C.Structure):

@@ -17,6 +17,9 @@ CONAN_EMFORMER = {
     "audio_num_mel_bins": 80,      # dataset_params
     "audio_sample_rate": 16000,    # conan_emformer.yaml:29
     "hop_size": 320,               # conan_emformer.yaml:30
+    "win_size": 1024, "fft_size": 1024,   # conan_emformer.yaml:33-34
+    "fmin": 80, "fmax": 7600,             # conan_emformer.yaml:37-38
+    "loud_norm": False,                   # egs_bases/tts/dataset_params.yaml:15
     "decoder_type": "conv",        # conan_emformer.yaml:56
     "dec_dilations": [1, 1, 1, 1],  # fs.yaml
     "dec_kernel_size": 5,          # fs.yaml

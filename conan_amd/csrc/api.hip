@@ -312,6 +312,17 @@ int conan_streams_join(conan_streams* s, void* stream) {
   });
 }
 
+int conan_wav2mel(conan_ctx* ctx, const conan_mel_cfg* cfg, const float* wav_dev, int n, int samples, float* mel_out_dev,
+                  int32_t* frames_out, void* stream) {
+  return guarded([&] {
+    if (!ctx || !cfg || !wav_dev || !mel_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!ctx->finalized) throw Error(CONAN_ERR_STATE, "conan_ctx_finalize must run before conan_wav2mel");
+    HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->wav2mel(*cfg, wav_dev, n, samples, mel_out_dev, (hipStream_t)stream);
+    if (frames_out) *frames_out = 1 + samples / cfg->hop_size;
+  });
+}
+
 int conan_profile_begin(conan_streams* s) {
   return guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");

@@ -52,6 +52,9 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     bool ring = a.y.mode == 0 || (a.has_res && a.res.mode == 0) || (a.has_m1 && a.m1.mode == 0) || (a.has_m2 && a.m2.mode == 0) || a.bvec != nullptr;
     for (int q = 0; q < a.nsrc; ++q) ring = ring || a.x[q].mode == 0;
     if (!ring) { a.slots = nullptr; a.pos = nullptr; }
+    // the direct-to-LDS loader addresses its input with 32-bit byte offsets from the tensor base
+    if (a.nsrc == 1 && (long long)(a.x[0].mode == 0 ? max_slots : a.n) * a.x[0].slot_stride * 4 >= (1ll << 32))
+      throw Error(CONAN_ERR_UNSUPPORTED, "activation tensor of 4 GiB or more: lower max_slots");
     if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop

@@ -1,6 +1,6 @@
 """StreamingVoiceConversion with the reference's interface (inference/Conan.py:20-166), running the chunk loop
-through the fused HIP step.  Inputs are mel spectrograms: the librosa wav front-end (inference/Conan.py:57-70) is
-the step before the hot path and is not re-implemented here."""
+through the fused HIP step.  Inputs are mel spectrograms ('ref_mel' / 'src_mel') or waveforms / wav paths ('ref_wav' /
+'src_wav', inference/Conan.py:72-80): the mel front-end (inference/Conan.py:57-70) runs on the GPU (conan_wav2mel)."""
 from typing import Dict
 
 import numpy as np
@@ -33,14 +33,29 @@ class StreamingVoiceConversion:
         self.ctx.finalize()
         self.engine = None
 
+    def _wav_to_mel(self, wav) -> torch.Tensor:
+        """inference/Conan.py:57-70 on the GPU: path or float array -> clipped log-mel [T, 80] (cuda)."""
+        from ..utils.audio import load_wav
+        hp = self.hparams
+        if isinstance(wav, str):
+            wav = load_wav(wav, hp["audio_sample_rate"])
+        if hp.get("loud_norm", False):
+            raise NotImplementedError("loud_norm is off on the inference path (egs_bases/tts/dataset_params.yaml:15)")
+        return self.ctx.wav2mel(torch.as_tensor(np.asarray(wav), dtype=torch.float32), fft_size=hp["fft_size"], hop_size=hp["hop_size"],
+                                win_length=hp["win_size"], num_mels=hp["audio_num_mel_bins"], fmin=hp["fmin"], fmax=hp["fmax"],
+                                sample_rate=hp["audio_sample_rate"], mel_vmin=hp["mel_vmin"], mel_vmax=hp["mel_vmax"])[0]
+
     def infer_once(self, inp: Dict):
-        """inp: {'ref_mel': [Tr,80], 'src_mel': [T,80]} (numpy / torch).  Returns (wav np[N], mel np[T,80])
-        like inference/Conan.py:166."""
-        if "ref_mel" not in inp or "src_mel" not in inp:
-            raise NotImplementedError("pass 'ref_mel' / 'src_mel' (clipped log-mel, inference/Conan.py:57-70); "
-                                      "the wav front-end is outside the hot path")
-        ref = torch.as_tensor(np.asarray(inp["ref_mel"]), dtype=torch.float32, device=self.device)[None]
-        src = torch.as_tensor(np.asarray(inp["src_mel"]), dtype=torch.float32, device=self.device)[None]
+        """inp: {'ref_wav', 'src_wav'} (paths or float arrays, like inference/Conan.py:72-80) or {'ref_mel': [Tr,80],
+        'src_mel': [T,80]} (numpy / torch).  Returns (wav np[N], mel np[T,80]) like inference/Conan.py:166."""
+        if "ref_mel" in inp and "src_mel" in inp:
+            ref = torch.as_tensor(np.asarray(inp["ref_mel"]), dtype=torch.float32, device=self.device)[None]
+            src = torch.as_tensor(np.asarray(inp["src_mel"]), dtype=torch.float32, device=self.device)[None]
+        elif "ref_wav" in inp and "src_wav" in inp:
+            ref = self._wav_to_mel(inp["ref_wav"])[None]
+            src = self._wav_to_mel(inp["src_wav"])[None]
+        else:
+            raise ValueError("pass 'ref_wav' / 'src_wav' or 'ref_mel' / 'src_mel'")
         if self.engine is None or self.engine.st.max_ref_frames < ref.shape[1]:
             self.engine = StreamingVoiceConversionEngine(self.ctx, 1, max_ref_frames=max(256, ref.shape[1]))
         wav, mel, _ = self.engine.infer(src, ref)

@@ -69,6 +69,20 @@ class Context:
     def weight_bytes(self):
         return self.lib.conan_ctx_weight_bytes(self.h)
 
+    def wav2mel(self, wav, fft_size=1024, hop_size=320, win_length=1024, num_mels=80, fmin=80, fmax=7600, sample_rate=16000,
+                eps=1e-6, mel_vmin=-6.0, mel_vmax=1.5):
+        """Mel front-end on the GPU (conan_wav2mel): wav cuda float32 [n, samples] -> mel [n, 1 + samples // hop, num_mels]
+        = clip(librosa_wav2spec(wav)['mel'], mel_vmin, mel_vmax) of inference/Conan.py:57-70 (loud_norm off)."""
+        wav = wav.to(torch.device("cuda", self.device), torch.float32).contiguous()
+        if wav.dim() == 1:
+            wav = wav[None]
+        n, samples = wav.shape
+        mc = _lib.MelCfg(fft_size, hop_size, win_length, num_mels, sample_rate, float(fmin), float(fmax), eps, mel_vmin, mel_vmax)
+        frames = 1 + samples // hop_size
+        mel = torch.empty(n, frames, num_mels, device=wav.device)
+        _lib.check(self.lib.conan_wav2mel(self.h, C.byref(mc), _ptr(wav), n, samples, _ptr(mel), None, _stream()))
+        return mel
+
     def streams(self, max_slots, max_frames=4, max_ref_frames=256):
         return Streams(self, max_slots, max_frames, max_ref_frames)
 

@@ -176,6 +176,18 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
 /* Make `stream` wait (device side, non-blocking for the host) for every step enqueued by conan_step_async. */
 int conan_streams_join(conan_streams* s, void* stream);
 
+/* Mel front-end (the step before the hot path): librosa_wav2spec as used by
+ * StreamingVoiceConversion._wav_to_mel (utils/audio/__init__.py:37-84, inference/Conan.py:57-70), loud_norm off:
+ * centred zero-padded STFT (periodic Hann) -> magnitude -> Slaney mel filterbank -> log10(max(eps, .)) -> clip.
+ * wav_dev[n][samples] fp32 in [-1, 1]; mel_out_dev[n][frames][num_mels] with frames = 1 + samples / hop_size
+ * (*frames_out, may be NULL).  fmin / fmax < 0 mean 0 / Nyquist.  Not re-entrant per context (shared workspace). */
+typedef struct conan_mel_cfg {
+  int32_t fft_size, hop_size, win_length, num_mels, sample_rate;
+  float fmin, fmax, eps, vmin, vmax;
+} conan_mel_cfg;
+int conan_wav2mel(conan_ctx* ctx, const conan_mel_cfg* cfg, const float* wav_dev, int n, int samples,
+                  float* mel_out_dev, int32_t* frames_out, void* stream);
+
 /* Measurement hook (replaces the reference's Timer('hifigan') around the vocoder forward,
  * utils/commons/meters.py:21-42, tasks/tts/vocoder_infer/hifigan.py:28): between begin and end every
  * launch of the conv_mfma kernel family is bracketed by HIP events on its launch stream.  end() waits

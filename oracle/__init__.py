@@ -20,4 +20,7 @@ Pinning status (see DESIGN.md "Oracle"):
     published torchaudio algorithm; tests pin it against an independently
     written dense-attention formulation and, opt-in, against torchaudio when
     that public package is installed.
+  * oracle.frontend -- PARITY UNPINNED: the mel front-end's arithmetic lives in librosa (absent here, not vendored
+    in the reference); it restates librosa's published STFT / Slaney mel algorithm and is pinned against an
+    independent formulation and analytic properties (tests/test_oracle_frontend.py).
 """

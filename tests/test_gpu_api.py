@@ -156,3 +156,63 @@ def test_pipelined_step_matches_fused_step():
     _, _, w2 = b.step(slots, chunk)
     assert torch.equal(w1, w2)
     a.close(); b.close(); ctx.close()
+
+
+def test_wav2mel_frontend_matches_oracle():
+    """conan_wav2mel (frames -> DFT GEMM -> magnitude -> mel GEMM -> log10/clip, all on the GPU) against the numpy
+    restatement of librosa_wav2spec (oracle/frontend.py; parity unpinned, librosa is absent).  Tolerance: the log
+    compresses, so 2e-3 in log10 units where the mel energy is above 1e-3 of the floor-to-peak range (mel > -3), and
+    5e-2 below (fp32 DFT sums of 1024 terms against a float64 FFT, relative to bins ~1e-5 of the frame peak)."""
+    from conan_amd import configs
+    from conan_amd.runtime import Context
+    from oracle import frontend as ofe
+    chp = configs.conan_hparams(True)
+    ctx = Context(chp, None, 0, False, True, False)
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.finalize()
+    rng = np.random.default_rng(3)
+    sr, n = 16000, 3
+    t = np.arange(int(1.3 * sr) + 57) / sr
+    wavs = np.stack([(0.5 * np.sin(2 * np.pi * (220 * (i + 1)) * t) * np.exp(-t) + 0.1 * np.sin(2 * np.pi * 3100 * t)
+                      + 0.02 * rng.standard_normal(t.shape)).astype(np.float32) for i in range(n)])
+    mel = ctx.wav2mel(torch.from_numpy(wavs).cuda()).cpu().numpy()
+    for i in range(n):
+        ref = ofe.wav2mel(wavs[i])
+        assert mel[i].shape == ref.shape == (1 + wavs.shape[1] // 320, 80)
+        d = np.abs(mel[i] - ref)
+        assert d[ref > -3].max() < 2e-3, d[ref > -3].max()
+        assert d.max() < 5e-2, d.max()
+    # silence -> floor; a second call with another length reuses the tables
+    z = ctx.wav2mel(torch.zeros(1, 4000, device="cuda")).cpu().numpy()
+    assert z.shape == (1, 13, 80) and np.all(z == -6.0)
+    ctx.close()
+
+
+def test_streaming_vc_accepts_waveforms(tmp_path):
+    """StreamingVoiceConversion.infer_once({'ref_wav','src_wav'}) (inference/Conan.py:72-80): wav path / array ->
+    GPU mel front-end -> chunk loop; equals the mel-input call on the oracle's mels of the same waveforms."""
+    import wave
+    from conan_amd.inference.Conan import StreamingVoiceConversion
+    from oracle import frontend as ofe
+    chp, vhp = configs.conan_hparams(True), configs.hifigan_hparams(True)
+    sds = {"emformer": _t(synth.emformer_state_dict(chp, 0)), "conan": _t(synth.conan_state_dict(chp, 0)),
+           "hifigan": _t(synth.hifigan_state_dict(vhp, 0))}
+    vc = StreamingVoiceConversion(chp, vhp, sds)
+    sr = 16000
+    t = np.arange(int(0.5 * sr)) / sr
+    src = (0.4 * np.sin(2 * np.pi * 330 * t) + 0.1 * np.sin(2 * np.pi * 1900 * t)).astype(np.float32)
+    ref = (0.3 * np.sin(2 * np.pi * 180 * t) * np.cos(2 * np.pi * 3 * t)).astype(np.float32)
+    path = str(tmp_path / "src.wav")
+    pcm = np.round(src * 32767).astype("<i2")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr); f.writeframes(pcm.tobytes())
+    wav_a, mel_a = vc.infer_once({"ref_wav": ref, "src_wav": path})
+    T = 1 + len(src) // 320
+    assert mel_a.shape == (T, 80) and wav_a.shape == (T * 320,) and np.isfinite(wav_a).all()
+    src_q = pcm.astype(np.float32) / 32768.0
+    m_src, m_ref = vc._wav_to_mel(src_q).cpu().numpy(), vc._wav_to_mel(ref).cpu().numpy()
+    assert np.abs(m_src - ofe.wav2mel(src_q)).max() < 5e-2 and np.abs(m_ref - ofe.wav2mel(ref)).max() < 5e-2
+    wav_b, mel_b = vc.infer_once({"ref_mel": m_ref, "src_mel": m_src})
+    assert np.array_equal(wav_a, wav_b) and np.array_equal(mel_a, mel_b)
+    with pytest.raises(ValueError):
+        vc.infer_once({"src_wav": src})

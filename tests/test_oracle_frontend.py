@@ -1,0 +1,54 @@
+"""The mel front-end oracle (oracle/frontend.py) restates librosa's published algorithm; librosa is not installed here
+and the reference holds no fixture for it (PARITY UNPINNED), so it is pinned against an independently written
+formulation and analytic properties."""
+import numpy as np
+
+from oracle import frontend as fe
+
+
+def _wave(seconds=0.4, sr=16000, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(int(seconds * sr)) / sr
+    x = 0.4 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 2300 * t + 1.0) + 0.05 * rng.standard_normal(t.shape)
+    return x.astype(np.float32)
+
+
+def test_stft_matches_explicit_dft_sums():
+    x = _wave(0.1)
+    n_fft, hop = 256, 80
+    mag = fe.stft_mag(x, n_fft, hop, n_fft)
+    assert mag.shape == (n_fft // 2 + 1, 1 + len(x) // hop)
+    # independent formulation: explicit zero-padded frames and a dense DFT matrix in float64
+    k = np.arange(n_fft)
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * k / n_fft)                      # periodic Hann
+    y = np.concatenate([np.zeros(n_fft // 2), x.astype(np.float64), np.zeros(n_fft // 2)])
+    dft = np.exp(-2j * np.pi * np.outer(np.arange(n_fft // 2 + 1), k) / n_fft)
+    for f in (0, 1, 7, mag.shape[1] - 1):
+        ref = np.abs(dft @ (y[f * hop:f * hop + n_fft] * win))
+        np.testing.assert_allclose(mag[:, f], ref, rtol=1e-4, atol=1e-4)
+
+
+def test_mel_filterbank_properties():
+    fb = fe.mel_filterbank(16000, 1024, 80, 80, 7600)
+    assert fb.shape == (80, 513) and fb.dtype == np.float32 and (fb >= 0).all()
+    freqs = np.linspace(0, 8000, 513)
+    mel_f = fe.mel_to_hz(np.linspace(fe.hz_to_mel(80), fe.hz_to_mel(7600), 82))
+    for i in (0, 10, 40, 79):
+        nz = np.nonzero(fb[i])[0]
+        assert freqs[nz[0]] > mel_f[i] and freqs[nz[-1]] < mel_f[i + 2]           # support = (left edge, right edge)
+        assert abs(freqs[np.argmax(fb[i])] - mel_f[i + 1]) <= 8000 / 512          # peak at the centre frequency
+        # slaney normalisation: triangle of height 2/(right-left) -> unit area (bin width 15.625 Hz)
+        assert abs(fb[i].sum() * (8000 / 512) - 1.0) < 0.08
+    # Slaney scale: linear below 1 kHz, logarithmic above, continuous at 1 kHz
+    assert abs(fe.hz_to_mel(1000.0) - 15.0) < 1e-12 and abs(fe.mel_to_hz(fe.hz_to_mel(3210.0)) - 3210.0) < 1e-9
+
+
+def test_wav2mel_shape_clip_and_tone_location():
+    x = _wave(0.5)
+    mel = fe.wav2mel(x)
+    assert mel.shape == (1 + len(x) // 320, 80) and mel.dtype == np.float32
+    assert mel.min() >= -6.0 and mel.max() <= 1.5
+    fb_centres = fe.mel_to_hz(np.linspace(fe.hz_to_mel(80), fe.hz_to_mel(7600), 82))[1:-1]
+    loud = int(np.argmax(mel[10]))
+    assert abs(fb_centres[loud] - 440) < 60                                       # the 440 Hz partial dominates
+    assert np.all(fe.wav2mel(np.zeros(3200, np.float32)) == -6.0)                 # silence sits on the floor
