@@ -100,3 +100,31 @@ def test_40ms_chunks_seg2():
         np.testing.assert_allclose(mel[b].numpy(), m_ref, atol=1e-4, rtol=1e-4)
         np.testing.assert_allclose(wav[b].numpy(), w_ref, atol=1e-4, rtol=0)
     st.close(); ctx.close()
+
+
+def test_right_context_zero_fast_system():
+    """`right_context: 0` (the reference README's "fast system"): the Emformer sees segment-only
+    chunks.  Fused step vs the oracle, 14 chunks so the left-context ring saturates and wraps."""
+    from oracle import emformer as oemf
+    from oracle.common import to_torch_sd
+    chp = dict(configs.conan_hparams(), right_context=0)
+    ctx, chp, vhp = _full_ctx(chp)
+    assert ctx.cfg.emf_right_context == 0
+    sd = to_torch_sd(synth.emformer_state_dict(chp, 0))
+    cfg = oemf.EmformerCfg(chp)
+    B, T = 3, 56
+    mel = torch.from_numpy(synth.mel(T, 99, B))
+    st = ctx.streams(B, max_frames=4, max_ref_frames=16)
+    slots = [2, 0, 1]
+    st.reset(slots)
+    state = None
+    for pos, emit, chunk in oemf.chunk_iter(mel, cfg.segment_length, 0):
+        o_ref, _, state = oemf.emformer_infer(sd, cfg, chunk, torch.full((B,), chunk.shape[1]), state)
+        lg_ref, codes_ref = oemf.logits_and_codes(sd, o_ref)
+        o, lg, codes = st.emformer_step(slots, chunk.cuda())
+        np.testing.assert_allclose(o.cpu().numpy(), o_ref.numpy(), atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(lg.cpu().numpy(), lg_ref.numpy(), atol=2e-4, rtol=1e-4)
+        top2 = lg_ref.topk(2, -1).values
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert torch.equal(codes.cpu().long()[safe], codes_ref[safe])
+    st.close(); ctx.close()
