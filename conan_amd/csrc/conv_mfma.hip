@@ -761,8 +761,8 @@ int conv_cfg_tn(int cfg) { return kTN[cfg]; }
 // Schedule of a persistent launch, computed on the host and cached per launch shape in device memory (a handful of
 // shapes per model; never freed):
 //  * XCD-aware: workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2, so each XCD gets one contiguous
-//    eighth of every problem's m-tiles - its activation slice (re-read for every tap and n-tile) and the weights stay
-//    in that L2 instead of being fetched over the fabric by all eight (measured: L2 hit rate 78-85 % either way at
+//    eighth of every problem's m-tiles (or, where the weights are the larger operand, of its n-tiles) - its slice of
+//    the big operand then stays in that L2 instead of being fetched over the fabric by all eight (measured: L2 hit rate 78-85 % either way at
 //    these sizes, so the step time does not move; it matters once a stage's activations outgrow one L2);
 //  * balanced: within an XCD, longest-processing-time-first over its blocks (the three branches of a grouped resblock
 //    launch have k = 11 / 7 / 3); cost of an item = its K-steps + a constant for prologue/epilogue.
@@ -784,8 +784,13 @@ static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int*
   for (int item = 0; item < total; ++item) {
     const int q = (item >= g.tile_start[1] ? 1 : 0) + (item >= g.tile_start[2] ? 1 : 0);
     const int local = item - g.tile_start[q], tn = g.tiles_n[q];
-    const int n_mt = (g.tile_start[q + 1] - g.tile_start[q]) / tn, mt = local / tn;
-    const int x = by_xcd ? std::min(NX - 1, (int)((long long)mt * NX / std::max(n_mt, 1))) : 0;
+    const int n_mt = (g.tile_start[q + 1] - g.tile_start[q]) / tn, mt = local / tn, nt = local - mt * tn;
+    // split along the axis whose operand is the larger one: activations (rows) for the streaming layers, weights
+    // (columns) for small-M x huge-K*N layers such as ups[0] (0.5 MB of rows against 67 MB of weights)
+    const ConvArgs& a = g.p[g.order[q]];
+    const bool by_cols = (long long)a.ktaps * a.Cin * a.Cout > (long long)a.n * a.T * a.Cin && tn >= NX;
+    const int x = !by_xcd ? 0 : by_cols ? std::min(NX - 1, (int)((long long)nt * NX / tn))
+                                        : std::min(NX - 1, (int)((long long)mt * NX / std::max(n_mt, 1)));
     Bin top = heap[x].top(); heap[x].pop();
     lists[top.second].push_back(item);
     heap[x].push({top.first + nks[q] + 3, top.second});
