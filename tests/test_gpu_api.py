@@ -251,3 +251,44 @@ def test_batch_file_runner_matches_single_conversions(tmp_path):
         assert a.shape == b.shape and a.dtype == np.int16
         # different batch sizes pick different tile shapes / split-K: equal up to fp32 re-association = +-1 LSB of int16
         assert np.abs(a.astype(np.int32) - b.astype(np.int32)).max() <= 1
+
+
+def test_pipelined_steps_with_changing_slot_lists_and_short_emit():
+    """Pipelined steps whose slot list (and batch size) changes from call to call, with emit < segment on the way: the
+    library drains the in-flight vocoder before it rewrites the slot table.  Reference: the same call sequence with
+    blocking conan_step on a second stream-set; results must be bit-identical."""
+    from conan_amd.runtime import Context
+    chp, vhp = configs.conan_hparams(True), configs.hifigan_hparams(True)
+    ctx = Context(chp, vhp, 0, True, True, True)
+    ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0))
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    S = 4
+    a, b = ctx.streams(S, 4, 64), ctx.streams(S, 4, 64)
+    ref = torch.from_numpy(synth.mel(36, 8, S)).cuda()
+    src = torch.from_numpy(synth.mel(64, 9, S)).cuda()
+    for st in (a, b):
+        st.reset(list(range(S)))
+        st.set_reference(list(range(S)), ref)
+    hop = ctx.hop
+    pos = [0] * S                                   # per-stream frame cursor
+    plan = [([0, 1, 2, 3], 4), ([2, 0], 4), ([1, 3], 4), ([3], 2), ([0, 1, 2, 3], 4), ([1], 4), ([2, 3, 0], 3), ([0, 1, 2, 3], 4)]
+    outs_a, outs_b = [], []
+    for slots, emit in plan:
+        chunk = torch.stack([src[s, pos[s]:pos[s] + 6] for s in slots]).contiguous()
+        if emit < 4:    # a short final-style chunk: repeat-last padding of the look-ahead (inference/Conan.py:100-110)
+            chunk = torch.cat([chunk[:, :emit], chunk[:, emit - 1:emit].expand(-1, 6 - emit, -1)], 1).contiguous()
+        n = len(slots)
+        c, m, w = a.step(slots, chunk, emit=emit)
+        outs_a.append((c.clone(), m.clone(), w.clone()))
+        cb = torch.empty(n, 4, dtype=torch.int32, device="cuda"); mb = torch.empty(n, emit, 80, device="cuda"); wb = torch.empty(n, emit * hop, device="cuda")
+        b.step_async(slots, chunk, wb, emit=emit, codes=cb, mel_out=mb)
+        outs_b.append((cb, mb, wb))
+        for s in slots:
+            pos[s] += emit
+    b.join()
+    torch.cuda.synchronize()
+    for k, ((ca, ma, wa), (cb, mb, wb)) in enumerate(zip(outs_a, outs_b)):
+        assert torch.equal(ca, cb) and torch.equal(ma, mb) and torch.equal(wa, wb), f"step {k}"
+    a.close(); b.close(); ctx.close()

@@ -33,6 +33,12 @@ int main(int argc, char** argv) {
     {"stage4 rb (M=81920,C=32,k7)", 64, 1280, 32, 32, 7, 3, 3, ck::CFG_128x32},
     {"stage4 rb 128x32 KS64... (Cin=32: n/a)", 64, 1280, 32, 32, 7, 3, 3, ck::CFG_128x32},
     {"ups0 (M=256,Cin=512,N=2048,k16)", 64, 4, 512, 2048, 16, 1, 1, ck::CFG_64x64},
+    {"ups1 (M=2048,256->640,k10) 64x64", 64, 32, 256, 640, 10, 1, 1, ck::CFG_64x64},
+    {"ups1 64x64 KS64", 64, 32, 256, 640, 10, 1, 1, ck::CFG_64x64_KS64},
+    {"ups1 32x64 K2", 64, 32, 256, 640, 10, 1, 1, ck::CFG_32x64_K2},
+    {"ups2 (M=10240,128->256,k8) 64x64", 64, 160, 128, 256, 8, 1, 1, ck::CFG_64x64},
+    {"ups3 (M=40960,64->64,k4) 64x64", 64, 640, 64, 64, 4, 1, 1, ck::CFG_64x64},
+    {"stage4 mixed 64x32 K2", 64, 1280, 32, 32, -1, 3, 3, ck::CFG_64x32_K2},
     {"ups0 32x64", 64, 4, 512, 2048, 16, 1, 1, ck::CFG_32x64_K2},
     {"dec c1 (M=256,256->512,k5)", 64, 4, 256, 512, 5, 1, 1, ck::CFG_32x32_K4},
     {"emf ff2 (M=384,2048->80)", 64, 6, 2048, 80, 1, 1, 1, ck::CFG_32x32_K4},
