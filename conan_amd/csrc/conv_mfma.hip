@@ -772,7 +772,9 @@ static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int*
   constexpr int NX = 8;
   int nks[3];
   for (int q = 0; q < 3; ++q) { const ConvArgs& a = g.p[g.order[q]]; nks[q] = a.ktaps * ((a.Cin_pad + KS - 1) / KS); }
-  Key k = {{grid, g.tile_start[1], g.tile_start[2], g.tile_start[3], nks[0], nks[1], nks[2], KS, g.tiles_n[0], g.tiles_n[1], g.tiles_n[2], 0}};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);                     // the cached lists live in that device's memory
+  Key k = {{grid, g.tile_start[1], g.tile_start[2], g.tile_start[3], nks[0], nks[1], nks[2], KS, g.tiles_n[0], g.tiles_n[1], g.tiles_n[2], dev_id}};
   auto it = cache.find(k);
   if (it != cache.end()) { *per_out = it->second.second; return it->second.first; }
   const int total = g.tile_start[3];

@@ -127,7 +127,14 @@ void conan_ctx::wav2mel(const conan_mel_cfg& m, const float* wav, int n, int sam
   if (rows > (1ll << 19)) throw Error(CONAN_ERR_INVALID, "wav2mel: more than 2^19 frames in one call (32-bit tile offsets)");
   // workspace: frames [rows][N] | spectrum [rows][2*NBP] | magnitude [rows][CM] | mel [rows][num_mels]
   const size_t need = (size_t)rows * ((size_t)N + 2 * NBP + CM + m.num_mels);
-  if (need > fe_ws_floats) { fe_ws = dev_alloc(need, false); fe_ws_floats = need; }     // grows monotonically; old blocks stay owned by the context
+  if (need > fe_ws_floats) {      // grow: the previous block is released once the stream has drained
+    if (fe_ws) {
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (size_t i = 0; i < allocs.size(); ++i) if (allocs[i] == fe_ws) { allocs.erase(allocs.begin() + i); break; }
+      HIP_CHECK(hipFree(fe_ws));
+    }
+    fe_ws = dev_alloc(need, false); fe_ws_floats = need;
+  }
   float* fr = fe_ws; float* spec = fr + (size_t)rows * N; float* mag = spec + (size_t)rows * 2 * NBP; float* melraw = mag + (size_t)rows * CM;
   { ck::FrameArgs a{wav, vec(k + ".win"), fr, n, samples, frames, m.hop_size, N}; hipLaunchKernelGGL(ck::stft_frames_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
   run_linear(this, linear_args(conv(k + ".dft"), fr, N, spec, (int)rows), st);

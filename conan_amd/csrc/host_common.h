@@ -97,7 +97,7 @@ struct conan_ctx {
   void finalize_hifigan();
   void finalize_conan();
   void finalize_emformer();
-  // mel front-end (frontend.hip): tables are built on first use per configuration; the workspace grows monotonically
+  // mel front-end (frontend.hip): tables are built on first use per configuration; one workspace, regrown when a call needs more
   float* fe_ws = nullptr; size_t fe_ws_floats = 0;
   void wav2mel(const conan_mel_cfg& m, const float* wav, int n, int samples, float* mel_out, hipStream_t st);
   ~conan_ctx();
