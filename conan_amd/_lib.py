@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conan_hip.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_UPS, MAX_RESBLOCKS, MAX_DILATIONS, MAX_DEC_BLOCKS = 8, 4, 4, 16
 MODEL_EMFORMER, MODEL_CONAN, MODEL_HIFIGAN = 1, 2, 4
 
@@ -34,8 +34,7 @@ class ConanCfg(C.Structure):
         ("voc_up_rates", C.c_int32 * MAX_UPS), ("voc_up_kernels", C.c_int32 * MAX_UPS),
         ("voc_num_resblocks", C.c_int32), ("voc_rb_kernels", C.c_int32 * MAX_RESBLOCKS),
         ("voc_rb_num_dil", C.c_int32), ("voc_rb_dilations", (C.c_int32 * MAX_DILATIONS) * MAX_RESBLOCKS),
-        ("models", C.c_int32),
-    ]
+        ("models", C.c_int32), ("voc_upsample", C.c_int32), ("voc_resblock", C.c_int32)]
 
 
 class ConanError(RuntimeError):
@@ -161,8 +160,14 @@ def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=
         c.emf_output_dim = hp.get("emformer_output_dim", 100)
     if hifigan_hp is not None and hifigan:
         v = hifigan_hp
-        if v.get("upsample", "shuffle") != "shuffle" or str(v.get("resblock", "1")) != "1":
-            raise ConanError(ERR_UNSUPPORTED, "only upsample='shuffle', resblock='1' (egs/hifi_16k320_shuffle.yaml) is on the hot path")
+        up = v.get("upsample", "shuffle")
+        if up not in ("shuffle", "zero"):
+            raise ConanError(ERR_UNSUPPORTED, "upsample='%s': CausalUpsampleBlock1's output frame t depends on input frames t+1, t+2 "
+                                              "(hifigan_causal.py:60-145), it cannot be streamed; use 'shuffle' or 'zero'" % up)
+        c.voc_upsample = 0 if up == "shuffle" else 1
+        c.voc_resblock = 1 if str(v.get("resblock", "1")) == "1" else 2
+        if len({len(ds) for ds in v["resblock_dilation_sizes"]}) != 1:
+            raise ConanError(ERR_UNSUPPORTED, "resblock branches with different numbers of dilations")
         models |= MODEL_HIFIGAN
         c.voc_initial_channel = v.get("upsample_initial_channel", 512)
         c.voc_num_ups = len(v["upsample_rates"])

@@ -68,6 +68,12 @@ CONAN_TINY = dict(copy.deepcopy(CONAN_EMFORMER), hidden_size=32, nVQ=16, emforme
 HIFIGAN_TINY = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample_initial_channel=64)
 
 
+# vocoder config.yaml variants the generator accepts (hifigan_causal.py:287-303): `upsample: zero` + `resblock: "2"`
+HIFIGAN_ZERO_RB2 = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample="zero", resblock="2",
+                        resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
+HIFIGAN_ZERO_RB2_TINY = dict(copy.deepcopy(HIFIGAN_ZERO_RB2), upsample_initial_channel=64)
+
+
 def conan_hparams(tiny=False):
     return copy.deepcopy(CONAN_TINY if tiny else CONAN_EMFORMER)
 

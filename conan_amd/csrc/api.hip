@@ -23,6 +23,8 @@ static void validate_cfg(const conan_cfg& c) {
     if (c.voc_num_ups < 1 || c.voc_num_ups > CONAN_MAX_UPS) throw Error(CONAN_ERR_INVALID, "voc_num_ups");
     if (c.voc_num_resblocks < 1 || c.voc_num_resblocks > 3) throw Error(CONAN_ERR_UNSUPPORTED, "1..3 resblock branches supported");
     if (c.voc_rb_num_dil < 1 || c.voc_rb_num_dil > CONAN_MAX_DILATIONS) throw Error(CONAN_ERR_INVALID, "voc_rb_num_dil");
+    if (c.voc_upsample < 0 || c.voc_upsample > 1) throw Error(CONAN_ERR_UNSUPPORTED, "voc_upsample: 0 (shuffle) or 1 (zero)");
+    if (c.voc_resblock < 0 || c.voc_resblock > 2) throw Error(CONAN_ERR_UNSUPPORTED, "voc_resblock: 1 or 2");
     int ch_ = c.voc_initial_channel;
     for (int i = 0; i < c.voc_num_ups; ++i) { ch_ /= 2; if (ch_ < 4 || ch_ % 4) throw Error(CONAN_ERR_UNSUPPORTED, "vocoder channel ladder must stay a multiple of 4"); }
     if (c.num_mels % 4) throw Error(CONAN_ERR_UNSUPPORTED, "num_mels must be a multiple of 4");

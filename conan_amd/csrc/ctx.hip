@@ -129,12 +129,39 @@ void conan_ctx::finalize_hifigan() {
   pack_weightnorm("voc.conv_pre", P + "conv_pre.conv");
   int ridx = 0;
   for (int i = 0; i < c.voc_num_ups; ++i) {
-    pack_weightnorm("voc.ups." + std::to_string(i), P + "ups." + std::to_string(i) + ".conv.conv", c.voc_up_rates[i]);
+    const std::string up = P + "ups." + std::to_string(i) + ".conv.conv";
+    if (c.voc_upsample == 0) {
+      pack_weightnorm("voc.ups." + std::to_string(i), up, c.voc_up_rates[i]);
+    } else {
+      // CausalUpsampleBlock2 (zero insertion + causal conv k, hifigan_causal.py:151-165) as a polyphase conv over the
+      // *input* rate in pixel-shuffle form: output sample t*s+j = sum_d w[(k-1) - j - s*d] . x[t-d], d = 0 .. D-1 with
+      // D = (k-1)/s + 1; phases whose index leaves [0, k) get zero taps.  Same kernel, same free shuffle as 'shuffle'.
+      std::vector<float> W, bias;
+      int Cout, Cin, k;
+      fold_weightnorm(up, W, bias, Cout, Cin, k);
+      const int sr = c.voc_up_rates[i], D = (k - 1) / sr + 1;
+      std::vector<float> Wp((size_t)Cout * sr * Cin * D, 0.f), bp((size_t)Cout * sr);
+      for (int co = 0; co < Cout; ++co)
+        for (int j = 0; j < sr; ++j) {
+          bp[(size_t)co * sr + j] = bias[co];
+          for (int d = 0; d < D; ++d) {
+            const int idx = (k - 1) - j - sr * d;
+            if (idx < 0 || idx >= k) continue;
+            for (int ci = 0; ci < Cin; ++ci)     // causal-conv tap q = D-1-d reads x[t-d]
+              Wp[(((size_t)co * sr + j) * Cin + ci) * D + (D - 1 - d)] = W[((size_t)co * Cin + ci) * k + idx];
+          }
+        }
+      pack_conv("voc.ups." + std::to_string(i), Wp, bp.data(), Cout * sr, Cin, D, sr);
+    }
     for (int b = 0; b < c.voc_num_resblocks; ++b, ++ridx)
       for (int d = 0; d < c.voc_rb_num_dil; ++d) {
         std::string rb = "resblocks." + std::to_string(ridx);
-        pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
-        pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
+        if (c.voc_resblock == 2) {
+          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c." + std::to_string(d), P + rb + ".convs." + std::to_string(d) + ".conv");
+        } else {
+          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
+          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
+        }
       }
   }
   pack_weightnorm("voc.conv_post", P + "conv_post.conv");

@@ -185,7 +185,20 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       a.y2_base = s.upa.base; a.y2_slope = LR;
       conv(a, st);
     }
-    for (int d = 0; d < ND; ++d) {  // ResBlock1 (hifigan_causal.py:230-238), the NB branches as one grouped launch
+    for (int d = 0; d < ND && c.voc_resblock == 2; ++d) {  // ResBlock2 (hifigan_causal.py:255-261): x = conv_d(lrelu(x)) + x
+      ConvGroup g1;
+      for (int b = 0; b < NB; ++b) {
+        const TRef xin = d == 0 ? s.up.ref() : s.xo[b][d - 1].ref();
+        const TRef xin_act = d == 0 ? s.upa.ref() : s.xa[b][d - 1].ref();
+        ConvArgs a1 = mk(ctx->conv("voc.rb." + std::to_string(ridx + b) + ".c." + std::to_string(d)), xin_act, s.xo[b][d].ref(), n, T, pos,
+                         c.voc_rb_dilations[b][d]);
+        a1.res = xin; a1.has_res = 1;
+        if (d + 1 < ND) { a1.y2_base = s.xa[b][d].base; a1.y2_slope = LR; }
+        g1.p[b] = a1;
+      }
+      launch_group(g1, NB, pick_cfg(n * T, s.C, NB), st);
+    }
+    for (int d = 0; d < ND && c.voc_resblock != 2; ++d) {  // ResBlock1 (hifigan_causal.py:230-238), the NB branches as one grouped launch
       ConvGroup g1, g2;
       for (int b = 0; b < NB; ++b) {
         // xt = c1(leaky_relu(x)); x = c2(leaky_relu(xt)) + x: both activations are applied where the tensor is written

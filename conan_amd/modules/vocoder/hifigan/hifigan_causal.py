@@ -18,9 +18,9 @@ class HifiGanGenerator(_tree.ParamTree):
     def __init__(self, hparams):
         super().__init__()
         self.h = hparams
-        if hparams.get("upsample", "shuffle") != "shuffle" or str(hparams.get("resblock", "1")) != "1":
-            raise NotImplementedError("only upsample='shuffle' / resblock='1' (egs/hifi_16k320_shuffle.yaml) is on the HIP hot path; "
-                                      "'nn'/'zero' upsamplers and ResBlock2 are next rows (SURVEY.md §8f.3)")
+        if hparams.get("upsample", "shuffle") not in ("shuffle", "zero"):
+            raise NotImplementedError("upsample='nn' (CausalUpsampleBlock1) looks two frames ahead and cannot be streamed; "
+                                      "'shuffle' (egs/hifi_16k320_shuffle.yaml) and 'zero' are on the HIP path, with resblock '1' or '2'")
         _tree.build_tree(self, specs.hifigan_spec(hparams))
         self._ctx = None
         self._streams = None

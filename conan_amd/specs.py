@@ -107,7 +107,8 @@ def conan_spec(hp):
 
 
 def hifigan_spec(hp):
-    """HifiGanGenerator (hifigan_causal.py:273-312), upsample == 'shuffle', resblock == '1'."""
+    """HifiGanGenerator (hifigan_causal.py:273-312): upsample 'shuffle' (CausalUpsampleBlock3) or 'zero'
+    (CausalUpsampleBlock2), resblock '1' (convs1/convs2) or '2' (convs)."""
     s = OrderedDict()
 
     def wn(prefix, co, ci, k):
@@ -115,20 +116,22 @@ def hifigan_spec(hp):
         s[f"{prefix}.weight_g"] = (co, 1, 1)
         s[f"{prefix}.weight_v"] = (co, ci, k)
 
+    mode = hp.get("upsample", "shuffle")
+    rb2 = str(hp.get("resblock", "1")) != "1"
     C = hp.get("upsample_initial_channel", 512)
     wn("conv_pre.conv", C, hp.get("num_mels", 80), 7)
     ch = C
     ups, rbs = [], []
     for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
         out = ch // 2
-        ups.append((f"ups.{i}.conv.conv", out * u, ch, k))
+        ups.append((f"ups.{i}.conv.conv", out * u if mode == "shuffle" else out, ch, k))
         for j, (rk, rd) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
             rbs.append((len(rbs), out, rk, rd))
         ch = out
     for (p, co, ci, k) in ups:
         wn(p, co, ci, k)
     for (idx, c, rk, rd) in rbs:
-        for name in ("convs1", "convs2"):
+        for name in (("convs",) if rb2 else ("convs1", "convs2")):
             for d in range(len(rd)):
                 wn(f"resblocks.{idx}.{name}.{d}.conv", c, c, rk)
     wn("conv_post.conv", 1, ch, 7)

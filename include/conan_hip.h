@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 1
+#define CONAN_HIP_ABI_VERSION 2
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -74,6 +74,9 @@ typedef struct conan_cfg {
   int32_t voc_rb_dilations[CONAN_MAX_RESBLOCKS][CONAN_MAX_DILATIONS];
   /* which sub-models this context holds (bit 0 Emformer, bit 1 Conan, bit 2 HiFi-GAN) */
   int32_t models;
+  /* vocoder config.yaml choices (hifigan_causal.py:287-303); 0 = the shipped egs/hifi_16k320_shuffle.yaml values */
+  int32_t voc_upsample;           /* 0: 'shuffle' (CausalUpsampleBlock3), 1: 'zero' (CausalUpsampleBlock2); 'nn' is not streamable */
+  int32_t voc_resblock;           /* 0 or 1: ResBlock1, 2: ResBlock2 */
 } conan_cfg;
 
 #define CONAN_MODEL_EMFORMER 1

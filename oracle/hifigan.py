@@ -1,8 +1,8 @@
 """Oracle: causal pixel-shuffle HiFi-GAN generator.
 
 Restates modules/vocoder/hifigan/hifigan_causal.py:
-  CausalConv1d :30-58, CausalPixelShuffle1d :171-189, CausalUpsampleBlock3 :191-212,
-  ResBlock1 :217-244, HifiGanGenerator.forward :314-333,
+  CausalConv1d :30-58, CausalUpsampleBlock2 :151-165, CausalPixelShuffle1d :171-189, CausalUpsampleBlock3 :191-212,
+  ResBlock1 :217-244, ResBlock2 :246-267, HifiGanGenerator.forward :314-333,
 and the numpy wrapper tasks/tts/vocoder_infer/hifigan.py:23-31 (spec2wav).
 Test infrastructure only (see oracle/__init__.py).
 """
@@ -46,12 +46,31 @@ def resblock1(sd, idx, x, dilations, st=None):
     return x
 
 
+def resblock2(sd, idx, x, dilations, st=None):
+    """ResBlock2.forward, hifigan_causal.py:255-261."""
+    for d_i, d in enumerate(dilations):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = _cconv(sd, f"resblocks.{idx}.convs.{d_i}.conv", xt, d, st)
+        x = x + xt
+    return x
+
+
+def zero_insert(x, stride):
+    """CausalUpsampleBlock2.forward, hifigan_causal.py:158-161: x[..., t] lands on sample t*stride, zeros between."""
+    B, C, T = x.shape
+    up = x.new_zeros(B, C, T * stride)
+    up[:, :, ::stride] = x
+    return up
+
+
 @torch.no_grad()
 def generator_forward(sd, hp, mel, st=None, taps=None):
     """HifiGanGenerator.forward (hifigan_causal.py:314-333). mel[B,80,T] -> wav[B,1,T*prod(rates)].
     `st` (dict) switches to stateful streaming (new frames only); `taps` (dict) collects
     per-stage pre-activation tensors for the parity tests."""
-    assert hp.get("upsample", "shuffle") == "shuffle" and str(hp.get("resblock", "1")) == "1"
+    mode = hp.get("upsample", "shuffle")
+    assert mode in ("shuffle", "zero")     # 'nn' (CausalUpsampleBlock1) is not restated
+    rb = resblock1 if str(hp.get("resblock", "1")) == "1" else resblock2
     x = _cconv(sd, "conv_pre.conv", mel, 1, st)
     if taps is not None:
         taps["conv_pre"] = x
@@ -59,13 +78,16 @@ def generator_forward(sd, hp, mel, st=None, taps=None):
     ridx = 0
     for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
         x = F.leaky_relu(x, LRELU_SLOPE)
-        x = _cconv(sd, f"ups.{i}.conv.conv", x, 1, st)
-        x = pixel_shuffle_1d(x, u)
+        if mode == "shuffle":
+            x = _cconv(sd, f"ups.{i}.conv.conv", x, 1, st)
+            x = pixel_shuffle_1d(x, u)
+        else:
+            x = _cconv(sd, f"ups.{i}.conv.conv", zero_insert(x, u), 1, st)
         if taps is not None:
             taps[f"ups.{i}"] = x
         xs = 0
         for j in range(n_rb):
-            xs = xs + resblock1(sd, ridx, x, hp["resblock_dilation_sizes"][j], st)
+            xs = xs + rb(sd, ridx, x, hp["resblock_dilation_sizes"][j], st)
             ridx += 1
         x = xs / n_rb
         if taps is not None:

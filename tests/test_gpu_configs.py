@@ -128,3 +128,39 @@ def test_right_context_zero_fast_system():
         safe = (top2[..., 0] - top2[..., 1]) > 1e-3
         assert torch.equal(codes.cpu().long()[safe], codes_ref[safe])
     st.close(); ctx.close()
+
+
+@pytest.mark.parametrize("tag,vhp", [("zero_rb2_tiny", configs.HIFIGAN_ZERO_RB2_TINY), ("zero_rb2_full", configs.HIFIGAN_ZERO_RB2)])
+def test_zero_insert_upsampler_and_resblock2(tag, vhp):
+    """`upsample: zero` (polyphase form of CausalUpsampleBlock2) + `resblock: "2"` through the
+    same conv kernel; streamed in 4-frame steps against the reference golden (one-shot forward) and the oracle taps."""
+    from conan_amd.runtime import Context
+    from oracle import hifigan as ohifi
+    from oracle.common import to_torch_sd
+    ctx = Context(None, vhp, 0, False, False, True)
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    g = load_golden(f"hifigan_{tag}.npz")
+    st = ctx.streams(2, max_frames=8, max_ref_frames=16)
+    mel = torch.from_numpy(g["mel_40"]).transpose(1, 2).contiguous().cuda()        # [1, 40, 80]
+    for slot, step in ((1, 4), (0, 8)):
+        st.reset([slot])
+        outs = [st.hifigan_step([slot], mel[:, i:i + step]) for i in range(0, 40, step)]
+        wav = torch.cat(outs, 1)[0].cpu().numpy()
+        np.testing.assert_allclose(wav, g["wav_40"], atol=1e-4, rtol=0)
+    # pre-tanh against the oracle on the 12-frame case
+    vsd = to_torch_sd(synth.hifigan_state_dict(vhp, 0))
+    taps = {}
+    ohifi.generator_forward(vsd, vhp, torch.from_numpy(g["mel_12"]), None, taps)
+    st.reset([0])
+    wav12, pre = st.hifigan_step([0], torch.from_numpy(g["mel_12"]).transpose(1, 2).contiguous().cuda()[:, :8], want_pre_tanh=True)
+    ref_pre = taps["pre_tanh"][0, 0, :8 * 320].numpy()
+    np.testing.assert_allclose(pre[0].cpu().numpy(), ref_pre, atol=1e-4 * max(1.0, np.abs(ref_pre).max()), rtol=0)
+    st.close(); ctx.close()
+
+
+def test_transposed_conv_upsampler_is_rejected():
+    from conan_amd import _lib
+    vhp = dict(configs.hifigan_hparams(True), upsample="nn")
+    with pytest.raises(_lib.ConanError):
+        _lib.make_cfg(None, vhp, emformer=False, conan=False, hifigan=True)

@@ -23,7 +23,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_cfg_struct_matches_header_and_hparams():
     cfg = _lib.make_cfg(configs.conan_hparams(), configs.hifigan_hparams())
-    assert C.sizeof(cfg) == 4 * 77
+    assert C.sizeof(cfg) == 4 * 79          # 79 int32 fields, include/conan_hip.h
+    assert cfg.voc_upsample == 0 and cfg.voc_resblock == 1
+    z = _lib.make_cfg(None, configs.HIFIGAN_ZERO_RB2, emformer=False, conan=False)
+    assert z.voc_upsample == 1 and z.voc_resblock == 2 and z.voc_rb_num_dil == 2
     assert cfg.models == 7 and cfg.hidden_size == 256 and cfg.emf_segment == 4 and cfg.emf_right_context == 2
     assert list(cfg.voc_up_rates)[:4] == [8, 5, 4, 2] and list(cfg.voc_up_kernels)[:4] == [16, 10, 8, 4]
     assert [list(r)[:3] for r in cfg.voc_rb_dilations][:3] == [[1, 3, 5]] * 3

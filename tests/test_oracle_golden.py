@@ -110,3 +110,24 @@ def test_loop_matches_reference(models, golden):
         np.testing.assert_array_equal(codes, g["codes"])
         np.testing.assert_allclose(mel, g["mel"], atol=TOL, rtol=1e-5)
         np.testing.assert_allclose(wav, g["wav"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("tag,vhp", [("zero_rb2_tiny", configs.HIFIGAN_ZERO_RB2_TINY), ("zero_rb2_full", configs.HIFIGAN_ZERO_RB2)])
+def test_hifigan_zero_upsampler_resblock2_matches_reference(tag, vhp, golden):
+    """The generator's other config.yaml choices (`upsample: zero`, `resblock: "2"`; hifigan_causal.py:151-165,
+    :246-267, :287-303) against the reference generator built from that config, plus stateful == one-shot."""
+    vsd = to_torch_sd(synth.hifigan_state_dict(vhp, 0))
+    g = golden(f"hifigan_{tag}.npz")
+    for T in (12, 40):
+        taps = {}
+        wav = ohifi.generator_forward(vsd, vhp, torch.from_numpy(g[f"mel_{T}"]), None, taps)
+        np.testing.assert_allclose(wav[0, 0].numpy(), g[f"wav_{T}"], atol=TOL, rtol=0)
+        if T == 12:
+            for i in range(4):
+                np.testing.assert_allclose(taps[f"ups.{i}"][0].numpy(), g[f"ups.{i}_12"], atol=2e-5, rtol=1e-5)
+            np.testing.assert_allclose(taps["pre_tanh"][0].numpy(), g["pre_tanh_12"], atol=2e-5, rtol=1e-5)
+    mel = torch.from_numpy(g["mel_40"])
+    st, outs = {}, []
+    for i in range(0, 40, 4):
+        outs.append(ohifi.generator_forward(vsd, vhp, mel[:, :, i:i + 4], st))
+    np.testing.assert_allclose(torch.cat(outs, 2)[0, 0].numpy(), g["wav_40"], atol=TOL, rtol=0)

@@ -76,6 +76,16 @@ def vocoder_goldens(g, tag, frames=(12, 150)):
 
 
 @torch.no_grad()
+def vocoder_variant_goldens():
+    """`upsample: zero` + `resblock: "2"` (hifigan_causal.py:287-303): the reference generator built from that config."""
+    from modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
+    for tag, ghp in (("zero_rb2_tiny", configs.HIFIGAN_ZERO_RB2_TINY), ("zero_rb2_full", configs.HIFIGAN_ZERO_RB2)):
+        g = HifiGanGenerator(dict(ghp)).eval()
+        g.load_state_dict(t(synth.hifigan_state_dict(ghp, 0)), strict=True)
+        vocoder_goldens(g, tag, frames=(12, 40))
+
+
+@torch.no_grad()
 def conan_goldens(m, tag, T=150, Tr=150):
     content = synth.codes(T, 1, seed=7)
     ref = synth.mel(Tr, 4321)
@@ -141,6 +151,10 @@ def main():
     ref_import.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    vocoder_variant_goldens()
+    print("wrote goldens: vocoder variants (zero-insert upsampler + ResBlock2)")
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        return
     for tiny in (False, True):
         tag = "tiny" if tiny else "full"
         m, g, chp, ghp = build_ref_models(tiny)
