@@ -157,7 +157,8 @@ def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=
         c.emf_segment = hp["chunk_size"] // 20
         c.emf_left_context = 50
         c.emf_right_context = hp["right_context"]
-        c.emf_output_dim = hp.get("emformer_output_dim", 100)
+        # mode == 'both': the streaming loop projects with proj1 (80 -> 100), inference/Conan.py:117-118
+        c.emf_output_dim = 100 if hp.get("mode", None) == "both" else hp.get("emformer_output_dim", 100)
     if hifigan_hp is not None and hifigan:
         v = hifigan_hp
         up = v.get("upsample", "shuffle")

@@ -195,7 +195,14 @@ void conan_ctx::finalize_emformer() {
     upload_vec(n + ".ln_out.g", p + ".layer_norm_output.weight");
     upload_vec(n + ".ln_out.b", p + ".layer_norm_output.bias");
   }
-  if (c.emf_output_dim != c.emf_input_dim) pack_from_keys("emf.proj", "emformer.proj.weight", "emformer.proj.bias");
+  // mode == 'both' checkpoints carry proj1 (80 -> 100) / proj2 (80 -> 768) heads; the streaming loop reads proj1
+  // (modules/Emformer/emformer.py:28-30, inference/Conan.py:117-118)
+  const std::string pj = has("emformer.proj1.weight") ? "emformer.proj1" : "emformer.proj";
+  if (c.emf_output_dim != c.emf_input_dim) {
+    if (get(pj + ".weight").shape.size() != 2 || get(pj + ".weight").shape[0] != c.emf_output_dim)
+      throw Error(CONAN_ERR_SHAPE, "Emformer projection rows != emf_output_dim: " + pj);
+    pack_from_keys("emf.proj", pj + ".weight", pj + ".bias");
+  }
   // Second copy of the Linear weights for the fused step (emformer_fused.hip), fragment-major: fragment (ntile, kq)
   // is the 64-lane x float4 MFMA B operand {W[ntile*16 + (lane&15)][kq*16 + (lane>>4)*4 + e]} stored as 1 KiB, and
   // fragments are ordered the way a wave consumes them, so each wave streams its weights sequentially.
@@ -231,7 +238,7 @@ void conan_ctx::finalize_emformer() {
   }
   if (c.emf_output_dim != D) {
     const int nt = (c.emf_output_dim + 15) / 16;
-    vecs["emf.fproj"] = upload(frags(get("emformer.proj.weight").data, c.emf_output_dim, D, (size_t)nt * KQ, [&](int t, int kq) { return (size_t)t * KQ + kq; }));
+    vecs["emf.fproj"] = upload(frags(get(pj + ".weight").data, c.emf_output_dim, D, (size_t)nt * KQ, [&](int t, int kq) { return (size_t)t * KQ + kq; }));
   }
 }
 

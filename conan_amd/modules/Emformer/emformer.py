@@ -64,13 +64,19 @@ class EmformerDistillModel(_tree.ParamTree):
         self.segment_length = hparams["chunk_size"] // 20
         self.right_context_len = hparams["right_context"]
         self.mode = hparams.get("mode", None)
-        if self.mode == "both":
-            raise NotImplementedError("mode='both' dual heads are a next row (SURVEY.md §8f.2)")
         _tree.build_tree(self, specs.emformer_spec(hparams, input_dim, output_dim))
         # `.emformer` must stay the container of the parameter tree (state_dict keys 'emformer.emformer_layers...'),
         # so the streaming entry point is attached to that sub-module; `.proj` keeps its parameters likewise.
         self._modules["emformer"].infer = _Emformer(self).infer
-        if "proj" in self._modules:
+        if self.mode == "both":
+            # dual heads (emformer.py:28-30): the streaming step projects with proj1; proj / proj2 stay plain Linears
+            # (torch on the device, off the hot path: only the distillation forward reads them)
+            self._modules["proj1"].forward = _Proj(self)
+            for name in ("proj", "proj2"):
+                if name in self._modules:
+                    m = self._modules[name]
+                    m.forward = (lambda x, m=m: torch.nn.functional.linear(x, m.weight.to(x.device), m.bias.to(x.device)))
+        elif "proj" in self._modules:
             self._modules["proj"].forward = _Proj(self)
         self._last = None
         self._ctx = None

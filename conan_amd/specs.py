@@ -166,4 +166,9 @@ def emformer_spec(hp, input_dim=80, output_dim=None, ffn_dim=2048):
     if output_dim != input_dim:
         s["proj.weight"] = (output_dim, D)
         s["proj.bias"] = (output_dim,)
+    if hp.get("mode", None) == "both":      # emformer.py:28-30: dual heads; inference reads proj1 (inference/Conan.py:117-118)
+        s["proj1.weight"] = (100, D)
+        s["proj1.bias"] = (100,)
+        s["proj2.weight"] = (768, D)
+        s["proj2.bias"] = (768,)
     return s

@@ -116,7 +116,10 @@ def emformer_infer(sd, cfg, inp, lengths, states=None):
 @torch.no_grad()
 def logits_and_codes(sd, chunk_out):
     """proj (emformer.py:25) + argmax (inference/Conan.py:123-124)."""
-    logits = F.linear(chunk_out, sd["proj.weight"], sd["proj.bias"]) if "proj.weight" in sd else chunk_out
+    if "proj1.weight" in sd:       # mode == 'both': inference/Conan.py:117-118 reads proj1
+        logits = F.linear(chunk_out, sd["proj1.weight"], sd["proj1.bias"])
+    else:
+        logits = F.linear(chunk_out, sd["proj.weight"], sd["proj.bias"]) if "proj.weight" in sd else chunk_out
     return logits, torch.argmax(logits, dim=-1)
 
 

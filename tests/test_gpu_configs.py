@@ -164,3 +164,35 @@ def test_transposed_conv_upsampler_is_rejected():
     vhp = dict(configs.hifigan_hparams(True), upsample="nn")
     with pytest.raises(_lib.ConanError):
         _lib.make_cfg(None, vhp, emformer=False, conan=False, hifigan=True)
+
+
+def test_emformer_mode_both_uses_proj1():
+    """`mode: both` (modules/Emformer/emformer.py:28-30): checkpoints carry proj1 (80 -> 100) and proj2 (80 -> 768); the
+    streaming loop projects with proj1 (inference/Conan.py:117-118).  Codes / logits against the oracle, and through the
+    reference-shaped module (`emformer.proj1(out)`)."""
+    from conan_amd.modules.Emformer.emformer import EmformerDistillModel
+    from oracle import emformer as oemf
+    from oracle.common import to_torch_sd
+    chp = dict(configs.conan_hparams(), mode="both", emformer_output_dim=768)
+    sd_np = synth.emformer_state_dict(chp, 0, output_dim=768)
+    assert "proj1.weight" in sd_np and sd_np["proj2.weight"].shape == (768, 80)
+    sd = to_torch_sd(sd_np)
+    cfg = oemf.EmformerCfg(chp)
+    model = EmformerDistillModel(chp, output_dim=768)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    B, T = 2, 24
+    mel = torch.from_numpy(synth.mel(T, 5, B))
+    state_ref, state = None, None
+    for pos, emit, chunk in oemf.chunk_iter(mel, cfg.segment_length, cfg.right_context_length):
+        lengths = torch.full((B,), chunk.shape[1])
+        o_ref, _, state_ref = oemf.emformer_infer(sd, cfg, chunk, lengths, state_ref)
+        lg_ref, codes_ref = oemf.logits_and_codes(sd, o_ref)
+        assert lg_ref.shape[-1] == 100
+        out, _, state = model.emformer.infer(chunk.cuda(), lengths.cuda(), state)
+        lg = model.proj1(out)
+        np.testing.assert_allclose(lg.cpu().numpy(), lg_ref.numpy(), atol=2e-4, rtol=1e-4)
+        top2 = lg_ref.topk(2, -1).values
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert torch.equal(lg.argmax(-1).cpu()[safe], codes_ref[safe])
+        lg2 = model.proj2(out)                       # the second head stays a plain Linear
+        np.testing.assert_allclose(lg2.cpu().numpy(), torch.nn.functional.linear(o_ref, sd["proj2.weight"], sd["proj2.bias"]).numpy(), atol=2e-4, rtol=1e-4)
