@@ -162,15 +162,18 @@ def main():
     # gather of chunk t runs on its own stream so that it does not serialise the pipeline either.
     NB = 4
     wavs = [torch.empty_like(wav) for _ in range(NB)]
-    comm = torch.cuda.Stream() if world > 1 else None
-    gdone = [torch.cuda.Event() for _ in range(NB)] if world > 1 else None
+    # CONAN_BENCH_COMM=1 exercises the gather stream / event choreography on a single rank (the gather itself is a
+    # no-op there); used to check that path on a one-GPU box
+    use_comm = world > 1 or os.environ.get("CONAN_BENCH_COMM", "0") == "1"
+    comm = torch.cuda.Stream() if use_comm else None
+    gdone = [torch.cuda.Event() for _ in range(NB)] if use_comm else None
 
     def step(j):
         k = j % NB
-        if world > 1 and j >= NB:
+        if use_comm and j >= NB:
             torch.cuda.current_stream().wait_event(gdone[k])      # the gather that read this buffer has finished
         eng.st.step_async(eng.slots, chunks[j % len(chunks)], wavs[k], emit=seg, codes=codes, mel_out=mel_out)
-        if world > 1:
+        if use_comm:
             with torch.cuda.stream(comm):
                 eng.st.join()
                 gather_audio_equal(wavs[k], world, rank, gbufs)
@@ -178,8 +181,9 @@ def main():
 
     def barrier():
         eng.st.join()
-        if world > 1:
+        if use_comm:
             comm.synchronize()
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
