@@ -7,6 +7,10 @@ template <typename F>
 static int guarded(F&& f) {
   try {
     f();
+    // kernel launches do not return a status: a launch that the runtime rejected (resources, bad configuration) is
+    // reported here instead of being lost - the product path must fail loudly
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) throw ch::Error(CONAN_ERR_HIP, std::string("HIP launch error: ") + hipGetErrorString(le));
     return CONAN_OK;
   } catch (const ch::Error& e) {
     g_err = e.what();
