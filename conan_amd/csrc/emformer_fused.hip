@@ -1,16 +1,19 @@
 // emformer_fused: one launch for the whole streaming Emformer step (torchaudio Emformer.infer: all layers, then the
 // output projection and arg-max), replacing ~60 latency-bound launches of the generic kernels.
 //
-// A step touches only Q = R+U (= 6) tokens per stream and streams are independent, so a block owns G = 16/Q streams
-// as one 16-row tile and walks all layers without leaving the chip.  Activations live in LDS; weights stream from L2
-// straight into MFMA B-fragments (the packed [k/4][n][4] layout is lane-contiguous: 16 columns x 4 k-groups = 1 KiB
-// per wave-wide load) and are prefetched one phase ahead into registers - the block runs one wave per SIMD, so it
-// has the whole 512-entry register file for that; barriers are raw s_barrier so those loads stay in flight across
-// them.  GEMMs use v_mfma_f32_16x16x4_f32 (exact fp32).  Per layer:
+// A step touches only Q = R+U (= 6) tokens per stream and streams are independent, so a block owns G = min(16/Q, 16/H)
+// streams as one 16-row tile and walks all layers without leaving the chip.  Activations, the per-stream key tables and
+// the layer's small parameters (biases, LayerNorm vectors; staged one layer ahead) live in LDS; weights stream from L2
+// straight into MFMA B fragments - they are stored fragment-major (ctx.hip: 1 KiB per 16-column x 16-row operand, in
+// the order a wave consumes them), so every load is lane-contiguous - and are refilled in place one phase ahead: the
+// block runs one wave per SIMD and has the whole 512-entry register file for that.  Barriers are raw s_barrier so
+// those loads stay in flight across them, and nothing but prefetches is loaded from global memory inside the layer
+// loop (vmcnt retires in order: a late small load would wait for every prefetch issued before it).
+// GEMMs use v_mfma_f32_16x16x4_f32 (exact fp32).  Per layer:
 //   LN -> [q|k|v] GEMM (k, v land directly in the per-stream key tables [rc | cached left context | utterance] next
 //   to the ring rows prefetched at the top of the layer; the U new rows are appended to the rings) -> attention with
-//   16-lane rows per (stream, head) -> out_proj + residual -> LN -> FFN in 512-wide hidden chunks (FF1 -> ReLU ->
-//   LDS -> FF2 accumulate, K split over the 4 waves) -> + residual -> LN.
+//   16-lane rows per (stream, head), K/V rows in registers, DPP row reductions -> out_proj + residual -> LN -> FFN in
+//   256-wide hidden chunks (FF1 -> ReLU -> LDS -> FF2 accumulate, K split over the 4 waves) -> + residual -> LN.
 // Token order inside a stream is [right context | utterance] like torchaudio's _EmformerLayer.infer.
 #include "kernels.h"
 
