@@ -130,3 +130,21 @@ def test_shard_range_partitions_streams():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [hi - lo for lo, hi in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_wav_io_roundtrip_and_pad(tmp_path):
+    """utils/audio: save_wav (utils/audio/io.py:7-13) writes 16-bit PCM that load_wav reads back; librosa_pad_lr
+    (utils/audio/__init__.py:13-22) pads to a whole number of hops plus one frame."""
+    from conan_amd.utils.audio import librosa_pad_lr, load_wav
+    from conan_amd.utils.audio.io import save_wav
+    x = (0.5 * np.sin(np.arange(4000) * 0.05)).astype(np.float32)
+    path = str(tmp_path / "a.wav")
+    save_wav(x, path, 16000)
+    y = load_wav(path, 16000)
+    assert y.shape == x.shape and np.abs(y - x).max() <= 2.0 / 32768    # truncation to int16 (as the reference writes) + the 32767/32768 scale
+    with pytest.raises(ValueError):
+        load_wav(path, 22050)
+    with pytest.raises(NotImplementedError):
+        save_wav(x, str(tmp_path / "a.mp3"), 16000)
+    assert librosa_pad_lr(np.zeros(1000), 1024, 320, 1) == (0, 280)
+    assert librosa_pad_lr(np.zeros(960), 1024, 320, 2) == (160, 160)
