@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conan_hip.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_UPS, MAX_RESBLOCKS, MAX_DILATIONS, MAX_DEC_BLOCKS = 8, 4, 4, 16
 MODEL_EMFORMER, MODEL_CONAN, MODEL_HIFIGAN = 1, 2, 4
 
@@ -34,7 +34,8 @@ class ConanCfg(C.Structure):
         ("voc_up_rates", C.c_int32 * MAX_UPS), ("voc_up_kernels", C.c_int32 * MAX_UPS),
         ("voc_num_resblocks", C.c_int32), ("voc_rb_kernels", C.c_int32 * MAX_RESBLOCKS),
         ("voc_rb_num_dil", C.c_int32), ("voc_rb_dilations", (C.c_int32 * MAX_DILATIONS) * MAX_RESBLOCKS),
-        ("models", C.c_int32), ("voc_upsample", C.c_int32), ("voc_resblock", C.c_int32)]
+        ("models", C.c_int32), ("voc_upsample", C.c_int32), ("voc_resblock", C.c_int32),
+        ("emf_max_memory_size", C.c_int32), ("emf_tanh_on_mem", C.c_int32)]
 
 
 class ConanError(RuntimeError):
@@ -58,6 +59,9 @@ _PROTOS = {
     "conan_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_hifigan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "conan_hifigan_step_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "conan_set_style": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "conan_get_prosody_ids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_decoder_step_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_get_style": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_wav2mel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -124,6 +128,11 @@ class DecoderTaps(C.Structure):
                 ("content_embed_proj", C.c_void_p), ("attn", C.c_void_p * 2)]
 
 
+class HifiganTaps(C.Structure):
+    """conan_hifigan_taps (include/conan_hip.h)."""
+    _fields_ = [("conv_pre_act", C.c_void_p), ("ups", C.c_void_p * MAX_UPS)]
+
+
 def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=True):
     """conan_cfg from the reference's hparams dicts (utils/commons/hparams.py)."""
     c = ConanCfg()
@@ -159,6 +168,10 @@ def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=
         c.emf_right_context = hp["right_context"]
         # mode == 'both': the streaming loop projects with proj1 (80 -> 100), inference/Conan.py:117-118
         c.emf_output_dim = 100 if hp.get("mode", None) == "both" else hp.get("emformer_output_dim", 100)
+        # not a key of the reference's yaml files (modules/Emformer/emformer.py:14-22 leaves torchaudio's defaults, 0 /
+        # False); read when present so that the memory bank can be exercised
+        c.emf_max_memory_size = int(hp.get("emformer_max_memory_size", 0))
+        c.emf_tanh_on_mem = int(bool(hp.get("emformer_tanh_on_mem", False)))
     if hifigan_hp is not None and hifigan:
         v = hifigan_hp
         up = v.get("upsample", "shuffle")

@@ -37,6 +37,8 @@ static void validate_cfg(const conan_cfg& c) {
     if (c.emf_input_dim % c.emf_heads || c.emf_input_dim / c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer head_dim must be <= 16");
     if (c.emf_input_dim % 4 || c.emf_input_dim > 512) throw Error(CONAN_ERR_UNSUPPORTED, "emformer input_dim");
     if (c.emf_segment < 1 || c.emf_right_context < 0) throw Error(CONAN_ERR_INVALID, "emformer segment/right context");
+    if (c.emf_max_memory_size < 0) throw Error(CONAN_ERR_INVALID, "emf_max_memory_size");
+    if (c.emf_max_memory_size > 0) throw Error(CONAN_ERR_UNSUPPORTED, "Emformer memory bank (max_memory_size > 0) is not built yet");
     if (c.emf_right_context + c.emf_left_context + c.emf_segment > 128 || c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer attention supports <= 128 keys, <= 16 heads");
   }
   if (c.models & CONAN_MODEL_CONAN) {
@@ -119,8 +121,10 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       s->d_slots = (int*)s->alloc(max_slots); s->d_ident = (int*)s->alloc(max_slots); s->d_zero = (int*)s->alloc(max_slots);
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
-      s->sk_slab_floats = 8ll << 20; s->sk_slab = s->alloc((size_t)s->sk_slab_floats);
-      s->sk_max_tiles = 4096; s->sk_counters = (int*)s->alloc(s->sk_max_tiles);
+      s->sk_slab_floats = 8ll << 20; s->sk_max_tiles = 4096;
+      for (int w = 0; w < 2; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); }
+      s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0);
+      s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
       std::vector<int> id(max_slots);
       for (int i = 0; i < max_slots; ++i) id[i] = i;
@@ -146,8 +150,8 @@ int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which
     s->set_slots(slots, n, st);
     const int models = s->ctx->cfg.models & which;
     auto zero = [&](std::vector<std::pair<float*, long long>>& v, int* pos) {
-      for (auto& b : v) ck::launch_zero_slots(b.first, b.second, b.second, s->d_slots, n, st);
-      ck::launch_fill_int(pos, s->d_slots, n, 0, st);
+      for (auto& b : v) cnk::launch_zero_slots(b.first, b.second, b.second, s->d_slots, n, st);
+      cnk::launch_fill_int(pos, s->d_slots, n, 0, st);
     };
     if (models & CONAN_MODEL_HIFIGAN) zero(s->voc_state, s->pos_voc);
     if (models & CONAN_MODEL_EMFORMER) zero(s->emf_state, s->pos_emf);
@@ -212,8 +216,11 @@ int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_
   return guarded([&] {
     if (!s || !slots || !style_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
-    if (!s->has_ref) throw Error(CONAN_ERR_STATE, "conan_get_style before conan_set_reference");
     if (n < 1 || n > s->max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
+    for (int i = 0; i < n; ++i) {
+      if (slots[i] < 0 || slots[i] >= s->max_slots) throw Error(CONAN_ERR_INVALID, "slot index out of range");
+      if (!s->has_ref[slots[i]]) throw Error(CONAN_ERR_STATE, "conan_get_style before conan_set_reference");
+    }
     HIP_CHECK(hipSetDevice(s->ctx->device));
     s->join((hipStream_t)stream);
     const int H = s->ctx->cfg.hidden_size;
@@ -222,6 +229,45 @@ int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_
       HIP_CHECK(hipMemcpyAsync(style_dev + (size_t)i * H, s->c_style + (size_t)slots[i] * H, (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     }
     if (max_tokens_out) *max_tokens_out = s->S_max;
+  });
+}
+
+int conan_set_style(conan_streams* s, const int32_t* slots, int n, const float* style_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !style_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
+    s->set_slots(slots, n, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i)
+      if (!s->has_ref[slots[i]]) throw Error(CONAN_ERR_STATE, "conan_set_style before conan_set_reference (the prosody tokens come from the reference mel)");
+    cnk::launch_scatter_rows(s->c_style, style_dev, s->d_slots, n, s->ctx->cfg.hidden_size, (hipStream_t)stream);
+  });
+}
+
+int conan_get_prosody_ids(conan_streams* s, const int32_t* slots, int n, int32_t* ids_dev, int32_t* count_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !ids_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
+    s->set_slots(slots, n, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i)
+      if (!s->has_ref[slots[i]]) throw Error(CONAN_ERR_STATE, "conan_get_prosody_ids before conan_set_reference");
+    cnk::launch_gather_ids(ids_dev, count_dev, s->c_vqids, s->c_slen, s->d_slots, n, s->S_max, (hipStream_t)stream);
+  });
+}
+
+int conan_hifigan_step_taps(conan_streams* s, const int32_t* slots, int n, int frames, const float* mel_dev, float* wav_out_dev,
+                            float* pre_tanh_dev, const conan_hifigan_taps* taps, void* stream) {
+  return guarded([&] {
+    if (!s || !slots || !mel_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_HIFIGAN)) throw Error(CONAN_ERR_STATE, "context holds no HiFi-GAN model");
+    if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    s->join((hipStream_t)stream);
+    s->set_slots(slots, n, (hipStream_t)stream);
+    s->hifigan_step(n, frames, mel_dev, wav_out_dev, pre_tanh_dev, (hipStream_t)stream, taps);
   });
 }
 
@@ -255,7 +301,7 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
     const int* codes_emit = codes_seg;
     if (emit != seg && n > 1) {
       int* compact = s->d_codes + (size_t)s->max_slots * s->max_frames;
-      ck::launch_copy_int_rows(compact, codes_seg, n, emit, seg, st);
+      cnk::launch_copy_int_rows(compact, codes_seg, n, emit, seg, st);
       codes_emit = compact;
     }
     float* mel = mel_out_dev ? mel_out_dev : s->c_mel.base;
@@ -296,7 +342,7 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     const int* codes_emit = codes_seg;
     if (emit != seg && n > 1) {
       int* compact = s->d_codes + (size_t)s->max_slots * s->max_frames;
-      ck::launch_copy_int_rows(compact, codes_seg, n, emit, seg, s->st_front);
+      cnk::launch_copy_int_rows(compact, codes_seg, n, emit, seg, s->st_front);
       codes_emit = compact;
     }
     float* mel = s->mel_hand[p];
@@ -348,8 +394,8 @@ int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int
       ms += t;
       const auto& r = s->prof_rec[i];
       bool found = false;
-      for (auto& k : s->prof_kernels) if (k.cfg == r.cfg && k.nsrc == r.nsrc) { k.ms += t; k.flops += r.flops; k.n += 1; found = true; break; }
-      if (!found) s->prof_kernels.push_back({r.cfg, r.nsrc, (double)t, r.flops, 1});
+      for (auto& k : s->prof_kernels) if (k.cfg == r.cfg) { k.ms += t; k.flops += r.flops; k.n += 1; found = true; break; }
+      if (!found) s->prof_kernels.push_back({r.cfg, (double)t, r.flops, 1});
     }
     if (conv_ms) *conv_ms = ms;
     if (conv_flops) *conv_flops = s->prof_flops;
@@ -362,10 +408,8 @@ int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, 
   int rc = guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
     if (index < 0 || index >= (int)s->prof_kernels.size()) return;
-    static const char* shapes[] = {"128, 64, 2, 2, 1, 32", "64, 64, 2, 2, 1, 32", "128, 32, 4, 1, 1, 32", "32, 64, 1, 2, 2, 64", "32, 32, 1, 1, 4, 128",
-                                   "64, 32, 2, 1, 2, 32", "64, 64, 2, 2, 1, 64", "128, 64, 2, 2, 1, 32", "128, 32, 4, 1, 1, 64"};
     const auto& k = s->prof_kernels[index];
-    if (name && name_cap > 0) snprintf(name, name_cap, "ck::conv_mfma_kernel<%s, %d>", shapes[k.cfg], k.nsrc);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", cnk::conv_cfg_name(k.cfg));
     if (ms) *ms = k.ms;
     if (flops) *flops = k.flops;
     if (launches) *launches = k.n;

@@ -6,28 +6,32 @@
 //   B[(j,ci)][co] = packed weights [tap][ci/4][co][4]
 // Block = 512 threads = 8 waves, two per SIMD, specialised: waves 0-3 issue nothing but fragment reads and
 // MFMAs; waves 4-7 stage the tiles.  Per K-step (one tap, KS input channels) the loader waves move an A tile
-// [TM][KS] (gathered ring rows; branch mean, LeakyReLU and zero fill applied on the registers) and a W tile
-// [KS][TN] global -> registers -> LDS; their global loads are issued TWO K-steps ahead of the LDS store (two
-// register sets), back-to-back with no dependent instruction between them.  Two LDS buffers, one barrier per
-// step shared by both roles: the loaders run one step ahead of the matrix waves.
+// [TM][KS] (gathered ring rows) and a W tile [KS][TN] global -> LDS directly (global_load_lds_dwordx4: no VGPR
+// round trip, no ds_write).  A wave instruction lands lane-linear in LDS, so the A tile is unpadded and bank
+// conflicts are removed by an XOR swizzle of its 16-byte chunks, applied to the per-lane SOURCE address and again
+// at the fragment read.  Three LDS buffers: loads run two K-steps ahead, retired by counted s_waitcnt vmcnt(N) and
+// one raw s_barrier per step shared by both roles.  The input is never transformed on the way (the DMA cannot):
+// producers store activated tensors; a second K-loop variant applies LeakyReLU on the A fragments when asked.
 // Fragments are read with ds_read_b128: a K-chunk of 8 feeds 4 MFMAs, lanes 0-31 carrying k 0..3 and
 // lanes 32-63 k 4..7 (the MFMA's two k-slots), so one 16-byte LDS read per operand serves 4 matrix
-// instructions.  A rows are padded by 4 floats: bank-conflict-free for the b128 lane groups.
-// Output tile D[time][co] keeps co on the lane -> 128-byte coalesced channel-last stores; the pixel
-// shuffle of CausalUpsampleBlock3 is a pure address remap of that store (weights pre-permuted).
-// KS = 32 for the large streaming tiles; KS = 128 for the small-M (latency-bound) tiles, where a
-// longer K-step amortises the per-step load latency and barrier.
+// instructions; the two fragment register sets are double-buffered by hand.
+// Output tile D[time][co] keeps co on the lane; each 32x32 accumulator is transposed through a wave-private LDS
+// patch so that stores are 16-byte channel-last accesses; the pixel shuffle of CausalUpsampleBlock3 is a pure
+// address remap of that store (weights pre-permuted).
+// KS = 32 for the large streaming tiles; KS = 64/128 for the small-M (latency-bound) tiles, where a longer K-step
+// amortises the per-step load latency and barrier.  Blocks are persistent over a host-made balanced tile list.
 #include <type_traits>
 
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <queue>
 #include <vector>
 
 #include "kernels.h"
 
-namespace ck {
+namespace cnk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -51,11 +55,10 @@ __device__ __forceinline__ unsigned tref_row(const TRef& r, int slot, const int*
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int TM, int TN, int WK, int KS, int NSRC>
+template <int TM, int TN, int WK, int KS>
 struct ConvLds {
-  static constexpr bool GLDS = (NSRC == 1);
-  static constexpr int NBUF = GLDS ? 3 : 2;
-  static constexpr int LDA = GLDS ? KS : KS + 4;
+  static constexpr int NBUF = 3;
+  static constexpr int LDA = KS;
   static constexpr int STAGE = NBUF * (TM * LDA + KS * TN);
   static constexpr int EPI_LD = 36;                 // epilogue transpose patch: 32 rows x 36 floats per compute wave
   static constexpr int PATCH = 4 * 32 * EPI_LD;
@@ -66,7 +69,7 @@ struct ConvLds {
 // One output tile (rows m0.., columns n0..) of one problem.  `gbuf` is the LDS ring position of the tile's first
 // K-step: it is carried from tile to tile so that a persistent block's loader waves can start the next tile's
 // loads while the matrix waves are still in the previous tile's epilogue.
-template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
+template <int TM, int TN, int WM, int WN, int WK, int KS>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const int n0, float* lds, int& gbuf, const int tile,
                                           const int kslice, const int nslices, float* slab, int* counter) {
   static_assert(WM * WN * WK == 4, "4 compute waves per block");
@@ -74,22 +77,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   constexpr int RM = TM / WM / 32;
   constexpr int RN = TN / WN / 32;
   constexpr int SB = KS / 32;                 // 32-channel sub-blocks per K-step
-  constexpr int AQ = (TM / 32) * SB;          // A float4 staged per loader thread
   constexpr int WV = (KS / 4 * TN) / 256;     // W float4 staged per loader thread
   constexpr int NKQ = KS / 8;                 // 8-deep K chunks per step
-  // NSRC == 1: tiles go global -> LDS directly (global_load_lds, no VGPR round trip, no ds_write); the LDS image
+  // Tiles go global -> LDS directly (global_load_lds, no VGPR round trip, no ds_write); the LDS image
   // of a wave instruction is lane-linear, so A rows are unpadded and bank conflicts are removed by an XOR swizzle
   // of the 16-byte chunks applied on the per-lane SOURCE address and again on the fragment read; three buffers
-  // (loads run two K-steps ahead).  NSRC > 1 (mean of the resblock branches) keeps the register-staged loader.
-  constexpr bool GLDS = (NSRC == 1);
-  constexpr int NBUF = GLDS ? 3 : 2;
-  constexpr int LDA = GLDS ? KS : KS + 4;
+  // (loads run two K-steps ahead).
+  constexpr int NBUF = 3;
+  constexpr int LDA = KS;
   constexpr int CPR = KS / 4;                  // 16-byte chunks per A row
   constexpr int RPI = 64 / CPR;                // A rows covered by one wave-wide 1 KiB load
   constexpr int NA = TM / RPI / 4;             // A load instructions per loader wave per K-step
   constexpr int A_FLOATS = TM * LDA;
   constexpr int W_FLOATS = KS * TN;
-  using L = ConvLds<TM, TN, WK, KS, NSRC>;
+  using L = ConvLds<TM, TN, WK, KS>;
   static_assert(L::RED == ((WK > 1) ? (WK - 1) * WM * WN * RM * RN * 16 * 64 : 0), "split-K reduction region");
   constexpr int STAGE_FLOATS_TOTAL = L::STAGE;      // [staging ring | epilogue patches | split-K reduction]
   constexpr int EPI_LD = L::EPI_LD;
@@ -148,7 +149,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   const int nks = SK ? (int)((long long)nks_all * (kslice + 1) / nslices) - ks_lo : nks_all;
   int* const sflag = reinterpret_cast<int*>(lds + L::STAGE + L::PATCH + L::RED);
   auto block_barrier = [&]() __attribute__((always_inline)) {
-    if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
   };
   // every wave of the block takes part in the two barriers of the split-K hand-off (X1: partial tiles written,
   // X2: "this block is the reducer" flag published through LDS)
@@ -158,7 +159,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 
   if (is_loader) {
     // ================================================================= loader waves
-    if constexpr (GLDS) {
+    {
       const int lwave = __builtin_amdgcn_readfirstlane(ltid >> 6);
       const int prow = lane / CPR;                     // row inside one wave instruction
       const int pchunk = lane % CPR;                   // physical chunk written by this lane
@@ -166,11 +167,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       // VGPR offset" and a K-step costs ~5 vector instructions per A load: the loader waves share their SIMD's issue
       // slots with MFMA-saturated matrix waves, and every VALU instruction here shows up in the step time.
       int abrow[NA], aoff[NA], amask[NA], amask_last[NA];     // masks: all ones for lanes that load, 0 otherwise
-      const bool xring = a.x[0].mode == 0;
-      const float* const xb = a.x[0].base;
+      const bool xring = a.x.mode == 0;
+      const float* const xb = a.x.base;
       {
-        const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
-        const long long xss = a.x[0].slot_stride;
+        const int xrate = a.x.rate, xoff = a.x.off - a.pad_left;
+        const long long xss = a.x.slot_stride;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
           const int ml = (u * 4 + lwave) * RPI + prow;
@@ -186,8 +187,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
           amask_last[u] = ((Cin % KS) != 0 && acol >= (Cin % KS)) ? 0 : amask[u];
         }
       }
-      const int xC4 = a.x[0].C * 4;
-      const int xmask = xring ? a.x[0].lmask : -1;
+      const int xC4 = a.x.C * 4;
+      const int xmask = xring ? a.x.lmask : -1;
       const int ci4n = a.Cin_alloc >> 2;
       const int cb_last = (Cin % KS) != 0 ? Cin / KS : 0x7fffffff;
       // weights are packed per group of 64 output columns: [n/64][tap][Cin_alloc/4][64][4] (1 KiB rows)
@@ -246,127 +247,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       if constexpr (WK > 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
       splitk_idle();
       return;
-    } else {
-    // per-thread A staging geometry (fixed over the K loop): rows arow + 32*q, channel quad ac4
-    const int arow = ltid >> 3;
-    const int ac4 = ltid & 7;
-    const float* arowbase[TM / 32];
-    int abrow[TM / 32];
-    unsigned avalid = 0;
-    const bool xring = a.x[0].mode == 0;
-    {
-      const int xrate = a.x[0].rate, xoff = a.x[0].off - a.pad_left;
-      const long long xss = a.x[0].slot_stride;
-      const float* xb = a.x[0].base;
-#pragma unroll
-      for (int q = 0; q < TM / 32; ++q) {
-        const int ml = arow + 32 * q;
-        int i, t, slot, pv;
-        rowmap(ml, i, t, slot, pv);
-        abrow[q] = (xring ? pv * xrate : 0) + xoff + t;
-        arowbase[q] = xb + (long long)(xring ? slot : i) * xss;
-        avalid |= ((m0 + ml) < Mtot ? 1u : 0u) << q;
-      }
     }
-    const long long d1 = (NSRC > 1) ? (a.x[1].base - a.x[0].base) : 0;
-    const long long d2 = (NSRC > 2) ? (a.x[2].base - a.x[0].base) : 0;
-    const int xC = a.x[0].C;
-    const int xmask = xring ? a.x[0].lmask : -1;
-    const int ci4n = a.Cin_alloc >> 2;
-    const float* wgrp = wbase + ((long long)(n0 >> 6) * ktaps * ci4n * 64 + (n0 & 63)) * 4;
-    const float neg_mul = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
-    static_assert(WV >= 1 && WV <= 8, "W staging vectors per thread");
-    int woff[WV];      // per-thread W staging offsets (floats, relative to the K-step's tile base)
-#pragma unroll
-    for (int v = 0; v < WV; ++v) { const int idx = ltid + 256 * v; const int kq4 = idx / TN, co = idx - kq4 * TN; woff[v] = (kq4 * 64 + co) * 4; }
-    int jn = ks_lo % ktaps, cbn = ks_lo / ktaps;   // (tap, channel block) of the next K-step to issue; tap index fastest so that
-                           // consecutive steps re-touch the same activation rows (L1/L2 hits)
-
-    // two register sets (P, Q): loads are issued TWO K-steps ahead of their LDS store
-#define CK_DECL(S)                                                                                                      \
-    float4 ra##S[AQ][NSRC];                                                                                             \
-    float4 rw##S##0 = f4zero(), rw##S##1 = rw##S##0, rw##S##2 = rw##S##0, rw##S##3 = rw##S##0, rw##S##4 = rw##S##0,     \
-           rw##S##5 = rw##S##0, rw##S##6 = rw##S##0, rw##S##7 = rw##S##0;                                               \
-    unsigned ok##S = 0;
-    CK_DECL(P) CK_DECL(Q)
-#undef CK_DECL
-
-#define CK_W_ISSUE(S, V)                                                                                  \
-    if constexpr (WV > V) {                                                                               \
-      const int o = woff[V]; /* rows past Cin_pad exist (Cin_alloc) and are zero */                       \
-      rw##S##V = *reinterpret_cast<const float4*>(wstep + o);                                             \
-    }
-#define CK_ISSUE(S)                                                                                       \
-    {                                                                                                     \
-      const int j = jn, cb = cbn;                                                                         \
-      ok##S = 0;                                                                                          \
-      _Pragma("unroll") for (int q = 0; q < TM / 32; ++q) {                                               \
-        const int r = (abrow[q] + j * dil) & xmask;                                                       \
-        const float* rowp = arowbase[q] + r * xC;                                                         \
-        _Pragma("unroll") for (int sb = 0; sb < SB; ++sb) {                                               \
-          const int col = (cb * SB + sb) * 32 + ac4 * 4;                                                  \
-          const bool ok = ((avalid >> q) & 1u) && col < Cin;                                              \
-          const float* p = ok ? rowp + col : arowbase[q]; /* always mapped; value dropped if !ok */       \
-          ra##S[q * SB + sb][0] = *reinterpret_cast<const float4*>(p);                                    \
-          if constexpr (NSRC > 1) ra##S[q * SB + sb][1] = *reinterpret_cast<const float4*>(p + d1);       \
-          if constexpr (NSRC > 2) ra##S[q * SB + sb][2] = *reinterpret_cast<const float4*>(p + d2);       \
-          ok##S |= (ok ? 1u : 0u) << (q * SB + sb);                                                       \
-        }                                                                                                 \
-      }                                                                                                   \
-      const float* wstep = wgrp + (long long)(j * ci4n + cb * (KS / 4)) * 256;                            \
-      CK_W_ISSUE(S, 0) CK_W_ISSUE(S, 1) CK_W_ISSUE(S, 2) CK_W_ISSUE(S, 3)                                 \
-      CK_W_ISSUE(S, 4) CK_W_ISSUE(S, 5) CK_W_ISSUE(S, 6) CK_W_ISSUE(S, 7)                                 \
-      if (++jn == ktaps) { jn = 0; ++cbn; }                                                               \
-    }
-#define CK_W_STORE(S, V) if constexpr (WV > V) *reinterpret_cast<float4*>(Ws + (ltid + 256 * V) * 4) = rw##S##V;
-#define CK_STORE(S, BUF)                                                                                  \
-    {                                                                                                     \
-      float* As = lds + (BUF) * (A_FLOATS + W_FLOATS);                                                    \
-      float* Ws = As + A_FLOATS;                                                                          \
-      _Pragma("unroll") for (int q = 0; q < TM / 32; ++q)                                                 \
-        _Pragma("unroll") for (int sb = 0; sb < SB; ++sb) {                                               \
-          float4 v = ra##S[q * SB + sb][0];                                                               \
-          if constexpr (NSRC > 1) {                                                                       \
-            const float4 v1 = ra##S[q * SB + sb][1];                                                      \
-            v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;                                           \
-            if constexpr (NSRC > 2) {                                                                     \
-              const float4 v2 = ra##S[q * SB + sb][2];                                                    \
-              v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;                                         \
-            }                                                                                             \
-            const float dn = (float)NSRC; /* xs / num_resblocks (hifigan_causal.py:329): true division */ \
-            v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;                                                   \
-          }                                                                                               \
-          /* LeakyReLU as a select on the multiplier (neg_mul == 1 when no input activation) */           \
-          v.x *= v.x > 0.f ? 1.0f : neg_mul; v.y *= v.y > 0.f ? 1.0f : neg_mul;                           \
-          v.z *= v.z > 0.f ? 1.0f : neg_mul; v.w *= v.w > 0.f ? 1.0f : neg_mul;                           \
-          if (!((ok##S >> (q * SB + sb)) & 1u)) v = f4zero();                                             \
-          *reinterpret_cast<float4*>(As + (arow + 32 * q) * LDA + sb * 32 + ac4 * 4) = v;                 \
-        }                                                                                                 \
-      CK_W_STORE(S, 0) CK_W_STORE(S, 1) CK_W_STORE(S, 2) CK_W_STORE(S, 3)                                 \
-      CK_W_STORE(S, 4) CK_W_STORE(S, 5) CK_W_STORE(S, 6) CK_W_STORE(S, 7)                                 \
-    }
-
-    gbuf = (gbuf + nks) % 2;     // (register-staged build runs one tile per block: the ring always starts at 0)
-    CK_ISSUE(P)
-    if (nks > 1) CK_ISSUE(Q)
-    for (int ks = 0; ks < nks; ks += 2) {
-      CK_STORE(P, 0)
-      if (ks + 2 < nks) CK_ISSUE(P)
-      __syncthreads();                       // step ks staged (buffer 0)
-      if (ks + 1 < nks) {
-        CK_STORE(Q, 1)
-        if (ks + 3 < nks) CK_ISSUE(Q)
-        __syncthreads();                     // step ks+1 staged (buffer 1)
-      }
-    }
-#undef CK_STORE
-#undef CK_W_STORE
-#undef CK_ISSUE
-#undef CK_W_ISSUE
-    if constexpr (WK > 1) { __syncthreads(); __syncthreads(); }   // the compute waves' split-K reduction barriers
-    splitk_idle();
-    return;
-    }  // register-staged loader
   }
 
   // ===================================================================== compute waves
@@ -398,8 +279,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       const float* As = lds + bufc * (A_FLOATS + W_FLOATS);
       const float* Ws = As + A_FLOATS;
       if (++bufc == NBUF) bufc = 0;
-      if constexpr (GLDS) asm volatile("s_barrier" ::: "memory");   // B(ks): tile ks landed in LDS (clobber: no LDS read may move above it)
-      else __syncthreads();                                // step ks staged by the loader waves
+      asm volatile("s_barrier" ::: "memory");   // B(ks): tile ks landed in LDS (clobber: no LDS read may move above it)
       CK_CSTAMP(c_wait)
       // Fragments are double-buffered by hand: the ds_reads of k-group kc+1 are issued before the MFMAs of k-group kc,
       // so only the first read after the barrier is exposed (left to itself the compiler reuses one register set and
@@ -411,12 +291,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
           const int R = (wm * RM + rm) * 32 + l31;
-          if constexpr (GLDS) {
-            const int sw = (KS == 32) ? ((R >> 1) & 7) : (R & 15);
-            fa[rm] = *reinterpret_cast<const float4*>(As + R * LDA + (((kq * 2 + lh) ^ sw) * 4));
-          } else {
-            fa[rm] = *reinterpret_cast<const float4*>(As + R * LDA + kq * 8 + lh * 4);
-          }
+          const int sw = (KS == 32) ? ((R >> 1) & 7) : (R & 15);
+          fa[rm] = *reinterpret_cast<const float4*>(As + R * LDA + (((kq * 2 + lh) ^ sw) * 4));
         }
   #pragma unroll
         for (int rn = 0; rn < RN; ++rn)
@@ -429,7 +305,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
         __builtin_amdgcn_sched_barrier(0);   // keep the reads above this k-group's MFMAs
         float4 (&fa)[RM] = af[kc & 1];
         float4 (&fb)[RN] = bf[kc & 1];
-        if constexpr (GLDS && XF) {
+        if constexpr (XF) {
           // the loader cannot transform on the way: LeakyReLU of the conv input is applied here
   #pragma unroll
           for (int rm = 0; rm < RM; ++rm) {
@@ -455,14 +331,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       CK_CSTAMP(c_comp)
     }
   };
-  if (GLDS && a.in_act == ACT_LRELU) kloop(std::true_type{}); else kloop(std::false_type{});
+  if (a.in_act == ACT_LRELU) kloop(std::true_type{}); else kloop(std::false_type{});
 #ifdef CK_STAMPS
   const unsigned long long c_kend = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- intra-block split-K reduction through LDS
   if constexpr (WK > 1) {
-    if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
     constexpr int PER_WAVE = RM * RN * 16 * 64;
     if (wk > 0) {
       float* dst = red + ((wk - 1) * WM * WN + wm * WN + wn) * PER_WAVE;
@@ -473,7 +349,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #pragma unroll
           for (int e = 0; e < 16; ++e) dst[((rm * RN + rn) * 16 + e) * 64 + lane] = acc[rm][rn][e];
     }
-    if constexpr (GLDS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } else __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
     if (wk > 0) { splitk_idle(); return; }
 #pragma unroll
     for (int k2 = 1; k2 < WK; ++k2) {
@@ -723,9 +599,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 // Persistent launch: the grid is at most the number of co-resident blocks; every block walks the tile list
 // tile = blockIdx.x, blockIdx.x + gridDim.x, ...  Tiles are ordered problem by problem, longest K first (the three
 // resblock branches of a grouped launch have k = 11 / 7 / 3), n-tile fastest (neighbours share activation rows).
-template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
-__global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4 > 80 * 1024) ? 2 : 4) void conv_mfma_kernel(const ConvGroup g) {
-  __shared__ __attribute__((aligned(16))) float lds[ConvLds<TM, TN, WK, KS, NSRC>::TOTAL];
+template <int TM, int TN, int WM, int WN, int WK, int KS>
+__global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS>::TOTAL * 4 > 80 * 1024) ? 2 : 4) void conv_mfma_kernel(const ConvGroup g) {
+  __shared__ __attribute__((aligned(16))) float lds[ConvLds<TM, TN, WK, KS>::TOTAL];
   int gbuf = 0;
   const int S = g.ksplit;
   const int total = g.tile_start[3] * S;
@@ -743,7 +619,7 @@ __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4 > 80
     const int local = tile - g.tile_start[p];
     const int tn = g.tiles_n[p];
     const int mt = local / tn, nt = local - mt * tn;
-    conv_tile<TM, TN, WM, WN, WK, KS, NSRC>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, S,
+    conv_tile<TM, TN, WM, WN, WK, KS>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, S,
                                             g.slab + (long long)tile * S * (TM * TN), g.counters + tile);
     ++i;
     cur = assign ? (i < g.assign_per ? assign[i] : -1) : cur + (int)gridDim.x;
@@ -753,13 +629,22 @@ __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4 > 80
 #endif
 }
 
-static const int kTM[NUM_CFG] = {128, 64, 128, 32, 32, 64, 64, 128, 128};
-static const int kTN[NUM_CFG] = {64, 64, 32, 64, 32, 32, 64, 64, 32};
+static const int kTM[NUM_CFG] = {128, 64, 128, 32, 32, 64, 64, 128};
+static const int kTN[NUM_CFG] = {64, 64, 32, 64, 32, 32, 64, 32};
 int conv_cfg_tm(int cfg) { return kTM[cfg]; }
 int conv_cfg_tn(int cfg) { return kTN[cfg]; }
+static const int kKS[NUM_CFG] = {32, 32, 32, 64, 128, 32, 64, 64};
+int conv_cfg_ks(int cfg) { return kKS[cfg]; }
+const char* conv_cfg_name(int cfg) {
+  static const char* names[NUM_CFG] = {
+      "cnk::conv_mfma_kernel<128, 64, 2, 2, 1, 32>", "cnk::conv_mfma_kernel<64, 64, 2, 2, 1, 32>", "cnk::conv_mfma_kernel<128, 32, 4, 1, 1, 32>",
+      "cnk::conv_mfma_kernel<32, 64, 1, 2, 2, 64>",  "cnk::conv_mfma_kernel<32, 32, 1, 1, 4, 128>", "cnk::conv_mfma_kernel<64, 32, 2, 1, 2, 32>",
+      "cnk::conv_mfma_kernel<64, 64, 2, 2, 1, 64>",  "cnk::conv_mfma_kernel<128, 32, 4, 1, 1, 64>"};
+  return cfg >= 0 && cfg < NUM_CFG ? names[cfg] : "?";
+}
 
 // Schedule of a persistent launch, computed on the host and cached per launch shape in device memory (a handful of
-// shapes per model; never freed):
+// shapes per model and device; never freed; guarded by a mutex):
 //  * XCD-aware: workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2, so each XCD gets one contiguous
 //    eighth of every problem's m-tiles (or, where the weights are the larger operand, of its n-tiles) - its slice of
 //    the big operand then stays in that L2 instead of being fetched over the fabric by all eight (measured: L2 hit rate 78-85 % either way at
@@ -769,6 +654,8 @@ int conv_cfg_tn(int cfg) { return kTN[cfg]; }
 static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int* per_out) {
   struct Key { int v[12]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
   static std::map<Key, std::pair<const int*, int>> cache;
+  static std::mutex cache_mu;                       // host threads driving different devices / stream-sets share it
+  std::lock_guard<std::mutex> lock(cache_mu);
   constexpr int NX = 8;
   int nks[3];
   for (int q = 0; q < 3; ++q) { const ConvArgs& a = g.p[g.order[q]]; nks[q] = a.ktaps * ((a.Cin_pad + KS - 1) / KS); }
@@ -812,32 +699,30 @@ static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int*
   return dev;
 }
 
-template <int TM, int TN, int WM, int WN, int WK, int KS, int NSRC>
+template <int TM, int TN, int WM, int WN, int WK, int KS>
 static void launch_one(const ConvGroup& gin, int num_cu, hipStream_t st) {
-  constexpr int lds_bytes = ConvLds<TM, TN, WK, KS, NSRC>::TOTAL * 4;
+  constexpr int lds_bytes = ConvLds<TM, TN, WK, KS>::TOTAL * 4;
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   ConvGroup g = gin;
   g.assign = nullptr; g.assign_per = 0;
   int grid = g.tile_start[3] * g.ksplit;
-  if (NSRC == 1 && grid > num_cu * per_cu) {     // persistent blocks (direct-to-LDS build only)
+  if (grid > num_cu * per_cu) {     // persistent blocks
     grid = num_cu * per_cu;
     if (g.ksplit == 1) g.assign = balanced_assignment(g, grid, KS, &g.assign_per);
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, WK, KS, NSRC>), dim3(grid), dim3(512), 0, st, g);
+  hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, WK, KS>), dim3(grid), dim3(512), 0, st, g);
 }
 
-template <int NSRC>
-static void launch_conv_n(const ConvGroup& g, int cfg, int num_cu, hipStream_t st) {
+static void launch_conv_cfg(const ConvGroup& g, int cfg, int num_cu, hipStream_t st) {
   switch (cfg) {
-    case CFG_128x64: launch_one<128, 64, 2, 2, 1, 32, NSRC>(g, num_cu, st); break;
-    case CFG_64x64: launch_one<64, 64, 2, 2, 1, 32, NSRC>(g, num_cu, st); break;
-    case CFG_128x32: launch_one<128, 32, 4, 1, 1, 32, NSRC>(g, num_cu, st); break;
-    case CFG_32x64_K2: launch_one<32, 64, 1, 2, 2, 64, NSRC>(g, num_cu, st); break;
-    case CFG_32x32_K4: launch_one<32, 32, 1, 1, 4, 128, NSRC>(g, num_cu, st); break;
-    case CFG_64x32_K2: launch_one<64, 32, 2, 1, 2, 32, NSRC>(g, num_cu, st); break;
-    case CFG_64x64_KS64: launch_one<64, 64, 2, 2, 1, 64, NSRC>(g, num_cu, st); break;
-    case CFG_128x64_KS64: launch_one<128, 64, 2, 2, 1, 32, NSRC>(g, num_cu, st); break;
-    case CFG_128x32_KS64: launch_one<128, 32, 4, 1, 1, 64, NSRC>(g, num_cu, st); break;
+    case CFG_128x64: launch_one<128, 64, 2, 2, 1, 32>(g, num_cu, st); break;
+    case CFG_64x64: launch_one<64, 64, 2, 2, 1, 32>(g, num_cu, st); break;
+    case CFG_128x32: launch_one<128, 32, 4, 1, 1, 32>(g, num_cu, st); break;
+    case CFG_32x64_K2: launch_one<32, 64, 1, 2, 2, 64>(g, num_cu, st); break;
+    case CFG_32x32_K4: launch_one<32, 32, 1, 1, 4, 128>(g, num_cu, st); break;
+    case CFG_64x32_K2: launch_one<64, 32, 2, 1, 2, 32>(g, num_cu, st); break;
+    case CFG_64x64_KS64: launch_one<64, 64, 2, 2, 1, 64>(g, num_cu, st); break;
+    case CFG_128x32_KS64: launch_one<128, 32, 4, 1, 1, 64>(g, num_cu, st); break;
     default: break;
   }
 }
@@ -865,10 +750,7 @@ void launch_conv(const ConvGroup& gin, int nprob, int cfg, hipStream_t st, int n
   }
   g.tile_start[3] = acc;
   if (acc == 0) return;
-  const int nsrc = g.p[0].nsrc;
-  if (nsrc == 1) launch_conv_n<1>(g, cfg, num_cu, st);
-  else if (nsrc == 2) launch_conv_n<2>(g, cfg, num_cu, st);
-  else launch_conv_n<3>(g, cfg, num_cu, st);
+  launch_conv_cfg(g, cfg, num_cu, st);
 }
 
-}  // namespace ck
+}  // namespace cnk

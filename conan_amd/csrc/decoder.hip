@@ -2,8 +2,8 @@
 // the per-utterance style pass (reference-mel-only part), see modules/Conan/Conan.py:115-270,:324-351,:584-589.
 #include "streams.h"
 
-static ck::LNArgs mk_ln(const TRef& x, const TRef& y, float* g, float* b, const int* slots, const int* pos, int n, int T, int C) {
-  ck::LNArgs a; memset(&a, 0, sizeof(a));
+static cnk::LNArgs mk_ln(const TRef& x, const TRef& y, float* g, float* b, const int* slots, const int* pos, int n, int T, int C) {
+  cnk::LNArgs a; memset(&a, 0, sizeof(a));
   a.x = x; a.y = y; a.gamma = g; a.beta = b; a.slots = slots; a.pos = pos; a.lens = nullptr; a.T = T; a.n = n; a.C = C; a.eps = 1e-5f;
   return a;
 }
@@ -14,22 +14,24 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   const conan_cfg& c = ctx->cfg;
   const int H = c.hidden_size;
   const int* pos = pos_dec;
-  if (!has_ref) throw Error(CONAN_ERR_STATE, "conan_decoder_step before conan_set_reference (the reference raises ValueError when ref is None)");
+  for (int i = 0; i < n; ++i)
+    if (!has_ref[h_slots[i]]) throw Error(CONAN_ERR_STATE, "conan_decoder_step before conan_set_reference for slot " + std::to_string(h_slots[i]) +
+                                                            " (the reference raises ValueError when ref is None)");
   // content_embedding (Conan.py:140)
   {
-    ck::EmbedArgs a; memset(&a, 0, sizeof(a));
+    cnk::EmbedArgs a; memset(&a, 0, sizeof(a));
     a.y = c_emb.ref(); a.table = ctx->vec("conan.content_embedding"); a.idx = codes; a.slots = d_slots; a.pos = pos;
     a.T = T; a.n = n; a.C = H; a.vocab = c.content_vocab;
-    ck::launch_embed(a, st);
+    cnk::launch_embed(a, st);
   }
   // content_proj: CausalConv1d k3 + LeakyReLU(0.01) (Conan.py:57-60, :142); pitch_inp = content + style (Conan.py:162)
   {
     ConvArgs a = mk(ctx->conv("conan.content_proj"), c_emb.ref(), c_pin.ref(), n, T, pos);
-    a.out_act = ck::ACT_LRELU; a.out_slope = 0.01f; a.bvec = c_style; a.bvec_stride = H;
+    a.out_act = cnk::ACT_LRELU; a.out_slope = 0.01f; a.bvec = c_style; a.bvec_stride = H;
     conv(a, st);
     if (taps.content_embed_proj) {   // the tap is the same conv without the fused "+ style" (exact, tap mode only)
       ConvArgs t = mk(ctx->conv("conan.content_proj"), c_emb.ref(), ch::lin_ref(taps.content_embed_proj, T, H), n, T, pos);
-      t.out_act = ck::ACT_LRELU; t.out_slope = 0.01f;
+      t.out_act = cnk::ACT_LRELU; t.out_slope = 0.01f;
       conv(t, st);
     }
   }
@@ -40,18 +42,18 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     const std::string nm = "conan.align." + std::to_string(l);
     { ConvArgs a = mk(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T, pos); a.out_scale = (float)std::sqrt(1.0 / (double)dh); conv(a, st); }
     {
-      ck::XAttnArgs a; memset(&a, 0, sizeof(a));
+      cnk::XAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = c_q.ref(); a.out = c_att.ref(); a.kv = c_kv + (size_t)l * S_max * 2 * H; a.kv_slot_stride = (long long)2 * S_max * 2 * H;
       a.kmask = c_kmask; a.slen = c_slen; a.attn_avg = taps.attn[l]; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.E = H; a.H = nh; a.S_max = S_max;
-      ck::launch_xattn(a, st);
+      cnk::launch_xattn(a, st);
     }
     { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }
-    ck::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
-    { ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = ck::ACT_RELU; conv(a, st); }
+    cnk::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
+    { ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st); }
     { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
-    ck::LNArgs ln = mk_ln(c_q.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
+    cnk::LNArgs ln = mk_ln(c_q.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
     if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
-    ck::launch_layernorm(ln, st);
+    cnk::launch_layernorm(ln, st);
     src = &c_x[0];
   }
   // uv_predictor: 5 x [CausalConv k5 + ReLU] (nar_tts_modules.py:113-122)
@@ -59,21 +61,21 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     const TRef xin = i == 0 ? c_pin2.ref() : c_uvh[i - 1].ref();
     const TRef yout = i == 4 ? c_uv5.ref() : c_uvh[i].ref();
     ConvArgs a = mk(ctx->conv("conan.uv." + std::to_string(i)), xin, yout, n, T, pos);
-    a.out_act = ck::ACT_RELU;
+    a.out_act = cnk::ACT_RELU;
     conv(a, st);
   }
   {
-    ck::PitchHeadArgs a; memset(&a, 0, sizeof(a));
+    cnk::PitchHeadArgs a; memset(&a, 0, sizeof(a));
     a.h = c_uv5.ref(); a.pitch_inp = c_pin2.ref(); a.dec_inp = c_x[0].ref();
     a.gamma = ctx->vec("conan.uv.ln.g"); a.beta = ctx->vec("conan.uv.ln.b"); a.w = ctx->vec("conan.uv.lin.w"); a.b = ctx->vec("conan.uv.lin.b");
     a.pitch_embed = ctx->vec("conan.pitch_embed"); a.codes = codes; a.uv_pred = uv_pred; a.f0 = f0; a.bins = bins;
     a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.Cp = 128; a.E = H; a.silent_token = c.silent_token;
-    ck::launch_pitch_head(a, st);
+    cnk::launch_pitch_head(a, st);
   }
   if (dec_inp) {
-    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.n = n; ca.C = H; ca.T = T; ca.x = c_x[0].ref(); ca.y = ch::lin_ref(dec_inp, T, H);
-    ck::launch_copy_rows(ca, st);
+    cnk::launch_copy_rows(ca, st);
   }
   // decoder: CausalConvBlocks (conv.py:127-264)
   int cur = 0;
@@ -83,10 +85,10 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     for (int j = 0; j < c.dec_layers_in_block; ++j) {
       const std::string nm = "conan.dec." + std::to_string(b) + "." + std::to_string(j);
       Ring& lr = c_lnrs[b * c.dec_layers_in_block + j];
-      ck::LNArgs ln = mk_ln(c_x[cur].ref(), lr.ref(), ctx->vec(nm + ".ln.g"), ctx->vec(nm + ".ln.b"), d_slots, pos, n, T, H);
+      cnk::LNArgs ln = mk_ln(c_x[cur].ref(), lr.ref(), ctx->vec(nm + ".ln.g"), ctx->vec(nm + ".ln.b"), d_slots, pos, n, T, H);
       if (j == 0) { ln.mask_out = blkmask; ln.has_mask_out = 1; }
-      ck::launch_layernorm(ln, st);
-      { ConvArgs a = mk(ctx->conv(nm + ".c1"), lr.ref(), c_h.ref(), n, T, pos, c.dec_dilations[b]); a.out_scale = kscale; a.out_act = ck::ACT_GELU; conv(a, st); }
+      cnk::launch_layernorm(ln, st);
+      { ConvArgs a = mk(ctx->conv(nm + ".c1"), lr.ref(), c_h.ref(), n, T, pos, c.dec_dilations[b]); a.out_scale = kscale; a.out_act = cnk::ACT_GELU; conv(a, st); }
       {
         ConvArgs a = mk(ctx->conv(nm + ".c2"), c_h.ref(), c_x[cur ^ 1].ref(), n, T, pos);
         a.res = c_x[cur].ref(); a.has_res = 1; a.m1 = blkmask; a.has_m1 = 1;
@@ -97,13 +99,13 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     }
   }
   {
-    ck::LNArgs ln = mk_ln(c_x[cur].ref(), c_lastr.ref(), ctx->vec("conan.dec.last.g"), ctx->vec("conan.dec.last.b"), d_slots, pos, n, T, H);
+    cnk::LNArgs ln = mk_ln(c_x[cur].ref(), c_lastr.ref(), ctx->vec("conan.dec.last.g"), ctx->vec("conan.dec.last.b"), d_slots, pos, n, T, H);
     ln.m1 = c_mask_out.ref(); ln.has_m1 = 1;
-    ck::launch_layernorm(ln, st);
+    cnk::launch_layernorm(ln, st);
   }
   { ConvArgs a = mk(ctx->conv("conan.dec.post"), c_lastr.ref(), c_post.ref(), n, T, pos); a.m1 = c_mask_out.ref(); a.has_m1 = 1; conv(a, st); }
   conv(mk(ctx->conv("conan.mel_out"), c_post.ref(), ch::lin_ref(mel_out, T, c.num_mels), n, T, pos), st);
-  ck::launch_advance(pos_dec, d_slots, n, T, st);
+  cnk::launch_advance(pos_dec, d_slots, n, T, st);
 }
 
 // ------------------------------------------------------------------------------------------------ style pass
@@ -116,13 +118,13 @@ void conan_streams::conv_blocks_noncausal(const std::string& name, int nblocks, 
   for (int b = 0; b < nblocks; ++b)
     for (int j = 0; j < 2; ++j) {
       const std::string nm = name + "." + std::to_string(b) + "." + std::to_string(j);
-      ck::LNArgs l = mk_ln(x[cur].ref(PADR), ln.ref(PADR), ctx->vec(nm + ".ln.g"), ctx->vec(nm + ".ln.b"), nullptr, nullptr, n, T, C);
+      cnk::LNArgs l = mk_ln(x[cur].ref(PADR), ln.ref(PADR), ctx->vec(nm + ".ln.g"), ctx->vec(nm + ".ln.b"), nullptr, nullptr, n, T, C);
       l.lens = lens;
       if (j == 0) { l.mask_out = blkm.ref(PADR); l.has_mask_out = 1; }
-      ck::launch_layernorm(l, st);
+      cnk::launch_layernorm(l, st);
       {
         ConvArgs a = mk(ctx->conv(nm + ".c1"), ln.ref(PADR), h.ref(PADR), n, T, nullptr, 1, (k - 1) / 2);
-        a.slots = nullptr; a.lens = lens; a.out_scale = kscale; a.out_act = ck::ACT_GELU;
+        a.slots = nullptr; a.lens = lens; a.out_scale = kscale; a.out_act = cnk::ACT_GELU;
         conv(a, st);
       }
       {
@@ -148,20 +150,20 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
     int T = 0;
     for (int i = 0; i < n; ++i) { T = std::max(T, lens[i]); lens2[i] = (lens[i] + 3) / 4; }
     const int S = (T + 3) / 4;
-    HIP_CHECK(hipMemcpyAsync(d_lens, lens.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipMemcpyAsync(d_lens2, lens2.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    pin.upload(d_lens, lens.data(), (size_t)n, st);
+    pin.upload(d_lens2, lens2.data(), (size_t)n, st);
     Lin* all[] = {&s_mel, &s_np, &s_wnm, &s_x[0], &s_x[1], &s_ln, &s_h, &s_blkm, &s_wx, &s_wout, &s_win, &s_acts, &s_rs, &s_ph, &s_pm,
                   &s_px[0], &s_px[1], &s_pln, &s_phh, &s_pblk, &s_enc, &s_dots, &s_cat, &s_tok, &s_kvtmp};
     for (Lin* l : all) HIP_CHECK(hipMemsetAsync(l->base, 0, (size_t)n * l->rows * l->C * sizeof(float), st));
     {  // reference mel rows -> padded workspace
-      ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+      cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
       ca.n = n; ca.C = NM; ca.T = T; ca.lens = d_lens;
       ca.x = ch::lin_ref(const_cast<float*>(ref) + (size_t)b0 * max_len * NM, max_len, NM); ca.y = s_mel.ref(PADR);
-      ck::launch_copy_rows(ca, st);
-      ca.y = s_wx.ref(PADR); ck::launch_copy_rows(ca, st);
+      cnk::launch_copy_rows(ca, st);
+      ca.y = s_wx.ref(PADR); cnk::launch_copy_rows(ca, st);
     }
-    { ck::RowMaskArgs a; memset(&a, 0, sizeof(a)); a.x = s_mel.ref(PADR); a.m = s_np.ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.C = NM; a.mode = 0; ck::launch_rowmask(a, st);
-      a.m = s_wnm.ref(PADR); a.mode = 1; ck::launch_rowmask(a, st); }
+    { cnk::RowMaskArgs a; memset(&a, 0, sizeof(a)); a.x = s_mel.ref(PADR); a.m = s_np.ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.C = NM; a.mode = 0; cnk::launch_rowmask(a, st);
+      a.m = s_wnm.ref(PADR); a.mode = 1; cnk::launch_rowmask(a, st); }
     // ---- global style vector: encode_spk_embed (Conan.py:200-219)
     {
       ConvArgs a = mk(ctx->conv("conan.global_conv_in"), s_mel.ref(PADR), s_x[0].ref(PADR), n, T, nullptr);
@@ -171,15 +173,15 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
     int cur = 0;
     conv_blocks_noncausal("conan.genc", 5, 31, H, s_x, s_ln, s_h, s_blkm, s_np.ref(PADR), d_lens, n, T, cur, st);
     {
-      ck::LNArgs l = mk_ln(s_x[cur].ref(PADR), s_ln.ref(PADR), ctx->vec("conan.genc.last.g"), ctx->vec("conan.genc.last.b"), nullptr, nullptr, n, T, H);
+      cnk::LNArgs l = mk_ln(s_x[cur].ref(PADR), s_ln.ref(PADR), ctx->vec("conan.genc.last.g"), ctx->vec("conan.genc.last.b"), nullptr, nullptr, n, T, H);
       l.lens = d_lens; l.m1 = s_np.ref(PADR); l.has_m1 = 1;
-      ck::launch_layernorm(l, st);
+      cnk::launch_layernorm(l, st);
       ConvArgs a = mk(ctx->conv("conan.genc.post"), s_ln.ref(PADR), s_x[cur ^ 1].ref(PADR), n, T, nullptr, 1, 1);
       a.slots = nullptr; a.lens = d_lens; a.m1 = s_np.ref(PADR); a.has_m1 = 1;
       conv(a, st);
-      ck::MeanArgs m; memset(&m, 0, sizeof(m));
+      cnk::MeanArgs m; memset(&m, 0, sizeof(m));
       m.x = s_x[cur ^ 1].ref(PADR); m.m = s_np.ref(PADR); m.out = c_style; m.out_stride = H; m.slots = d_slots; m.lens = d_lens; m.T = T; m.n = n; m.C = H;
-      ck::launch_masked_mean(m, st);
+      cnk::launch_masked_mean(m, st);
     }
     // ---- local prosody tokens: LocalStyleAdaptor (prosody_util.py:183-200)
     for (int i = 0; i < 4; ++i) {   // WN (wavenet.py:56-89): kernel 3, dilation 1, gated tanh*sigmoid
@@ -187,23 +189,23 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
         ConvArgs a = mk(ctx->conv("conan.wn.in." + std::to_string(i)), s_wx.ref(PADR), s_win.ref(PADR), n, T, nullptr, 1, 1);
         a.slots = nullptr; a.lens = d_lens; conv(a, st);
       }
-      { ck::WNGateArgs a; memset(&a, 0, sizeof(a)); a.xin = s_win.ref(PADR); a.acts = s_acts.ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.H = 80; ck::launch_wn_gate(a, st); }
+      { cnk::WNGateArgs a; memset(&a, 0, sizeof(a)); a.xin = s_win.ref(PADR); a.acts = s_acts.ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.H = 80; cnk::launch_wn_gate(a, st); }
       {
         ConvArgs a = mk(ctx->conv("conan.wn.rs." + std::to_string(i)), s_acts.ref(PADR), s_rs.ref(PADR), n, T, nullptr);
         a.slots = nullptr; a.lens = d_lens; conv(a, st);
       }
-      { ck::WNUpdateArgs a; memset(&a, 0, sizeof(a)); a.rs = s_rs.ref(PADR); a.x = s_wx.ref(PADR); a.out = s_wout.ref(PADR); a.m = s_wnm.ref(PADR);
-        a.lens = d_lens; a.T = T; a.n = n; a.H = 80; a.last = i == 3; a.first = i == 0; ck::launch_wn_update(a, st); }
+      { cnk::WNUpdateArgs a; memset(&a, 0, sizeof(a)); a.rs = s_rs.ref(PADR); a.x = s_wx.ref(PADR); a.out = s_wout.ref(PADR); a.m = s_wnm.ref(PADR);
+        a.lens = d_lens; a.T = T; a.n = n; a.H = 80; a.last = i == 3; a.first = i == 0; cnk::launch_wn_update(a, st); }
     }
-    { ck::PoolArgs a; memset(&a, 0, sizeof(a)); a.x = s_wout.ref(PADR); a.m = s_wnm.ref(PADR); a.y = s_px[0].ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.C = 80; a.group = 4;
-      ck::launch_group_pool(a, st); }
-    { ck::RowMaskArgs a; memset(&a, 0, sizeof(a)); a.x = s_px[0].ref(PADR); a.m = s_pm.ref(PADR); a.lens = d_lens2; a.T = S; a.n = n; a.C = 80; a.mode = 0; ck::launch_rowmask(a, st); }
+    { cnk::PoolArgs a; memset(&a, 0, sizeof(a)); a.x = s_wout.ref(PADR); a.m = s_wnm.ref(PADR); a.y = s_px[0].ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.C = 80; a.group = 4;
+      cnk::launch_group_pool(a, st); }
+    { cnk::RowMaskArgs a; memset(&a, 0, sizeof(a)); a.x = s_px[0].ref(PADR); a.m = s_pm.ref(PADR); a.lens = d_lens2; a.T = S; a.n = n; a.C = 80; a.mode = 0; cnk::launch_rowmask(a, st); }
     int pc = 0;
     conv_blocks_noncausal("conan.penc", 5, 5, 80, s_px, s_pln, s_phh, s_pblk, s_pm.ref(PADR), d_lens2, n, S, pc, st);
     {
-      ck::LNArgs l = mk_ln(s_px[pc].ref(PADR), s_pln.ref(PADR), ctx->vec("conan.penc.last.g"), ctx->vec("conan.penc.last.b"), nullptr, nullptr, n, S, 80);
+      cnk::LNArgs l = mk_ln(s_px[pc].ref(PADR), s_pln.ref(PADR), ctx->vec("conan.penc.last.g"), ctx->vec("conan.penc.last.b"), nullptr, nullptr, n, S, 80);
       l.lens = d_lens2; l.m1 = s_pm.ref(PADR); l.has_m1 = 1;
-      ck::launch_layernorm(l, st);
+      cnk::launch_layernorm(l, st);
       ConvArgs a = mk(ctx->conv("conan.penc.post"), s_pln.ref(PADR), s_enc.ref(PADR), n, S, nullptr, 1, 1);
       a.slots = nullptr; a.lens = d_lens2; a.m1 = s_pm.ref(PADR); a.has_m1 = 1;
       conv(a, st);
@@ -211,15 +213,16 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
     // ---- VQ + positions + l1 (prosody_util.py:34-46,:88; Conan.py:244-245)
     { ConvArgs a = mk(ctx->conv("conan.vq.dot"), s_enc.ref(PADR), s_dots.ref(PADR), n, S, nullptr); a.slots = nullptr; a.lens = d_lens2; conv(a, st); }
     {
-      ck::VQArgs a; memset(&a, 0, sizeof(a));
+      cnk::VQArgs a; memset(&a, 0, sizeof(a));
       a.x = s_enc.ref(PADR); a.dots = s_dots.ref(PADR); a.cat = s_cat.ref(PADR); a.emb = ctx->vec("conan.vq.emb"); a.e2 = ctx->vec("conan.vq.e2");
       a.postable = ctx->vec("conan.postable"); a.ids = s_ids; a.lens = d_lens2; a.S = S; a.n = n; a.E = H; a.M = c.nvq; a.S_max = S_max;
-      ck::launch_vq(a, st);
+      cnk::launch_vq(a, st);
     }
     { ConvArgs a = mk(ctx->conv("conan.l1"), s_cat.ref(PADR), s_tok.ref(PADR), n, S, nullptr); a.slots = nullptr; a.lens = d_lens2; conv(a, st); }
-    { ck::KMaskArgs a; memset(&a, 0, sizeof(a)); a.tok = s_tok.ref(PADR); a.kmask = c_kmask; a.kmask_stride = S_max; a.slots = d_slots; a.lens = d_lens2; a.S = S; a.n = n; a.S_max = S_max;
-      ck::launch_kmask(a, st); }
-    ck::launch_scatter_int(c_slen, d_slots, d_lens2, n, st);
+    { cnk::KMaskArgs a; memset(&a, 0, sizeof(a)); a.tok = s_tok.ref(PADR); a.kmask = c_kmask; a.kmask_stride = S_max; a.slots = d_slots; a.lens = d_lens2; a.S = S; a.n = n; a.S_max = S_max;
+      cnk::launch_kmask(a, st); }
+    cnk::launch_scatter_int(c_slen, d_slots, d_lens2, n, st);
+    cnk::launch_scatter_ids(c_vqids, d_slots, s_ids, d_lens2, n, S_max, st);
     // ---- K/V of the two aligner layers, cached per slot
     for (int l = 0; l < 2; ++l) {
       TRef y; y.base = c_kv + (size_t)l * S_max * 2 * H; y.slot_stride = (long long)2 * S_max * 2 * H; y.C = 2 * H;
@@ -228,6 +231,6 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
       a.slots = d_slots; a.lens = d_lens2;
       conv(a, st);
     }
+    for (int i = 0; i < n; ++i) has_ref[slots[b0 + i]] = 1;
   }
-  has_ref = true;
 }

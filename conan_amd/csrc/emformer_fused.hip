@@ -15,9 +15,10 @@
 //   16-lane rows per (stream, head), K/V rows in registers, DPP row reductions -> out_proj + residual -> LN -> FFN in
 //   256-wide hidden chunks (FF1 -> ReLU -> LDS -> FF2 accumulate, K split over the 4 waves) -> + residual -> LN.
 // Token order inside a stream is [right context | utterance] like torchaudio's _EmformerLayer.infer.
+#include <atomic>
 #include "kernels.h"
 
-namespace ck {
+namespace cnk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -543,8 +544,15 @@ bool emformer_fused_supported(const EmfFusedArgs& a) {
 template <int KQD, int DH>
 static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
   const int G = ef_streams_per_block(a.R + a.U, a.H);
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)emformer_fused_kernel<KQD, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  // the attribute is per device (the code object is loaded once per device): remember which devices have it
+  static std::atomic<unsigned long long> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)emformer_fused_kernel<KQD, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_devs.fetch_or(bit, std::memory_order_release);
+  }
   hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH>), dim3((a.n + G - 1) / G), dim3(256), emformer_fused_smem(a), st, a);
 }
 
@@ -555,4 +563,4 @@ void launch_emformer_fused(const EmfFusedArgs& a, hipStream_t st) {
   else if (a.D == 64 && a.D / a.H == 8) launch_ef<4, 8>(a, st);
 }
 
-}  // namespace ck
+}  // namespace cnk

@@ -7,7 +7,7 @@
 
 #include "host_common.h"
 
-namespace ck {
+namespace cnk {
 
 struct FrameArgs { const float* wav; const float* win; float* out; int n, samples, frames, hop, n_fft; };
 
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const LogMelArgs a) {
   a.y[e] = fminf(fmaxf(v, a.vmin), a.vmax);
 }
 
-}  // namespace ck
+}  // namespace cnk
 
 namespace {
 
@@ -57,23 +57,23 @@ double mel_to_hz(double m) {
   return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
 }
 
-ck::ConvArgs linear_args(const ch::PackedConv& pc, float* x, int xC, float* y, int rows) {
-  ck::ConvArgs a; memset(&a, 0, sizeof(a));
-  a.x[0] = a.x[1] = a.x[2] = ch::lin_ref(x, rows, xC); a.nsrc = 1;
+cnk::ConvArgs linear_args(const ch::PackedConv& pc, float* x, int xC, float* y, int rows) {
+  cnk::ConvArgs a; memset(&a, 0, sizeof(a));
+  a.x = ch::lin_ref(x, rows, xC);
   a.y = ch::lin_ref(y, rows, pc.Cout);
   a.res = ch::null_ref(); a.m1 = ch::null_ref(); a.m2 = ch::null_ref();
   a.w = pc.w; a.bias = pc.bias;
   a.Cin = pc.Cin; a.Cin_pad = pc.Cin_pad; a.Cin_alloc = pc.Cin_alloc; a.Cout = pc.Cout; a.Cout_pad = pc.Cout_pad;
   a.ktaps = 1; a.dil = 1; a.pad_left = 0; a.T = rows; a.n = 1;
-  a.in_act = ck::ACT_NONE; a.out_act = ck::ACT_NONE; a.out_scale = 1.f; a.shuffle_r = 1;
+  a.in_act = cnk::ACT_NONE; a.out_act = cnk::ACT_NONE; a.out_scale = 1.f; a.shuffle_r = 1;
   return a;
 }
 
-void run_linear(conan_ctx* ctx, const ck::ConvArgs& a, hipStream_t st) {
-  ck::ConvGroup g; memset(&g, 0, sizeof(g));
+void run_linear(conan_ctx* ctx, const cnk::ConvArgs& a, hipStream_t st) {
+  cnk::ConvGroup g; memset(&g, 0, sizeof(g));
   g.p[0] = a; g.ksplit = 1;
   const long long tiles64 = (long long)((a.T + 63) / 64) * ((a.Cout + 63) / 64);
-  ck::launch_conv(g, 1, tiles64 >= ctx->num_cu ? ck::CFG_64x64 : ck::CFG_32x32_K4, st, ctx->num_cu);
+  cnk::launch_conv(g, 1, tiles64 >= ctx->num_cu ? cnk::CFG_64x64 : cnk::CFG_32x32_K4, st, ctx->num_cu);
 }
 
 }  // namespace
@@ -136,10 +136,10 @@ void conan_ctx::wav2mel(const conan_mel_cfg& m, const float* wav, int n, int sam
     fe_ws = dev_alloc(need, false); fe_ws_floats = need;
   }
   float* fr = fe_ws; float* spec = fr + (size_t)rows * N; float* mag = spec + (size_t)rows * 2 * NBP; float* melraw = mag + (size_t)rows * CM;
-  { ck::FrameArgs a{wav, vec(k + ".win"), fr, n, samples, frames, m.hop_size, N}; hipLaunchKernelGGL(ck::stft_frames_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
+  { cnk::FrameArgs a{wav, vec(k + ".win"), fr, n, samples, frames, m.hop_size, N}; hipLaunchKernelGGL(cnk::stft_frames_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
   run_linear(this, linear_args(conv(k + ".dft"), fr, N, spec, (int)rows), st);
-  { ck::MagArgs a{spec, mag, rows, NB, NBP, CM}; hipLaunchKernelGGL(ck::stft_mag_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
+  { cnk::MagArgs a{spec, mag, rows, NB, NBP, CM}; hipLaunchKernelGGL(cnk::stft_mag_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
   run_linear(this, linear_args(conv(k + ".mel"), mag, CM, melraw, (int)rows), st);
-  { const long long total = rows * m.num_mels; ck::LogMelArgs a{melraw, mel_out, total, m.eps, m.vmin, m.vmax};
-    hipLaunchKernelGGL(ck::logmel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a); }
+  { const long long total = rows * m.num_mels; cnk::LogMelArgs a{melraw, mel_out, total, m.eps, m.vmin, m.vmax};
+    hipLaunchKernelGGL(cnk::logmel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a); }
 }

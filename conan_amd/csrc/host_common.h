@@ -43,8 +43,8 @@ struct Ring {
   float* base = nullptr;
   int L = 0, C = 0, rate = 1;
   long long slot_stride = 0;
-  ck::TRef ref(int off = 0) const {
-    ck::TRef r; r.base = base; r.slot_stride = slot_stride; r.C = C; r.lmask = L - 1; r.rate = rate; r.off = off; r.mode = 0; r.pad_ = 0;
+  cnk::TRef ref(int off = 0) const {
+    cnk::TRef r; r.base = base; r.slot_stride = slot_stride; r.C = C; r.lmask = L - 1; r.rate = rate; r.off = off; r.mode = 0; r.pad_ = 0;
     return r;
   }
   long long floats_per_slot() const { return slot_stride; }
@@ -53,16 +53,16 @@ struct Ring {
 struct Lin {   // batch-indexed linear buffer [n][rows][C]
   float* base = nullptr;
   int rows = 0, C = 0;
-  ck::TRef ref(int off = 0) const {
-    ck::TRef r; r.base = base; r.slot_stride = (long long)rows * C; r.C = C; r.lmask = 0; r.rate = 0; r.off = off; r.mode = 1; r.pad_ = 0;
+  cnk::TRef ref(int off = 0) const {
+    cnk::TRef r; r.base = base; r.slot_stride = (long long)rows * C; r.C = C; r.lmask = 0; r.rate = 0; r.off = off; r.mode = 1; r.pad_ = 0;
     return r;
   }
 };
 
-inline ck::TRef lin_ref(float* p, int rows, int C, int off = 0) {
+inline cnk::TRef lin_ref(float* p, int rows, int C, int off = 0) {
   Lin l; l.base = p; l.rows = rows; l.C = C; return l.ref(off);
 }
-inline ck::TRef null_ref() { ck::TRef r; memset(&r, 0, sizeof(r)); r.mode = 1; return r; }
+inline cnk::TRef null_ref() { cnk::TRef r; memset(&r, 0, sizeof(r)); r.mode = 1; return r; }
 
 inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

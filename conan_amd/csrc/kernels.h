@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace ck {
+namespace cnk {
 
 // A channel-last fp32 activation tensor [slot][row][C].
 //  mode 0 (ring):   row(t) = (pos[slot] * rate + off + t) & lmask, slot = slots[i]
@@ -23,12 +23,12 @@ enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4
 
 // Causal / shifted 1-D convolution as an implicit GEMM on the f32 MFMA:
 //   y[i][t][co] = epilogue( sum_{j<ktaps} sum_{ci<Cin} W[j][ci][co] * f(x[i][t + j*dil - pad_left][ci]) )
-//   f(v)        = in_act( (x0 + x1 + x2) / nsrc )
+//   f(v)        = in_act(v)   (LeakyReLU only; the hot layers read tensors their producer stored activated)
 //   epilogue(a) = ((out_act((a + bias[co]) * out_scale) + bvec[slot][co]) + res[i][t][co]) * m1[i][t] * m2[i][t]
 // and, with shuffle_r > 1, the pixel-shuffled store y[i][t*r + co / Cq][co % Cq] (Cq = Cout / r) for
 // weights whose output channels were permuted to j-major at pack time.
 struct ConvArgs {
-  TRef x[3];
+  TRef x;
   TRef y;
   TRef res;
   TRef m1, m2;          // per-row masks (C == 1)
@@ -39,7 +39,6 @@ struct ConvArgs {
   const int* pos;       // per-slot frame counters (indexed by slot) or nullptr
   const int* lens;      // per-batch valid output rows (or nullptr: all T rows valid)
   long long bvec_stride;
-  int nsrc;
   int has_res, has_m1, has_m2;
   int Cin, Cin_pad, Cout, Cout_pad;
   int ktaps, dil, pad_left;
@@ -79,7 +78,9 @@ struct ConvGroup {      // up to 3 independent problems in one launch
 
 // Tile configurations of conv_mfma (block = 256 threads = 4 waves).
 enum ConvCfg { CFG_128x64 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_32x64_K2 = 3, CFG_32x32_K4 = 4, CFG_64x32_K2 = 5,
-               CFG_64x64_KS64 = 6, CFG_128x64_KS64 = 7, CFG_128x32_KS64 = 8, NUM_CFG };
+               CFG_64x64_KS64 = 6, CFG_128x32_KS64 = 7, NUM_CFG };
+int conv_cfg_ks(int cfg);          // K-step of the configuration
+const char* conv_cfg_name(int cfg);  // the kernel's name as rocprofv3 prints it
 int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);
 void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num_cu = 256);
@@ -203,6 +204,9 @@ void launch_advance(int* pos, const int* slots, int n, int delta, hipStream_t st
 void launch_fill_int(int* p, const int* slots, int n, int value, hipStream_t st);
 void launch_copy_int_rows(int* dst, const int* src, int n, int T, int S, hipStream_t st);
 void launch_scatter_int(int* dst, const int* slots, const int* src, int n, hipStream_t st);
+void launch_scatter_ids(int* dst, const int* slots, const int* src, const int* lens, int n, int S_max, hipStream_t st);   // dst[slot][s] = s < lens[i] ? src[i][s] : -1
+void launch_gather_ids(int* dst, int* cnt, const int* src, const int* slen, const int* slots, int n, int S_max, hipStream_t st);
+void launch_scatter_rows(float* dst, const float* src, const int* slots, int n, int C, hipStream_t st);   // dst[slots[i]][:] = src[i][:]
 void launch_zero_slots(float* base, long long slot_stride, long long count, const int* slots, int n, hipStream_t st);
 
 // ---- style pass (per utterance) helpers
@@ -228,4 +232,4 @@ void launch_masked_mean(const MeanArgs& a, hipStream_t st);
 struct ScaleMaskArgs { TRef x; TRef m; const int* lens; int T, n, C; };           // x *= m (in place)
 void launch_mul_mask(const ScaleMaskArgs& a, hipStream_t st);
 
-}  // namespace ck
+}  // namespace cnk

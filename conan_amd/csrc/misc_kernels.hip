@@ -4,7 +4,7 @@
 // Reductions use 64-lane wavefront shuffles; one wave owns one row.
 #include "kernels.h"
 
-namespace ck {
+namespace cnk {
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -473,6 +473,31 @@ __global__ void scatter_int_kernel(int* dst, const int* slots, const int* src, i
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[slots[i]] = src[i];
 }
+__global__ void scatter_ids_kernel(int* dst, const int* slots, const int* src, const int* lens, int n, int S_max) {
+  const int i = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S_max) dst[(long long)slots[i] * S_max + s] = s < lens[i] ? src[(long long)i * S_max + s] : -1;
+}
+void launch_scatter_ids(int* dst, const int* slots, const int* src, const int* lens, int n, int S_max, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scatter_ids_kernel, dim3((S_max + 63) / 64, n), dim3(64), 0, st, dst, slots, src, lens, n, S_max);
+}
+__global__ void gather_ids_kernel(int* dst, int* cnt, const int* src, const int* slen, const int* slots, int n, int S_max) {
+  const int i = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < S_max) dst[(long long)i * S_max + s] = src[(long long)slots[i] * S_max + s];
+  if (cnt && s == 0) cnt[i] = slen[slots[i]];
+}
+void launch_gather_ids(int* dst, int* cnt, const int* src, const int* slen, const int* slots, int n, int S_max, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_ids_kernel, dim3((S_max + 63) / 64, n), dim3(64), 0, st, dst, cnt, src, slen, slots, n, S_max);
+}
+__global__ void scatter_rows_kernel(float* dst, const float* src, const int* slots, int C) {
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) dst[(long long)slots[i] * C + c] = src[(long long)i * C + c];
+}
+void launch_scatter_rows(float* dst, const float* src, const int* slots, int n, int C, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(64), 0, st, dst, src, slots, C);
+}
 void launch_scatter_int(int* dst, const int* slots, const int* src, int n, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(scatter_int_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dst, slots, src, n);
@@ -666,4 +691,4 @@ void launch_mul_mask(const ScaleMaskArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(mul_mask_kernel, dim3(rows), dim3(a.C >= 256 ? 256 : 64), 0, st, a);
 }
 
-}  // namespace ck
+}  // namespace cnk

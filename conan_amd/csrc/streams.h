@@ -6,9 +6,9 @@ using ch::Error;
 using ch::Lin;
 using ch::PackedConv;
 using ch::Ring;
-using ck::ConvArgs;
-using ck::ConvGroup;
-using ck::TRef;
+using cnk::ConvArgs;
+using cnk::ConvGroup;
+using cnk::TRef;
 
 constexpr int kMaxBranches = 3;
 constexpr int PADR = 16;   // zero rows before/after a reference utterance in the style-pass buffers (k31 -> 15)
@@ -20,6 +20,35 @@ struct VocStage {
   std::vector<std::vector<Ring>> xt, xo;    // [branch][dilation]; xt is stored activated
   std::vector<std::vector<Ring>> xa;        // leaky_relu(xo) for the outputs that feed another c1
   int C = 0, rate = 1;
+};
+
+// Small host tables (slot lists, reference lengths) go to the device through a ring of pinned staging buffers: an
+// asynchronous copy from pageable memory may still be reading the host buffer after the call returns, and the callers'
+// vectors do not live that long.  A buffer is reused only after the copy that read it has completed (event).
+struct PinRing {
+  static constexpr int N = 8;
+  int* buf = nullptr;
+  size_t cap = 0;            // ints per buffer
+  hipEvent_t ev[N] = {};
+  int next = 0, cur = 0;
+  void init(size_t ints) {
+    cap = ints;
+    HIP_CHECK(hipHostMalloc((void**)&buf, cap * N * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < N; ++i) HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+  }
+  // copy `n` ints to `dst` (device) on `st`
+  void upload(int* dst, const int* src, size_t n, hipStream_t st) {
+    if (n > cap) throw ch::Error(CONAN_ERR_INVALID, "host table larger than the staging buffer");
+    cur = next; next = (next + 1) % N;
+    HIP_CHECK(hipEventSynchronize(ev[cur]));          // never recorded / long complete in the steady state
+    memcpy(buf + (size_t)cur * cap, src, n * sizeof(int));
+    HIP_CHECK(hipMemcpyAsync(dst, buf + (size_t)cur * cap, n * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipEventRecord(ev[cur], st));
+  }
+  ~PinRing() {
+    for (int i = 0; i < N; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (buf) (void)hipHostFree(buf);
+  }
 };
 
 struct conan_streams {
@@ -35,11 +64,17 @@ struct conan_streams {
   int* d_lens = nullptr;    // [max_slots] per-batch lengths (style pass)
   int* d_lens2 = nullptr;
   int* d_codes = nullptr;   // [max_slots][max_frames] codes scratch for the fused step
-  float* sk_slab = nullptr; // inter-block split-K partial tiles
-  int* sk_counters = nullptr;
+  // inter-block split-K workspaces (partial tiles + ticket counters), one per stream that can have conv launches in
+  // flight: [0] the caller's stream and the pipelined front-end, [1] the pipelined vocoder (conan_step_async runs the
+  // two concurrently, and both split K at small batch sizes)
+  float* sk_slab[2] = {nullptr, nullptr};
+  int* sk_counters[2] = {nullptr, nullptr};
   long long sk_slab_floats = 0;
   int sk_max_tiles = 0;
   std::vector<int> h_slots;
+  std::vector<int> slot_seen;   // duplicate detection: generation stamp per slot
+  int slot_gen = 0;
+  PinRing pin;
   int* pos_emf = nullptr; int* pos_dec = nullptr; int* pos_voc = nullptr;
 
   // --- vocoder
@@ -49,7 +84,7 @@ struct conan_streams {
   std::vector<Ring> e_k, e_v;
   Lin e_x[2], e_ln, e_q, e_kv, e_att, e_r1, e_ffn, e_h, e_r2, e_logits;
   bool emf_fused = false;
-  ck::EmfFusedArgs emf_fused_args;
+  cnk::EmfFusedArgs emf_fused_args;
   // --- conan decoder
   Ring c_emb, c_pin2, c_uvh[4], c_lastr;
   std::vector<Ring> c_lnrs;     // post-LN rings, one per (block, sub-layer)
@@ -58,7 +93,8 @@ struct conan_streams {
   float* c_kv = nullptr;        // [slot][2 layers][S_max][2H]
   float* c_kmask = nullptr;     // [slot][S_max]
   int* c_slen = nullptr;        // [slot]
-  bool has_ref = false;
+  int* c_vqids = nullptr;       // [slot][S_max] VQ indices of the prosody tokens (-1 past the token count)
+  std::vector<char> has_ref;    // per slot: conan_set_reference has run for it
   // --- style pass workspace (batch indexed, max_slots_sp at a time)
   int sp_batch = 0;
   Lin s_mel, s_np, s_wnm, s_x[2], s_ln, s_h, s_blkm, s_wx, s_wout, s_win, s_acts, s_rs, s_ph, s_pm, s_px[2], s_pln, s_phh,
@@ -115,15 +151,15 @@ struct conan_streams {
   size_t prof_used = 0;
   double prof_flops = 0.0;
   long long prof_launches = 0;
-  struct ProfRec { int cfg, nsrc; double flops; };
+  struct ProfRec { int cfg; double flops; };
   std::vector<ProfRec> prof_rec;                 // one per recorded launch (same order as prof_ev)
-  struct ProfKernel { int cfg, nsrc; double ms, flops; long long n; };
+  struct ProfKernel { int cfg; double ms, flops; long long n; };
   std::vector<ProfKernel> prof_kernels;          // filled by conan_profile_end: per template instantiation
   void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
   void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;
 
-  void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st);
+  void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps = nullptr);
   void emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st);
   void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st);
   void set_reference(const int32_t* slots, int n, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st);

@@ -7,12 +7,12 @@ ConvArgs conan_streams::mk(const PackedConv& pc, const TRef& x, const TRef& y, i
                            int pad_left) const {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.x[0] = x; a.x[1] = x; a.x[2] = x; a.nsrc = 1;
+  a.x = x;
   a.y = y; a.res = ch::null_ref(); a.m1 = ch::null_ref(); a.m2 = ch::null_ref();
   a.w = pc.w; a.bias = pc.bias; a.bvec = nullptr; a.slots = d_slots; a.pos = pos; a.lens = nullptr;
   a.Cin = pc.Cin; a.Cin_pad = pc.Cin_pad; a.Cin_alloc = pc.Cin_alloc; a.Cout = pc.Cout; a.Cout_pad = pc.Cout_pad;
   a.ktaps = pc.k; a.dil = dil; a.pad_left = pad_left < 0 ? (pc.k - 1) * dil : pad_left;
-  a.T = T; a.n = n; a.in_act = ck::ACT_NONE; a.in_slope = 0.f; a.out_act = ck::ACT_NONE; a.out_scale = 1.f; a.out_slope = 0.f;
+  a.T = T; a.n = n; a.in_act = cnk::ACT_NONE; a.in_slope = 0.f; a.out_act = cnk::ACT_NONE; a.out_scale = 1.f; a.out_slope = 0.f;
   a.shuffle_r = pc.shuffle_r;
   if (x.C != pc.Cin && !(x.C > pc.Cin)) throw Error(CONAN_ERR_SHAPE, "conv input width mismatch");
   return a;
@@ -23,20 +23,20 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
   // its 3-deep direct-to-LDS ring needs 92 KB) on every streaming layer; below one block per CU the small-M shapes
   // with intra-block split-K take over, and when even those cannot fill the chip the one with the most blocks
   // (those layers are latency-bound).
-  const int wide[] = {ck::CFG_64x64, ck::CFG_32x64_K2, ck::CFG_32x32_K4};
-  const int narrow[] = {ck::CFG_128x32, ck::CFG_64x32_K2, ck::CFG_32x32_K4};
+  const int wide[] = {cnk::CFG_64x64, cnk::CFG_32x64_K2, cnk::CFG_32x32_K4};
+  const int narrow[] = {cnk::CFG_128x32, cnk::CFG_64x32_K2, cnk::CFG_32x32_K4};
   const int* order = N <= 32 ? narrow : wide;
   const int cnt = 3;
   long long need = ctx->num_cu;
   int best = order[cnt - 1];
   for (int k = 0; k < cnt; ++k) {
     int c = order[k];
-    long long blocks = (long long)((M + ck::conv_cfg_tm(c) - 1) / ck::conv_cfg_tm(c)) * ((N + ck::conv_cfg_tn(c) - 1) / ck::conv_cfg_tn(c)) * nprob;
+    long long blocks = (long long)((M + cnk::conv_cfg_tm(c) - 1) / cnk::conv_cfg_tm(c)) * ((N + cnk::conv_cfg_tn(c) - 1) / cnk::conv_cfg_tn(c)) * nprob;
     if (blocks >= need) {
       best = c;
       // too few 64x64 tiles for two blocks per CU (stage-1 resblocks at 64 streams: 384 tiles): the K-step-64 build runs
       // one persistent block per CU over a balanced tile list instead of leaving a third of the CUs half empty
-      if (c == ck::CFG_64x64 && blocks < 2 * need) best = ck::CFG_64x64_KS64;
+      if (c == cnk::CFG_64x64 && blocks < 2 * need) best = cnk::CFG_64x64_KS64;
       break;
     }
   }
@@ -50,19 +50,20 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     // removes two dependent global loads from the prologue and from the epilogue of these latency-bound launches
     ConvArgs& a = g.p[p];
     bool ring = a.y.mode == 0 || (a.has_res && a.res.mode == 0) || (a.has_m1 && a.m1.mode == 0) || (a.has_m2 && a.m2.mode == 0) || a.bvec != nullptr;
-    for (int q = 0; q < a.nsrc; ++q) ring = ring || a.x[q].mode == 0;
+    ring = ring || a.x.mode == 0;
     if (!ring) { a.slots = nullptr; a.pos = nullptr; }
     // the direct-to-LDS loader addresses its input with 32-bit byte offsets from the tensor base
-    if (a.nsrc == 1 && (long long)(a.x[0].mode == 0 ? max_slots : a.n) * a.x[0].slot_stride * 4 >= (1ll << 32))
+    if ((long long)(a.x.mode == 0 ? max_slots : a.n) * a.x.slot_stride * 4 >= (1ll << 32))
       throw Error(CONAN_ERR_UNSUPPORTED, "activation tensor of 4 GiB or more: lower max_slots");
     if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
-  g.slab = sk_slab; g.counters = sk_counters; g.ksplit = 1;
-  if (nprob == 1 && ck::conv_cfg_tm(cfg) == 32) {
+  const int wsi = (st_voc != nullptr && st == st_voc) ? 1 : 0;
+  g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1;
+  if (nprob == 1 && cnk::conv_cfg_tm(cfg) == 32) {
     const ConvArgs& a = g.p[0];
-    const int TM = ck::conv_cfg_tm(cfg), TN = ck::conv_cfg_tn(cfg);
-    const int KS = (cfg == ck::CFG_32x64_K2) ? 64 : 128;
+    const int TM = cnk::conv_cfg_tm(cfg), TN = cnk::conv_cfg_tn(cfg);
+    const int KS = cnk::conv_cfg_ks(cfg);
     const long long tiles = (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
     const int nks = a.ktaps * ((a.Cin_pad + KS - 1) / KS);
     int S = tiles > 0 ? (int)(ctx->num_cu / tiles) : 1;
@@ -73,7 +74,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     // split only when it removes at least a dozen steps from the critical path
     if (S >= 2 && tiles <= sk_max_tiles && nks - nks / S >= 12) g.ksplit = S;
   }
-  if (!prof_on) { ck::launch_conv(g, nprob, cfg, st, ctx->num_cu); return; }
+  if (!prof_on) { cnk::launch_conv(g, nprob, cfg, st, ctx->num_cu); return; }
   if (prof_used == prof_ev.size()) {
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
@@ -81,13 +82,13 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   }
   auto& ev = prof_ev[prof_used++];
   HIP_CHECK(hipEventRecord(ev.first, st));
-  ck::launch_conv(g, nprob, cfg, st, ctx->num_cu);
+  cnk::launch_conv(g, nprob, cfg, st, ctx->num_cu);
   HIP_CHECK(hipEventRecord(ev.second, st));
   double fl = 0.0;
   for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
   prof_flops += fl;
   prof_launches += 1;
-  prof_rec.push_back({cfg, g.p[0].nsrc, fl});
+  prof_rec.push_back({cfg, fl});
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
@@ -97,10 +98,14 @@ void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
     if (slots[i] < 0 || slots[i] >= max_slots) throw Error(CONAN_ERR_INVALID, "slot index out of range");
     if (same && h_slots[i] != slots[i]) same = false;
   }
-  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n && n <= 64; ++j) if (slots[i] == slots[j]) throw Error(CONAN_ERR_INVALID, "duplicate slot");
   if (same) return;
+  if (++slot_gen == 0x7fffffff) { std::fill(slot_seen.begin(), slot_seen.end(), 0); slot_gen = 1; }
+  for (int i = 0; i < n; ++i) {
+    if (slot_seen[slots[i]] == slot_gen) throw Error(CONAN_ERR_INVALID, "duplicate slot");
+    slot_seen[slots[i]] = slot_gen;
+  }
   h_slots.assign(slots, slots + n);
-  HIP_CHECK(hipMemcpyAsync(d_slots, h_slots.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+  pin.upload(d_slots, h_slots.data(), (size_t)n, st);
 }
 
 // ------------------------------------------------------------------------------------------------ pipelined stepping
@@ -157,21 +162,28 @@ void conan_streams::build_vocoder() {
   }
 }
 
-void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st) {
+void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps) {
   const conan_cfg& c = ctx->cfg;
   const int* pos = pos_voc;
   const float LR = 0.1f;   // LRELU_SLOPE, hifigan_causal.py:20
   {  // mel chunk -> ring (conv_pre needs 6 frames of left context)
-    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.x = ch::lin_ref(const_cast<float*>(mel_dev), frames, c.num_mels); ca.y = v_mel.ref();
     ca.slots = d_slots; ca.pos = pos; ca.lens = nullptr; ca.T = frames; ca.n = n; ca.C = c.num_mels;
-    ck::launch_copy_rows(ca, st);
+    cnk::launch_copy_rows(ca, st);
   }
   {  // conv_pre; its only consumer is leaky_relu -> ups[0] (hifigan_causal.py:319-322), so the activation is stored
     ConvArgs a = mk(ctx->conv("voc.conv_pre"), v_mel.ref(), v_pre.ref(), n, frames, pos);
-    a.out_act = ck::ACT_LRELU; a.out_slope = LR;
+    a.out_act = cnk::ACT_LRELU; a.out_slope = LR;
     conv(a, st);
   }
+  auto tap = [&](float* dst, const Ring& r, int T) {   // rows of this step: ring -> caller buffer [n][T][C]
+    if (!dst) return;
+    cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    ca.x = r.ref(); ca.y = ch::lin_ref(dst, T, r.C); ca.slots = d_slots; ca.pos = pos; ca.T = T; ca.n = n; ca.C = r.C;
+    cnk::launch_copy_rows(ca, st);
+  };
+  if (taps) tap(taps->conv_pre_act, v_pre, frames);
   const int NB = c.voc_num_resblocks, ND = c.voc_rb_num_dil;
   if (NB > kMaxBranches) throw Error(CONAN_ERR_UNSUPPORTED, "more than 3 resblock branches");
   int ridx = 0;
@@ -184,6 +196,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos);
       a.y2_base = s.upa.base; a.y2_slope = LR;
       conv(a, st);
+      if (taps) tap(taps->ups[i], s.up, T);
     }
     for (int d = 0; d < ND && c.voc_resblock == 2; ++d) {  // ResBlock2 (hifigan_causal.py:255-261): x = conv_d(lrelu(x)) + x
       ConvGroup g1;
@@ -206,7 +219,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         const TRef xin_act = d == 0 ? s.upa.ref() : s.xa[b][d - 1].ref();
         std::string base = "voc.rb." + std::to_string(ridx + b);
         ConvArgs a1 = mk(ctx->conv(base + ".c1." + std::to_string(d)), xin_act, s.xt[b][d].ref(), n, T, pos, c.voc_rb_dilations[b][d]);
-        a1.out_act = ck::ACT_LRELU; a1.out_slope = LR;
+        a1.out_act = cnk::ACT_LRELU; a1.out_slope = LR;
         g1.p[b] = a1;
         ConvArgs a2 = mk(ctx->conv(base + ".c2." + std::to_string(d)), s.xt[b][d].ref(), s.xo[b][d].ref(), n, T, pos, 1);
         a2.res = xin; a2.has_res = 1;
@@ -218,22 +231,22 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       launch_group(g2, NB, cfg, st);
     }
     {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1] / conv_post
-      ck::MeanActArgs ma; memset(&ma, 0, sizeof(ma));
+      cnk::MeanActArgs ma; memset(&ma, 0, sizeof(ma));
       for (int b = 0; b < NB; ++b) ma.x[b] = s.xo[b][ND - 1].ref();
       ma.y = s.xs.ref(); ma.slots = d_slots; ma.pos = pos; ma.nsrc = NB; ma.T = T; ma.n = n; ma.C = s.C; ma.slope = LR;
-      ck::launch_mean_act(ma, st);
+      cnk::launch_mean_act(ma, st);
     }
     ridx += NB;
   }
   {  // conv_post + tanh on leaky_relu(xs / NB)   (hifigan_causal.py:329-333)
     VocStage& s = v_st.back();
     const int T = frames * s.rate;
-    ck::ConvPostArgs a; memset(&a, 0, sizeof(a));
+    cnk::ConvPostArgs a; memset(&a, 0, sizeof(a));
     a.x = s.xs.ref(); a.w = ctx->vec("voc.conv_post.w"); a.bias = ctx->scalars.at("voc.conv_post.b");
     a.wav = wav_out; a.pre = pre_tanh; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.C = s.C; a.k = (int)ctx->scalars.at("voc.conv_post.k");
-    ck::launch_conv_post(a, st);
+    cnk::launch_conv_post(a, st);
   }
-  ck::launch_advance(pos_voc, d_slots, n, frames, st);
+  cnk::launch_advance(pos_voc, d_slots, n, frames, st);
 }
 
 // ------------------------------------------------------------------------------------------------ emformer
@@ -250,11 +263,11 @@ void conan_streams::build_emformer() {
   e_att = mk_lin(Q, D); e_r1 = mk_lin(Q, D); e_ffn = mk_lin(Q, D); e_h = mk_lin(Q, c.emf_ffn_dim); e_r2 = mk_lin(Q, D);
   e_logits = mk_lin(c.emf_segment, c.emf_output_dim);
   // plan of the fused step; the per-op path below stays for shapes it does not cover (and CONAN_EMF_UNFUSED=1)
-  ck::EmfFusedArgs& a = emf_fused_args; memset(&a, 0, sizeof(a));
-  if (c.emf_layers <= ck::EMF_MAX_LAYERS) {
+  cnk::EmfFusedArgs& a = emf_fused_args; memset(&a, 0, sizeof(a));
+  if (c.emf_layers <= cnk::EMF_MAX_LAYERS) {
     for (int l = 0; l < c.emf_layers; ++l) {
       const std::string nm = "emf." + std::to_string(l);
-      ck::EmfLayerW& w = a.layers[l];
+      cnk::EmfLayerW& w = a.layers[l];
       const ch::PackedConv &q = ctx->conv(nm + ".q"), &kv = ctx->conv(nm + ".kv"), &o = ctx->conv(nm + ".out"), &f1 = ctx->conv(nm + ".ff1"), &f2 = ctx->conv(nm + ".ff2");
       if (D % 16 || c.emf_ffn_dim % 64) return;   // no fragment-major copies for such shapes: per-op path
       w.wqkv = ctx->vec(nm + ".fqkv"); w.wo = ctx->vec(nm + ".fo"); w.w1 = ctx->vec(nm + ".f1"); w.w2 = ctx->vec(nm + ".f2");
@@ -278,7 +291,7 @@ void conan_streams::build_emformer() {
     a.F = c.emf_ffn_dim; a.K = c.emf_output_dim; a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
     { const unsigned long long per_g = (unsigned long long)std::max(c.emf_left_context, 1) * (D / 4); a.magic_per_g = (unsigned)(((1ull << 32) + per_g - 1) / per_g); }
     const char* off = getenv("CONAN_EMF_UNFUSED");
-    emf_fused = ck::emformer_fused_supported(a) && !(off && off[0] == '1');
+    emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1');
   }
 }
 
@@ -286,24 +299,24 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
   const conan_cfg& c = ctx->cfg;
   const int D = c.emf_input_dim, R = c.emf_right_context, U = c.emf_segment, Q = R + U;
   if (emf_fused) {   // whole step in one launch (emformer_fused.hip)
-    ck::EmfFusedArgs a = emf_fused_args;
+    cnk::EmfFusedArgs a = emf_fused_args;
     a.chunk = chunk; a.out = out; a.logits = logits; a.codes = codes; a.n = n;
-    ck::launch_emformer_fused(a, st);
+    cnk::launch_emformer_fused(a, st);
     return;
   }
   // token order inside the layers is [right_context | utterance] (torchaudio _EmformerLayer.infer): reorder the chunk
   {
-    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.slots = nullptr; ca.pos = nullptr; ca.lens = nullptr; ca.n = n; ca.C = D;
-    ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, U); ca.y = e_x[0].ref(0); ca.T = R; if (R > 0) ck::launch_copy_rows(ca, st);
-    ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, 0); ca.y = e_x[0].ref(R); ca.T = U; ck::launch_copy_rows(ca, st);
+    ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, U); ca.y = e_x[0].ref(0); ca.T = R; if (R > 0) cnk::launch_copy_rows(ca, st);
+    ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, 0); ca.y = e_x[0].ref(R); ca.T = U; cnk::launch_copy_rows(ca, st);
   }
   int cur = 0;
   auto ln = [&](const TRef& x, const TRef& y, float* g, float* b, const TRef* pre) {
-    ck::LNArgs a; memset(&a, 0, sizeof(a));
+    cnk::LNArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.gamma = g; a.beta = b; a.slots = nullptr; a.pos = nullptr; a.lens = nullptr; a.T = Q; a.n = n; a.C = D; a.eps = 1e-5f;
     if (pre) { a.pre = *pre; a.has_pre = 1; }
-    ck::launch_layernorm(a, st);
+    cnk::launch_layernorm(a, st);
   };
   for (int l = 0; l < c.emf_layers; ++l) {
     const std::string nm = "emf." + std::to_string(l);
@@ -312,12 +325,12 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
     conv(mk(ctx->conv(nm + ".q"), e_ln.ref(), e_q.ref(), n, Q, nullptr), st);
     conv(mk(ctx->conv(nm + ".kv"), e_ln.ref(), e_kv.ref(), n, Q, nullptr), st);
     {
-      ck::EmfAttnArgs a; memset(&a, 0, sizeof(a));
+      cnk::EmfAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = e_q.base; a.kv = e_kv.base; a.out = e_att.base; a.kring = e_k[l].base; a.vring = e_v[l].base;
       a.ring_slot_stride = e_k[l].slot_stride; a.slots = d_slots; a.past = pos_emf;
       a.n = n; a.R = R; a.U = U; a.D = D; a.H = c.emf_heads; a.LC = c.emf_left_context; a.lmask = e_k[l].L - 1;
       a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
-      ck::launch_emf_attn(a, st);
+      cnk::launch_emf_attn(a, st);
     }
     {  // out_proj + residual with the un-normalised layer input
       ConvArgs a = mk(ctx->conv(nm + ".out"), e_att.ref(), e_r1.ref(), n, Q, nullptr);
@@ -325,24 +338,24 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       conv(a, st);
     }
     ln(e_r1.ref(), e_ffn.ref(), ctx->vec(nm + ".ln_ff.g"), ctx->vec(nm + ".ln_ff.b"), nullptr);
-    { ConvArgs a = mk(ctx->conv(nm + ".ff1"), e_ffn.ref(), e_h.ref(), n, Q, nullptr); a.out_act = ck::ACT_RELU; conv(a, st); }
+    { ConvArgs a = mk(ctx->conv(nm + ".ff1"), e_ffn.ref(), e_h.ref(), n, Q, nullptr); a.out_act = cnk::ACT_RELU; conv(a, st); }
     { ConvArgs a = mk(ctx->conv(nm + ".ff2"), e_h.ref(), e_r2.ref(), n, Q, nullptr); a.res = e_r1.ref(); a.has_res = 1; conv(a, st); }
     ln(e_r2.ref(), e_x[cur ^ 1].ref(), ctx->vec(nm + ".ln_out.g"), ctx->vec(nm + ".ln_out.b"), nullptr);
     cur ^= 1;
   }
   if (out) {
-    ck::CopyArgs ca; memset(&ca, 0, sizeof(ca));
+    cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.n = n; ca.C = D; ca.T = U; ca.x = e_x[cur].ref(R); ca.y = ch::lin_ref(out, U, D);
-    ck::launch_copy_rows(ca, st);
+    cnk::launch_copy_rows(ca, st);
   }
   if (logits || codes) {
     float* lg = logits ? logits : e_logits.base;
     const int K = c.emf_output_dim;
     if (c.emf_output_dim != D) conv(mk(ctx->conv("emf.proj"), e_x[cur].ref(R), ch::lin_ref(lg, U, K), n, U, nullptr), st);
-    else { ck::CopyArgs ca; memset(&ca, 0, sizeof(ca)); ca.n = n; ca.C = D; ca.T = U; ca.x = e_x[cur].ref(R); ca.y = ch::lin_ref(lg, U, D); ck::launch_copy_rows(ca, st); }
-    if (codes) { ck::ArgmaxArgs a; a.x = lg; a.idx = codes; a.rows = n * U; a.C = K; ck::launch_argmax(a, st); }
+    else { cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca)); ca.n = n; ca.C = D; ca.T = U; ca.x = e_x[cur].ref(R); ca.y = ch::lin_ref(lg, U, D); cnk::launch_copy_rows(ca, st); }
+    if (codes) { cnk::ArgmaxArgs a; a.x = lg; a.idx = codes; a.rows = n * U; a.C = K; cnk::launch_argmax(a, st); }
   }
-  ck::launch_advance(pos_emf, d_slots, n, U, st);
+  cnk::launch_advance(pos_emf, d_slots, n, U, st);
 }
 
 // ------------------------------------------------------------------------------------------------ conan decoder
@@ -366,6 +379,7 @@ void conan_streams::build_decoder() {
   c_kv = alloc((size_t)max_slots * 2 * S_max * 2 * H);
   c_kmask = alloc((size_t)max_slots * S_max);
   c_slen = (int*)alloc((size_t)max_slots);
+  c_vqids = (int*)alloc((size_t)max_slots * S_max);
   // style-pass workspace
   sp_batch = std::min(max_slots, 8);
   const int TR = max_ref + 2 * PADR, SR = S_max + 2 * PADR;

@@ -67,10 +67,10 @@ class StreamingVoiceConversionEngine:
     """The chunk loop of StreamingVoiceConversion.infer_once (inference/Conan.py:72-166) for many
     streams at once: mel in -> (wav, mel, codes) out, state carried in a conan_streams handle."""
 
-    def __init__(self, ctx, n_streams, max_ref_frames=256):
+    def __init__(self, ctx, n_streams, max_ref_frames=256, max_frames=None):
         self.ctx = ctx
         self.n = n_streams
-        self.st = ctx.streams(n_streams, max_frames=ctx.cfg.emf_segment, max_ref_frames=max_ref_frames)
+        self.st = ctx.streams(n_streams, max_frames=max(ctx.cfg.emf_segment, max_frames or 0), max_ref_frames=max_ref_frames)
         self.slots = list(range(n_streams))
         self.seg, self.rc = ctx.cfg.emf_segment, ctx.cfg.emf_right_context
 
@@ -92,6 +92,23 @@ class StreamingVoiceConversionEngine:
                 chunk = torch.cat([chunk, chunk[:, -1:].expand(B, need, F)], 1)
             yield pos, emit, chunk.contiguous()
             pos += emit
+
+    @torch.no_grad()
+    def windowed_step(self, chunk, ctx_codes, return_mel=False):
+        """One chunk in the bounded-window mode of BASELINE.json configs[1] / configs[4] ("80 ms chunk + 160 ms context",
+        "40 ms chunk / 320 ms context window"): the Emformer stays stateful (its left context is its own
+        K/V cache); the Conan decoder and the vocoder are reset and fed `ctx_codes` ([B, ctx] int32, the codes of the
+        preceding frames, possibly fewer at the start of an utterance) + this chunk's codes in one step; only the last
+        `seg` frames are kept.  The oracle of this mode is the reference module fed the same window.
+        Returns (codes [B, seg], wav [B, seg*hop]) (+ mel [B, seg, 80])."""
+        st, seg, hop = self.st, self.seg, self.ctx.hop
+        _, _, codes = st.emformer_step(self.slots, chunk, want_out=False, want_logits=False)
+        win = torch.cat([ctx_codes.to(codes.dtype), codes], 1) if ctx_codes is not None and ctx_codes.shape[1] else codes
+        st.reset(self.slots, which=2 | 4)
+        mel = st.decoder_step(self.slots, win)
+        wav = st.hifigan_step(self.slots, mel)
+        out = (codes, wav[:, -seg * hop:])
+        return out + (mel[:, -seg:],) if return_mel else out
 
     @torch.no_grad()
     def infer(self, src_mel, ref_mel, ref_len=None, pipelined=True):

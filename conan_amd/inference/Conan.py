@@ -11,27 +11,66 @@ from ..engine import StreamingVoiceConversionEngine
 from ..runtime import Context
 
 
+def state_dicts_from_checkpoints(hp: Dict):
+    """The three models exactly as inference/Conan.py:34-52 builds them: Conan(0, hp) + load_ckpt(work_dir, strict=False);
+    get_vocoder_cls(hp['vocoder'])() -> `{vocoder_ckpt}/config.yaml` + newest checkpoint's 'model_gen'
+    (tasks/tts/vocoder_infer/hifigan.py:13-20); EmformerDistillModel(hp, output_dim=100) + load_ckpt(emformer_ckpt,
+    strict=False).  Returns ({'emformer','conan','hifigan'} -> host state_dict, vocoder config).  Host-side only."""
+    from ..modules import _tree
+    from ..modules.Conan.Conan import Conan
+    from ..modules.Emformer.emformer import EmformerDistillModel
+    from ..modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
+    from ..tasks.tts.vocoder_infer import hifigan as _registers_hifigan  # noqa: F401  (@register_vocoder('HifiGAN'))
+    from ..tasks.tts.vocoder_infer.base_vocoder import get_vocoder_cls
+    from ..utils.commons.ckpt_utils import load_ckpt
+    from ..utils.commons.hparams import set_hparams
+    model = Conan(0, hp)
+    load_ckpt(model, hp["work_dir"], strict=False)
+    vocoder_cls = get_vocoder_cls(hp["vocoder"])
+    if vocoder_cls is None:
+        raise ValueError(f"Vocoder '{hp['vocoder']}' is not registered. Check vocoder name and registration.")
+    base_dir = hp["vocoder_ckpt"]
+    vocoder_hp = set_hparams(f"{base_dir}/config.yaml", global_hparams=False, print_hparams=False)
+    gen = HifiGanGenerator(vocoder_hp)
+    load_ckpt(gen, base_dir, "model_gen")
+    emformer = EmformerDistillModel(hp, output_dim=100)
+    load_ckpt(emformer, hp["emformer_ckpt"], strict=False)
+    sds = {"conan": _tree.host_state_dict(model), "hifigan": _tree.host_state_dict(gen), "emformer": _tree.host_state_dict(emformer)}
+    return sds, vocoder_hp
+
+
 class StreamingVoiceConversion:
     tokens_per_chunk: int = 4
 
     def __init__(self, hp: Dict, vocoder_hp: Dict = None, state_dicts: Dict = None, device: int = 0):
-        """hp: Conan/Emformer hparams (utils.commons.hparams.set_hparams('egs/conan_emformer.yaml'));
-        vocoder_hp: the vocoder's own config; state_dicts: {'emformer','conan','hifigan'} -> state_dict
-        (as extracted by utils.commons.ckpt_utils.extract_state_dict from the reference's checkpoints)."""
+        """StreamingVoiceConversion(hp) as the reference constructs it (inference/Conan.py:26-55): the models come from
+        hp['work_dir'] / hp['vocoder_ckpt'] / hp['emformer_ckpt'] through load_ckpt, then the vocoder is warmed with 4
+        zero frames (:54-55).  `vocoder_hp` / `state_dicts` ({'emformer','conan','hifigan'} -> state_dict) build the
+        same object from in-memory weights instead (no checkpoint files)."""
         if not torch.cuda.is_available():
             raise RuntimeError("StreamingVoiceConversion needs a HIP device (no CPU fallback)")
         self.hparams = hp
         self.device = f"cuda:{device}"
-        vocoder_hp = vocoder_hp or configs.hifigan_hparams()
         if hp.get("vocoder", "HifiGAN") != "HifiGAN":
             raise ValueError(f"Vocoder '{hp['vocoder']}' is not registered. Check vocoder name and registration.")
-        self.ctx = Context(hp, vocoder_hp, device)
         if state_dicts is None:
-            raise ValueError("state_dicts with 'emformer', 'conan' and 'hifigan' entries are required")
+            state_dicts, ckpt_vocoder_hp = state_dicts_from_checkpoints(hp)
+            vocoder_hp = vocoder_hp or ckpt_vocoder_hp
+        vocoder_hp = vocoder_hp or configs.hifigan_hparams()
+        self.ctx = Context(hp, vocoder_hp, device)
         for name in ("emformer", "conan", "hifigan"):
             self.ctx.load_state_dict(name, state_dicts[name])
         self.ctx.finalize()
         self.engine = None
+        self._vocoder_warm_zero()
+
+    def _vocoder_warm_zero(self):
+        """inference/Conan.py:54-55: one vocoder pass over 4 zero frames (first-launch costs); state is reset per utterance."""
+        st = self.ctx.streams(1, max_frames=4, max_ref_frames=4)
+        st.reset([0], which=4)
+        st.hifigan_step([0], torch.zeros(1, 4, self.ctx.cfg.num_mels, device=self.device))
+        torch.cuda.synchronize()
+        st.close()
 
     def _wav_to_mel(self, wav) -> torch.Tensor:
         """inference/Conan.py:57-70 on the GPU: path or float array -> clipped log-mel [T, 80] (cuda)."""

@@ -56,8 +56,11 @@ class Conan(_tree.ParamTree):
     def forward(self, content, spk_embed=None, target=None, ref=None, f0=None, uv=None, infer=False, global_steps=0, **kwargs):
         if spk_embed is None and ref is None:
             raise ValueError("When spk_embed is None, need target tensor to extract speaker embedding.")   # Conan.py:152-155
-        if spk_embed is not None or not infer:
-            raise NotImplementedError("the HIP hot path covers Conan.forward(ref=..., infer=True) (inference/Conan.py:132-141)")
+        if not infer:
+            raise NotImplementedError("the HIP hot path covers Conan.forward(..., infer=True) (inference/Conan.py:132-141)")
+        if ref is None:
+            # the reference reaches get_prosody(pitch_inp, ref, ...) with ref=None and fails there (Conan.py:166, style: true)
+            raise ValueError("ref is required: the prosody tokens are extracted from the reference mel (Conan.py:166)")
         if not content.is_cuda:
             raise RuntimeError("conan_amd.Conan runs on a HIP device only (no CPU fallback)")
         B, T = content.shape
@@ -66,6 +69,8 @@ class Conan(_tree.ParamTree):
         slots = list(range(B))
         st.reset(slots, which=2)
         st.set_reference(slots, ref.float().contiguous())
+        if spk_embed is not None:   # Conan.py:146-149: style_embed = spk_embed ([B,1,H]); the prosody still comes from ref
+            st.set_style(slots, spk_embed)
         codes = content.to(torch.int32).contiguous()
         mels, taps = [], {"uv_pred": [], "f0_denorm_pred": [], "pitch_bins": [], "decoder_inp": [], "content_embed_proj": []}
         attn = [[], []]

@@ -17,18 +17,23 @@ class EmformerState:
         self.streams, self.slots = streams, slots
 
 
-class _Proj:
-    """`.proj` of EmformerDistillModel (emformer.py:25).  The projection runs inside conan_emformer_step; calling
-    proj() on the tensor that infer() just returned hands back those logits."""
+def _linear(m, x):
+    return torch.nn.functional.linear(x, m.weight.to(x.device), m.bias.to(x.device))
 
-    def __init__(self, owner):
-        self.owner = owner
+
+class _Proj:
+    """`.proj` of EmformerDistillModel (emformer.py:25).  The projection runs inside conan_emformer_step: applied to
+    the very tensor infer() just returned (inference/Conan.py:115-120) it hands back those logits; any other input
+    (a slice, a concatenation of chunks) is projected with the module's own weight on the device."""
+
+    def __init__(self, owner, module):
+        self.owner, self.module = owner, module
 
     def __call__(self, x):
         last = self.owner._last
-        if last is None or x is not last[0]:
-            raise RuntimeError("proj() must be applied to the tensor returned by the preceding emformer.infer() call")
-        return last[1]
+        if last is not None and x is last[0]:
+            return last[1]
+        return _linear(self.module, x)
 
 
 class _Emformer:
@@ -71,13 +76,13 @@ class EmformerDistillModel(_tree.ParamTree):
         if self.mode == "both":
             # dual heads (emformer.py:28-30): the streaming step projects with proj1; proj / proj2 stay plain Linears
             # (torch on the device, off the hot path: only the distillation forward reads them)
-            self._modules["proj1"].forward = _Proj(self)
+            self._modules["proj1"].forward = _Proj(self, self._modules["proj1"])
             for name in ("proj", "proj2"):
                 if name in self._modules:
                     m = self._modules[name]
-                    m.forward = (lambda x, m=m: torch.nn.functional.linear(x, m.weight.to(x.device), m.bias.to(x.device)))
+                    m.forward = (lambda x, m=m: _linear(m, x))
         elif "proj" in self._modules:
-            self._modules["proj"].forward = _Proj(self)
+            self._modules["proj"].forward = _Proj(self, self._modules["proj"])
         self._last = None
         self._ctx = None
         self._streams = None
@@ -113,7 +118,8 @@ class EmformerDistillModel(_tree.ParamTree):
 
     @torch.inference_mode()
     def inference(self, mel_input):
-        """emformer.py:48-98: chunked streaming over mel_input[B, T, F] -> proj features [B, T, out_dim]."""
+        """emformer.py:48-98: chunked streaming over mel_input[B, T, F] -> proj(features) [B, T, out_dim], or the tuple
+        (proj1(features), proj2(features)) when mode == 'both' (emformer.py:95-97)."""
         B, T, F = mel_input.shape
         seg, rc = self.segment_length, self.right_context_len
         pos, state, outs = 0, None, []
@@ -127,9 +133,12 @@ class EmformerDistillModel(_tree.ParamTree):
                 chunk = torch.cat([chunk, chunk[:, -1:, :].expand(B, need, F)], dim=1)
             lengths = torch.full((B,), chunk.size(1), dtype=torch.long, device=mel_input.device)
             out, _, state = self.emformer.infer(chunk, lengths, state)
-            outs.append(self.proj(out)[:, :emit, :].clone())
+            outs.append(out[:, :emit, :].clone())
             pos += emit
-        return torch.cat(outs, dim=1)
+        streamed = torch.cat(outs, dim=1)
+        if self.mode == "both":
+            return self.proj1(streamed), self.proj2(streamed)
+        return self.proj(streamed)
 
     def forward(self, mel_input, lengths):
         raise NotImplementedError("non-streaming Emformer.forward (training) is outside the hot path")

@@ -116,9 +116,23 @@ class Streams:
     def state_bytes(self):
         return self.lib.conan_streams_state_bytes(self.h)
 
+    def _release(self):
+        """Buffers of pipelined steps may be dropped once the current torch stream waits for the library's internal
+        streams (every stream-ordered entry point joins them in C).  Those streams are invisible to torch's caching
+        allocator, so each buffer is first marked as in use on the current stream: its block then returns to the
+        pool only after work enqueued here - which sits behind the join - has completed."""
+        if self._keep:
+            cur = torch.cuda.current_stream()
+            for group in self._keep:
+                for t in group:
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
+            self._keep.clear()
+
     def reset(self, slots, which=7):
         a, p = _i32(slots)
         _lib.check(self.lib.conan_streams_reset(self.h, p, len(a), which, _stream()))
+        self._release()
 
     def set_reference(self, slots, ref_mel, ref_len=None):
         """ref_mel: cuda float32 [n, Tr, 80]."""
@@ -129,6 +143,7 @@ class Streams:
             ref_len = [tr] * n
         l, lp = _i32(ref_len)
         _lib.check(self.lib.conan_set_reference(self.h, p, len(a), _ptr(ref_mel), lp, tr, _stream()))
+        self._release()
 
     def emformer_step(self, slots, chunk, want_out=True, want_logits=True, want_codes=True):
         a, p = _i32(slots)
@@ -140,6 +155,7 @@ class Streams:
         logits = torch.empty(n, self.seg, c.emf_output_dim, device=self.dev) if want_logits else None
         codes = torch.empty(n, self.seg, dtype=torch.int32, device=self.dev) if want_codes else None
         _lib.check(self.lib.conan_emformer_step(self.h, p, n, _ptr(chunk), _ptr(out), _ptr(logits), _ptr(codes), _stream()))
+        self._release()
         return out, logits, codes
 
     def decoder_step(self, slots, codes, taps=False):
@@ -151,6 +167,7 @@ class Streams:
         mel = torch.empty(n, T, c.num_mels, device=self.dev)
         if not taps:
             _lib.check(self.lib.conan_decoder_step(self.h, p, n, T, _ptr(codes), _ptr(mel), None, None, None, None, _stream()))
+            self._release()
             return mel
         S = (self.max_ref_frames + 3) // 4 if self.max_ref_frames >= 4 else 1
         out = {"uv_pred": torch.empty(n, T, 2, device=self.dev), "f0_denorm_pred": torch.empty(n, T, device=self.dev),
@@ -163,6 +180,7 @@ class Streams:
         t.decoder_inp, t.content_embed_proj = out["decoder_inp"].data_ptr(), out["content_embed_proj"].data_ptr()
         t.attn[0], t.attn[1] = out["attn"][0].data_ptr(), out["attn"][1].data_ptr()
         _lib.check(self.lib.conan_decoder_step_taps(self.h, p, n, T, _ptr(codes), _ptr(mel), C.byref(t), _stream()))
+        self._release()
         return mel, out
 
     def style_embed(self, slots):
@@ -170,7 +188,48 @@ class Streams:
         a, p = _i32(slots)
         out = torch.empty(len(a), self.ctx.cfg.hidden_size, device=self.dev)
         _lib.check(self.lib.conan_get_style(self.h, p, len(a), _ptr(out), None, _stream()))
+        self._release()
         return out
+
+    def set_style(self, slots, style):
+        """Conan.forward(spk_embed=...): override the cached global style vector, style [n, H] (cuda)."""
+        a, p = _i32(slots)
+        style = style.to(self.dev, torch.float32).reshape(len(a), self.ctx.cfg.hidden_size).contiguous()
+        _lib.check(self.lib.conan_set_style(self.h, p, len(a), _ptr(style), _stream()))
+        self._release()
+
+    def prosody_ids(self, slots):
+        """VQ indices of the slots' prosody tokens: (ids int32 [n, max_tokens] (-1 padded), counts int32 [n])."""
+        a, p = _i32(slots)
+        S = (self.max_ref_frames + 3) // 4 if self.max_ref_frames >= 4 else 1
+        ids = torch.empty(len(a), S, dtype=torch.int32, device=self.dev)
+        cnt = torch.empty(len(a), dtype=torch.int32, device=self.dev)
+        _lib.check(self.lib.conan_get_prosody_ids(self.h, p, len(a), _ptr(ids), _ptr(cnt), _stream()))
+        self._release()
+        return ids, cnt
+
+    def hifigan_step_taps(self, slots, mel):
+        """hifigan_step plus the generator's intermediate tensors: (wav, pre_tanh, conv_pre_act [n,T,C0], [ups_i [n,T*rate_i,C_i]])."""
+        a, p = _i32(slots)
+        n = len(a)
+        c = self.ctx.cfg
+        mel = mel.to(self.dev, torch.float32).contiguous()
+        T = mel.shape[1]
+        hop = self.ctx.hop
+        wav = torch.empty(n, T * hop, device=self.dev)
+        pre = torch.empty(n, T * hop, device=self.dev)
+        cpre = torch.empty(n, T, c.voc_initial_channel, device=self.dev)
+        ups, ch_, rate = [], c.voc_initial_channel, 1
+        t = _lib.HifiganTaps()
+        t.conv_pre_act = cpre.data_ptr()
+        for i in range(c.voc_num_ups):
+            ch_ //= 2
+            rate *= c.voc_up_rates[i]
+            ups.append(torch.empty(n, T * rate, ch_, device=self.dev))
+            t.ups[i] = ups[-1].data_ptr()
+        _lib.check(self.lib.conan_hifigan_step_taps(self.h, p, n, T, _ptr(mel), _ptr(wav), _ptr(pre), C.byref(t), _stream()))
+        self._release()
+        return wav, pre, cpre, ups
 
     def hifigan_step(self, slots, mel, want_pre_tanh=False, out=None):
         """mel: cuda float32 [n, frames, 80] -> wav [n, frames*hop]."""
@@ -182,6 +241,7 @@ class Streams:
         wav = out if out is not None else torch.empty(n, T * hop, device=self.dev)
         pre = torch.empty(n, T * hop, device=self.dev) if want_pre_tanh else None
         _lib.check(self.lib.conan_hifigan_step(self.h, p, n, T, _ptr(mel), _ptr(wav), _ptr(pre), _stream()))
+        self._release()
         return (wav, pre) if want_pre_tanh else wav
 
     def step(self, slots, mel_chunk, emit=None, codes=None, mel_out=None, wav_out=None):
@@ -197,6 +257,7 @@ class Streams:
         if wav_out is None:
             wav_out = torch.empty(n, emit * hop, device=self.dev)
         _lib.check(self.lib.conan_step(self.h, p, n, emit, _ptr(mel_chunk), _ptr(codes), _ptr(mel_out), _ptr(wav_out), _stream()))
+        self._release()
         return codes, mel_out, wav_out
 
     def step_async(self, slots, mel_chunk, wav_out, emit=None, codes=None, mel_out=None):
@@ -214,7 +275,7 @@ class Streams:
     def join(self):
         """Make the current torch stream wait for every pipelined step enqueued so far."""
         _lib.check(self.lib.conan_streams_join(self.h, _stream()))
-        self._keep.clear()
+        self._release()
 
     def profile_begin(self):
         _lib.check(self.lib.conan_profile_begin(self.h))

@@ -27,8 +27,9 @@ def _load_chain(config_fn, loaded, chain):
     loaded.add(config_fn)
     out = {}
     if "base_config" in hp:
-        bases = hp["base_config"] if isinstance(hp["base_config"], list) else [hp["base_config"]]
-        for c in bases:
+        if not isinstance(hp["base_config"], list):
+            hp["base_config"] = [hp["base_config"]]     # kept as a list in the result, like hparams.py:60-61
+        for c in hp["base_config"]:
             if c.startswith("."):
                 c = os.path.normpath(f"{os.path.dirname(config_fn)}/{c}")
             if c not in loaded:

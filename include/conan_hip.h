@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 2
+#define CONAN_HIP_ABI_VERSION 3
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -77,6 +77,11 @@ typedef struct conan_cfg {
   /* vocoder config.yaml choices (hifigan_causal.py:287-303); 0 = the shipped egs/hifi_16k320_shuffle.yaml values */
   int32_t voc_upsample;           /* 0: 'shuffle' (CausalUpsampleBlock3), 1: 'zero' (CausalUpsampleBlock2); 'nn' is not streamable */
   int32_t voc_resblock;           /* 0 or 1: ResBlock1, 2: ResBlock2 */
+  /* torchaudio.models.Emformer(max_memory_size=, tanh_on_mem=): the memory bank.  modules/Emformer/emformer.py:14-22
+   * never passes them (0 / false), so shipped checkpoints run without a bank; > 0 enables the summary vector,
+   * the per-layer memory ring and the memory tokens in the attention (BASELINE.json north_star "memory-bank update") */
+  int32_t emf_max_memory_size;
+  int32_t emf_tanh_on_mem;
 } conan_cfg;
 
 #define CONAN_MODEL_EMFORMER 1
@@ -152,6 +157,15 @@ typedef struct conan_decoder_taps {
 } conan_decoder_taps;
 int conan_decoder_step_taps(conan_streams* s, const int32_t* slots, int n, int frames, const int32_t* codes_dev,
                             float* mel_out_dev, const conan_decoder_taps* taps, void* stream);
+/* Conan.forward(spk_embed=...) (modules/Conan/Conan.py:146-149): replace the cached global style vector of the slots
+ * by a caller-provided one, style_dev[n][H].  The prosody tokens still come from the reference mel
+ * (get_prosody(pitch_inp, ref, ...), Conan.py:166), so conan_set_reference must have run for the slots. */
+int conan_set_style(conan_streams* s, const int32_t* slots, int n, const float* style_dev, void* stream);
+/* VQ code indices of the slots' prosody tokens (VQEmbeddingEMA.encode argmin, prosody_util.py:34-46), cached by
+ * conan_set_reference: ids_dev[n][max_tokens] int32 (entries past the slot's token count are -1), count_dev[n] int32
+ * (may be NULL). */
+int conan_get_prosody_ids(conan_streams* s, const int32_t* slots, int n, int32_t* ids_dev, int32_t* count_dev, void* stream);
+
 /* style_embed of the slots' current reference (encode_spk_embed, Conan.py:200-219, cached by conan_set_reference):
  * style_dev[n][H].  max_tokens_out (may be NULL) receives the attn row width of conan_decoder_taps. */
 int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_dev, int32_t* max_tokens_out, void* stream);
@@ -161,6 +175,17 @@ int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_
  * pre_tanh_dev optional. */
 int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames, const float* mel_dev,
                        float* wav_out_dev, float* pre_tanh_dev, void* stream);
+
+/* conan_hifigan_step with optional taps of the generator's intermediate tensors (the forward hooks a reference
+ * maintainer would register on conv_pre / ups[i], hifigan_causal.py:319-322), channel-last; any pointer may be NULL.
+ *   conv_pre_act[n][frames][C0]             leaky_relu(conv_pre(mel), 0.1): the tensor ups[0] consumes
+ *   ups[i][n][frames*rate_i][C_i]           output of ups[i] after the pixel shuffle (rate_i = prod(up_rates[0..i])) */
+typedef struct conan_hifigan_taps {
+  float* conv_pre_act;
+  float* ups[CONAN_MAX_UPS];
+} conan_hifigan_taps;
+int conan_hifigan_step_taps(conan_streams* s, const int32_t* slots, int n, int frames, const float* mel_dev,
+                            float* wav_out_dev, float* pre_tanh_dev, const conan_hifigan_taps* taps, void* stream);
 
 /* Fused chunk step = one iteration of the loop inference/Conan.py:95-156 for n slots:
  * mel_chunk_dev[n][seg+rc][D] -> codes_dev[n][seg] (int32), mel_out_dev[n][seg][num_mels],

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_cfg_struct_matches_header_and_hparams():
     cfg = _lib.make_cfg(configs.conan_hparams(), configs.hifigan_hparams())
-    assert C.sizeof(cfg) == 4 * 79          # 79 int32 fields, include/conan_hip.h
+    assert C.sizeof(cfg) == 4 * 81          # 81 int32 fields, include/conan_hip.h
     assert cfg.voc_upsample == 0 and cfg.voc_resblock == 1
     z = _lib.make_cfg(None, configs.HIFIGAN_ZERO_RB2, emformer=False, conan=False)
     assert z.voc_upsample == 1 and z.voc_resblock == 2 and z.voc_rb_num_dil == 2
@@ -148,3 +148,71 @@ def test_wav_io_roundtrip_and_pad(tmp_path):
         save_wav(x, str(tmp_path / "a.mp3"), 16000)
     assert librosa_pad_lr(np.zeros(1000), 1024, 320, 1) == (0, 280)
     assert librosa_pad_lr(np.zeros(960), 1024, 320, 2) == (160, 160)
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("cfg,table", [("egs/conan_emformer.yaml", "CONAN_EMFORMER"), ("egs/hifi_16k320_shuffle.yaml", "HIFIGAN_16K320_SHUFFLE")])
+def test_set_hparams_equals_the_reference_parser_and_configs_py(cfg, table):
+    """conan_amd's yaml-chain parser against the reference's own utils/commons/hparams.py run in a subprocess on the
+    reference's egs/ files (key for key), and conan_amd/configs.py against those resolved chains."""
+    import json
+    import subprocess
+    import sys
+    code = ("import json,sys; sys.dont_write_bytecode=True\n"
+            "from utils.commons.hparams import set_hparams\n"
+            f"hp = set_hparams(config={cfg!r}, exp_name='', print_hparams=False, global_hparams=False)\n"
+            "print('JSON' + json.dumps(hp, sort_keys=True, default=str))\n")
+    env = dict(os.environ, PYTHONPATH=REFERENCE, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], cwd=REFERENCE, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ref = json.loads([l for l in out.stdout.splitlines() if l.startswith("JSON")][-1][4:])
+    from conan_amd.utils.commons import hparams as hpm
+    cwd = os.getcwd()
+    try:
+        os.chdir(REFERENCE)
+        ours = hpm.set_hparams(config=cfg, exp_name="", print_hparams=False, global_hparams=False)
+    finally:
+        os.chdir(cwd)
+    ours = json.loads(json.dumps(ours, sort_keys=True, default=str))
+    assert set(ours) == set(ref), (sorted(set(ours) ^ set(ref)))
+    for k in ref:
+        assert ours[k] == ref[k], k
+    # the hot-path tables in configs.py carry the resolved values of those chains
+    tab = getattr(configs, table)
+    skip = {"tiny", "emformer_input_dim", "emformer_output_dim", "emformer_mode", "content_embedding_dim", "num_mels", "profile_infer", "work_dir"}
+    for k, v in tab.items():
+        if k in skip or k not in ref:
+            continue
+        assert ref[k] == v or (isinstance(v, float) and abs(float(ref[k]) - v) < 1e-12), (k, ref[k], v)
+
+
+def test_state_dicts_from_checkpoints_like_the_reference_constructor(tmp_path):
+    """inference/Conan.py:34-52: Conan from hp['work_dir'] (newest model_ckpt_steps_*.ckpt, 'model'), the vocoder from
+    hp['vocoder_ckpt'] (config.yaml + 'model_gen'), the Emformer from hp['emformer_ckpt'] - host side, no GPU."""
+    from conan_amd.inference.Conan import state_dicts_from_checkpoints
+    chp, vhp = configs.conan_hparams(True), configs.hifigan_hparams(True)
+    sds = {"emformer": synth.emformer_state_dict(chp, 5), "conan": synth.conan_state_dict(chp, 5), "hifigan": synth.hifigan_state_dict(vhp, 5)}
+    t = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}  # noqa: E731
+    wd, vd, ed = tmp_path / "conan", tmp_path / "hifigan_vc", tmp_path / "emformer"
+    for d in (wd, vd, ed):
+        d.mkdir()
+    torch.save({"state_dict": {"model": t(sds["conan"])}}, str(wd / "model_ckpt_steps_200.ckpt"))
+    torch.save({"state_dict": {"model": {k: v * 0 for k, v in t(sds["conan"]).items()}}}, str(wd / "model_ckpt_steps_30.ckpt"))
+    torch.save({"state_dict": {"model_gen": t(sds["hifigan"]), "model_disc": {}}}, str(vd / "model_ckpt_steps_7.ckpt"))
+    (vd / "config.yaml").write_text(yaml.safe_dump(vhp))
+    torch.save({"state_dict": {"model": t(sds["emformer"])}}, str(ed / "model_ckpt_steps_9.ckpt"))
+    hp = dict(chp, work_dir=str(wd), vocoder_ckpt=str(vd), emformer_ckpt=str(ed))
+    got, got_vhp = state_dicts_from_checkpoints(hp)
+    assert got_vhp["upsample_rates"] == vhp["upsample_rates"] and got_vhp["upsample_initial_channel"] == vhp["upsample_initial_channel"]
+    for name in sds:
+        want = {k: v for k, v in sds[name].items() if np.asarray(v).dtype.kind == "f"}
+        assert set(want) <= set(got[name]), (name, sorted(set(want) - set(got[name]))[:5])
+        for k, v in want.items():
+            assert np.array_equal(np.asarray(v, dtype=np.float32), got[name][k]), (name, k)
+    with pytest.raises(AssertionError):
+        state_dicts_from_checkpoints(dict(hp, emformer_ckpt=str(tmp_path / "missing")))
+    with pytest.raises(ValueError):
+        state_dicts_from_checkpoints(dict(hp, vocoder="NoSuchVocoder"))

@@ -1,4 +1,4 @@
-// Micro-benchmark of ck::launch_conv on synthetic shapes (developer tool; not part of the product).
+// Micro-benchmark of cnk::launch_conv on synthetic shapes (developer tool; not part of the product).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I conan_amd/csrc tools/conv_bench.hip conan_amd/csrc/conv_mfma.hip -o gpurun_out/conv_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,33 +15,33 @@ struct Shape { const char* name; int n, T, Cin, Cout, k, dil, nprob, cfg; };
 int main(int argc, char** argv) {
   int ablate = argc > 1 ? atoi(argv[1]) : 0;
   std::vector<Shape> shapes = {
-    {"stage1 rb (B64: M=2048,C=256,k7)", 64, 32, 256, 256, 7, 3, 3, ck::CFG_64x64},
-    {"stage1 mixed k=3/7/11 64x64", 64, 32, 256, 256, -1, 3, 3, ck::CFG_64x64},
-    {"stage1 mixed k 64x64 KS64", 64, 32, 256, 256, -1, 3, 3, ck::CFG_64x64_KS64},
-    {"stage1 mixed k 32x64 K2", 64, 32, 256, 256, -1, 3, 3, ck::CFG_32x64_K2},
-    {"stage2 mixed k 64x64", 64, 160, 128, 128, -1, 3, 3, ck::CFG_64x64},
-    {"stage3 mixed k 64x64", 64, 640, 64, 64, -1, 3, 3, ck::CFG_64x64},
-    {"stage3 mixed k 128x64", 64, 640, 64, 64, -1, 3, 3, ck::CFG_128x64},
-    {"stage4 mixed k 128x32", 64, 1280, 32, 32, -1, 3, 3, ck::CFG_128x32},
-    {"stage2 rb (M=10240,C=128,k7)", 64, 160, 128, 128, 7, 3, 3, ck::CFG_128x64},
-    {"stage2 rb 64x64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_64x64},
-    {"stage2 rb 64x64 KS64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_64x64_KS64},
-    {"stage2 rb 128x64 KS64", 64, 160, 128, 128, 7, 3, 3, ck::CFG_128x64_KS64},
-    {"stage3 rb (M=40960,C=64,k7)", 64, 640, 64, 64, 7, 3, 3, ck::CFG_128x64},
-    {"stage3 rb 128x64 KS64", 64, 640, 64, 64, 7, 3, 3, ck::CFG_128x64_KS64},
-    {"stage3 rb 64x64 KS64", 64, 640, 64, 64, 7, 3, 3, ck::CFG_64x64_KS64},
-    {"stage4 rb (M=81920,C=32,k7)", 64, 1280, 32, 32, 7, 3, 3, ck::CFG_128x32},
-    {"stage4 rb 128x32 KS64... (Cin=32: n/a)", 64, 1280, 32, 32, 7, 3, 3, ck::CFG_128x32},
-    {"ups0 (M=256,Cin=512,N=2048,k16)", 64, 4, 512, 2048, 16, 1, 1, ck::CFG_64x64},
-    {"ups1 (M=2048,256->640,k10) 64x64", 64, 32, 256, 640, 10, 1, 1, ck::CFG_64x64},
-    {"ups1 64x64 KS64", 64, 32, 256, 640, 10, 1, 1, ck::CFG_64x64_KS64},
-    {"ups1 32x64 K2", 64, 32, 256, 640, 10, 1, 1, ck::CFG_32x64_K2},
-    {"ups2 (M=10240,128->256,k8) 64x64", 64, 160, 128, 256, 8, 1, 1, ck::CFG_64x64},
-    {"ups3 (M=40960,64->64,k4) 64x64", 64, 640, 64, 64, 4, 1, 1, ck::CFG_64x64},
-    {"stage4 mixed 64x32 K2", 64, 1280, 32, 32, -1, 3, 3, ck::CFG_64x32_K2},
-    {"ups0 32x64", 64, 4, 512, 2048, 16, 1, 1, ck::CFG_32x64_K2},
-    {"dec c1 (M=256,256->512,k5)", 64, 4, 256, 512, 5, 1, 1, ck::CFG_32x32_K4},
-    {"emf ff2 (M=384,2048->80)", 64, 6, 2048, 80, 1, 1, 1, ck::CFG_32x32_K4},
+    {"stage1 rb (B64: M=2048,C=256,k7)", 64, 32, 256, 256, 7, 3, 3, cnk::CFG_64x64},
+    {"stage1 mixed k=3/7/11 64x64", 64, 32, 256, 256, -1, 3, 3, cnk::CFG_64x64},
+    {"stage1 mixed k 64x64 KS64", 64, 32, 256, 256, -1, 3, 3, cnk::CFG_64x64_KS64},
+    {"stage1 mixed k 32x64 K2", 64, 32, 256, 256, -1, 3, 3, cnk::CFG_32x64_K2},
+    {"stage2 mixed k 64x64", 64, 160, 128, 128, -1, 3, 3, cnk::CFG_64x64},
+    {"stage3 mixed k 64x64", 64, 640, 64, 64, -1, 3, 3, cnk::CFG_64x64},
+    {"stage3 mixed k 128x64", 64, 640, 64, 64, -1, 3, 3, cnk::CFG_128x64},
+    {"stage4 mixed k 128x32", 64, 1280, 32, 32, -1, 3, 3, cnk::CFG_128x32},
+    {"stage2 rb (M=10240,C=128,k7)", 64, 160, 128, 128, 7, 3, 3, cnk::CFG_128x64},
+    {"stage2 rb 64x64", 64, 160, 128, 128, 7, 3, 3, cnk::CFG_64x64},
+    {"stage2 rb 64x64 KS64", 64, 160, 128, 128, 7, 3, 3, cnk::CFG_64x64_KS64},
+    {"stage2 rb 128x64 KS64", 64, 160, 128, 128, 7, 3, 3, cnk::CFG_128x64},
+    {"stage3 rb (M=40960,C=64,k7)", 64, 640, 64, 64, 7, 3, 3, cnk::CFG_128x64},
+    {"stage3 rb 128x64 KS64", 64, 640, 64, 64, 7, 3, 3, cnk::CFG_128x64},
+    {"stage3 rb 64x64 KS64", 64, 640, 64, 64, 7, 3, 3, cnk::CFG_64x64_KS64},
+    {"stage4 rb (M=81920,C=32,k7)", 64, 1280, 32, 32, 7, 3, 3, cnk::CFG_128x32},
+    {"stage4 rb 128x32 KS64... (Cin=32: n/a)", 64, 1280, 32, 32, 7, 3, 3, cnk::CFG_128x32},
+    {"ups0 (M=256,Cin=512,N=2048,k16)", 64, 4, 512, 2048, 16, 1, 1, cnk::CFG_64x64},
+    {"ups1 (M=2048,256->640,k10) 64x64", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_64x64},
+    {"ups1 64x64 KS64", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_64x64_KS64},
+    {"ups1 32x64 K2", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_32x64_K2},
+    {"ups2 (M=10240,128->256,k8) 64x64", 64, 160, 128, 256, 8, 1, 1, cnk::CFG_64x64},
+    {"ups3 (M=40960,64->64,k4) 64x64", 64, 640, 64, 64, 4, 1, 1, cnk::CFG_64x64},
+    {"stage4 mixed 64x32 K2", 64, 1280, 32, 32, -1, 3, 3, cnk::CFG_64x32_K2},
+    {"ups0 32x64", 64, 4, 512, 2048, 16, 1, 1, cnk::CFG_32x64_K2},
+    {"dec c1 (M=256,256->512,k5)", 64, 4, 256, 512, 5, 1, 1, cnk::CFG_32x32_K4},
+    {"emf ff2 (M=384,2048->80)", 64, 6, 2048, 80, 1, 1, 1, cnk::CFG_32x32_K4},
   };
   int nslots = 64;
   for (auto& s : shapes) {
@@ -65,26 +65,26 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&slots, nslots * 4)); CHECK(hipMalloc(&pos, nslots * 4));
     std::vector<int> hs(nslots); for (int i = 0; i < nslots; ++i) hs[i] = i;
     CHECK(hipMemcpy(slots, hs.data(), nslots * 4, hipMemcpyHostToDevice)); CHECK(hipMemset(pos, 0, nslots * 4));
-    ck::ConvGroup g; memset(&g, 0, sizeof(g));
+    cnk::ConvGroup g; memset(&g, 0, sizeof(g));
     for (int p = 0; p < s.nprob; ++p) {
-      ck::ConvArgs& a = g.p[p];
-      ck::TRef xr; xr.base = x + p * xfl; xr.slot_stride = (long long)Lr * s.Cin; xr.C = s.Cin; xr.lmask = Lr - 1; xr.rate = 1; xr.off = 0; xr.mode = 0; xr.pad_ = 0;
-      ck::TRef yr = xr; yr.base = y + p * yfl; yr.slot_stride = (long long)Lr * s.Cout; yr.C = s.Cout;
-      a.x[0] = a.x[1] = a.x[2] = xr; a.nsrc = 1; a.y = yr; a.res = xr; a.has_res = (s.Cin == s.Cout);
+      cnk::ConvArgs& a = g.p[p];
+      cnk::TRef xr; xr.base = x + p * xfl; xr.slot_stride = (long long)Lr * s.Cin; xr.C = s.Cin; xr.lmask = Lr - 1; xr.rate = 1; xr.off = 0; xr.mode = 0; xr.pad_ = 0;
+      cnk::TRef yr = xr; yr.base = y + p * yfl; yr.slot_stride = (long long)Lr * s.Cout; yr.C = s.Cout;
+      a.x = xr; a.y = yr; a.res = xr; a.has_res = (s.Cin == s.Cout);
       a.w = w + p * wfl; a.bias = b; a.slots = slots; a.pos = pos;
       a.Cin = s.Cin; a.Cin_pad = Cin_pad; a.Cin_alloc = Cin_alloc; a.Cout = s.Cout; a.Cout_pad = Cout_pad; const int kk = s.k < 0 ? (p == 0 ? 3 : (p == 1 ? 7 : 11)) : s.k;
       a.ktaps = kk; a.dil = s.dil; a.pad_left = (kk - 1) * s.dil;
-      a.T = s.T; a.n = s.n; a.in_act = getenv("CB_INACT") ? ck::ACT_LRELU : ck::ACT_NONE; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1;
+      a.T = s.T; a.n = s.n; a.in_act = getenv("CB_INACT") ? cnk::ACT_LRELU : cnk::ACT_NONE; a.in_slope = 0.1f; a.out_scale = 1.f; a.shuffle_r = 1;
 #ifdef CK_STAMPS
       a.dbg = dbg;
 #endif
     }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int it = 0; it < 3; ++it) ck::launch_conv(g, s.nprob, s.cfg, 0);
+    for (int it = 0; it < 3; ++it) cnk::launch_conv(g, s.nprob, s.cfg, 0);
     CHECK(hipDeviceSynchronize());
     const int iters = 20;
     CHECK(hipEventRecord(e0, 0));
-    for (int it = 0; it < iters; ++it) ck::launch_conv(g, s.nprob, s.cfg, 0);
+    for (int it = 0; it < iters; ++it) cnk::launch_conv(g, s.nprob, s.cfg, 0);
     CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
     double fl = 2.0 * s.n * s.T * (double)s.Cout * (s.k < 0 ? 21.0 / 3.0 : (double)s.k) * s.Cin * s.nprob;

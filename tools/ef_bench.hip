@@ -16,9 +16,9 @@ static float* dev(size_t n, float scale) {
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, past0 = argc > 2 ? atoi(argv[2]) : 100;
   const int D = 80, F = 2048, L = 6, R = 2, U = 4, H = 8, LC = 50, K = 100, LR = 64;
-  ck::EmfFusedArgs a; memset(&a, 0, sizeof(a));
+  cnk::EmfFusedArgs a; memset(&a, 0, sizeof(a));
   for (int l = 0; l < L; ++l) {
-    ck::EmfLayerW& w = a.layers[l];
+    cnk::EmfLayerW& w = a.layers[l];
     w.wqkv = dev((size_t)3 * D * D, 0.2f); w.wo = dev((size_t)D * D, 0.2f); w.w1 = dev((size_t)D * F, 0.2f); w.w2 = dev((size_t)D * F, 0.2f);
     w.params = dev(11 * D + F, 0.5f);
     a.kring[l] = dev((size_t)B * LR * D, 1.f); a.vring[l] = dev((size_t)B * LR * D, 1.f);
@@ -38,14 +38,14 @@ int main(int argc, char** argv) {
 #ifdef EF_STAMPS
   hipMalloc(&a.dbg, 64 * 8); hipMemset(a.dbg, 0, 64 * 8);
 #endif
-  if (!ck::emformer_fused_supported(a)) { printf("unsupported\n"); return 1; }
+  if (!cnk::emformer_fused_supported(a)) { printf("unsupported\n"); return 1; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int it = 0; it < 5; ++it) { hipMemcpy(dp, hp.data(), B * 4, hipMemcpyHostToDevice); ck::launch_emformer_fused(a, 0); }
+  for (int it = 0; it < 5; ++it) { hipMemcpy(dp, hp.data(), B * 4, hipMemcpyHostToDevice); cnk::launch_emformer_fused(a, 0); }
   hipDeviceSynchronize();
   float best = 1e9f;
   for (int it = 0; it < 20; ++it) {
     hipMemcpy(dp, hp.data(), B * 4, hipMemcpyHostToDevice);
-    hipEventRecord(e0, 0); ck::launch_emformer_fused(a, 0); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    hipEventRecord(e0, 0); cnk::launch_emformer_fused(a, 0); hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }
   printf("B=%d past=%d  kernel %.1f us (hipGetLastError=%d)\n", B, past0, best * 1e3f, (int)hipGetLastError());
