@@ -28,19 +28,33 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 N_FRAMES, N_REF = 151, 151     # 3 s source + 3 s reference at 50 frames/s
+# algorithmic work per chunk per stream (stateful, seg = 4) and bytes per step
+GFLOP_PER_FRAME = 2.63 / 4     # vocoder 315.85 + Conan 9.6 MMAC per frame + Emformer 13.07 MMAC per chunk
+WEIGHT_BYTES_PER_STEP = 168e6  # vocoder 119.8 MB + Conan per-chunk subset 39 MB + Emformer 8.6 MB, read once per step
+STATE_BYTES_PER_STREAM = 1.2e6  # state read+write + I/O per stream per step
 
+# BASELINE.json configs -> bench workloads.  `window` = context frames of the windowed mode
+# (Conan decoder + vocoder reset and fed window + chunk frames per step; the Emformer stays stateful), 0 = stateful.
 WORKLOADS = {
-    "b64": dict(streams=64, desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full "
-                                 "Emformer->Conan->HiFi-GAN pipeline"),
-    "b1": dict(streams=1, desc="batch=1 stream, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
+    "b64": dict(streams=64, chunk_ms=80, window=0, config="BASELINE.json configs[2] (x8 GPUs = configs[3])",
+                desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
+    "b1": dict(streams=1, chunk_ms=80, window=0, config="BASELINE.json configs[1], stateful mode",
+               desc="batch=1 stream, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
+    "b1win": dict(streams=1, chunk_ms=80, window=8, config="BASELINE.json configs[1], 160 ms context window",
+                  desc="batch=1 stream, 80 ms chunk + 160 ms context: Conan/vocoder reset + 12 frames per step, Emformer stateful"),
+    "b128s2": dict(streams=128, chunk_ms=40, window=0, config="BASELINE.json configs[4], stateful mode",
+                   desc="batch=128 streams, 40 ms chunk (seg 2 + rc 2 frames), stateful full pipeline"),
+    "b128s2win": dict(streams=128, chunk_ms=40, window=16, config="BASELINE.json configs[4], 320 ms context window",
+                      desc="batch=128 streams, 40 ms chunk + 320 ms context: Conan/vocoder reset + 18 frames per step, Emformer stateful"),
 }
 
 
-def build_context(device):
+def build_context(device, chunk_ms=80):
     from conan_amd import configs, synth
     from conan_amd.runtime import Context
-    chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
+    chp, vhp = dict(configs.conan_hparams(), chunk_size=chunk_ms), configs.hifigan_hparams()
     ctx = Context(chp, vhp, device)
     ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0))
     ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
@@ -49,11 +63,11 @@ def build_context(device):
     return ctx, chp, vhp
 
 
-def make_engine(ctx, B, first_stream):
+def make_engine(ctx, B, first_stream, window=0):
     """B streams with their reference set and every full chunk of the 3 s utterance staged in HBM."""
     from conan_amd import synth
     from conan_amd.engine import StreamingVoiceConversionEngine
-    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1)
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1, max_frames=window + ctx.cfg.emf_segment if window else None)
     src = np.concatenate([synth.mel(N_FRAMES, 1234 + first_stream + s) for s in range(B)])
     ref = np.concatenate([synth.mel(N_REF, 4321 + first_stream + s) for s in range(B)])
     src = torch.from_numpy(src).cuda()
@@ -62,22 +76,33 @@ def make_engine(ctx, B, first_stream):
     return eng, chunks
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle's reference-semantics loop (inference/Conan.py:95-156: prefix re-run of Conan and the
-    vocoder every chunk, numpy hops) timed on the host cores, B=1, on a time-bounded prefix of the same
-    3 s utterance; plus the stateful CPU variant (same arithmetic the GPU path performs)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """BASELINE.md §3 / SURVEY.md §8(d) Config 1: the oracle's loop on the host cores, B = 1, same synthetic 3 s
+    utterance, two variants - reference semantics (inference/Conan.py:95-156: prefix re-run of Conan incl. the style
+    encoders and of the vocoder every chunk, numpy hops) and stateful (the arithmetic the GPU path performs) - at the
+    host's best thread count ("all-core": PyTorch's CPU convolutions collapse when over-threaded on a 256-thread
+    host, so a short probe picks among 8/16/32/64/all) and at 1 thread.  One warm-up + timed runs, median.  The samples
+    are bounded so that the default bench run stays within minutes; each entry says what it covered."""
     from conan_amd import configs, synth
     from oracle import emformer as oemf
+    from oracle import hifigan as ohifi
     from oracle import loop as oloop
     from oracle.common import to_torch_sd
-    from oracle import hifigan as ohifi
     chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
     esd = to_torch_sd(synth.emformer_state_dict(chp, 0))
     csd = to_torch_sd(synth.conan_state_dict(chp, 0))
     vsd = to_torch_sd(synth.hifigan_state_dict(vhp, 0))
     cfg = oemf.EmformerCfg(chp)
-    # PyTorch's CPU conv path degrades badly when heavily over-threaded on a many-core host: pick the
-    # fastest thread count for this workload (vocoder forward on 16 frames) among a few candidates.
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -94,37 +119,51 @@ def cpu_baseline(budget_s=20.0):
             best_t, best_dt = nt, dtp
         if dtp > 5.0:
             break
-    torch.set_num_threads(best_t)
     src, ref = synth.mel(N_FRAMES, 1234)[0], synth.mel(N_REF, 4321)[0]
+    seg = cfg.segment_length
 
-    class Stop(Exception):
-        pass
+    def run(fn, n_chunks, runs, warm_chunks):
+        """-> (median chunks/s over `runs` passes of the first n_chunks chunks, p50 ms, p95 ms of the per-chunk times)"""
+        def once(k):
+            stamps = [time.perf_counter()]
+            fn(esd, cfg, csd, chp, vsd, vhp, src[:k * seg + (2 if k * seg + 2 <= len(src) else 0)], ref, on_chunk=lambda: stamps.append(time.perf_counter()))
+            lat = [b - a for a, b in zip(stamps[:-1], stamps[1:])][:k]
+            return k / sum(lat), lat
+        once(warm_chunks)
+        rates, lats = [], []
+        for _ in range(runs):
+            r, l = once(n_chunks)
+            rates.append(r); lats += l
+        lats.sort()
+        return statistics.median(rates), lats[len(lats) // 2] * 1e3, lats[min(len(lats) - 1, int(len(lats) * 0.95))] * 1e3
 
-    def run(fn, budget):
-        stamps = [time.perf_counter()]
+    out = {"unit": "chunks/s", "kind": "port", "cpu_model": cpu_model(), "host_threads_available": avail}
+    torch.set_num_threads(best_t)
+    v, p50, p95 = run(oloop.infer_once_ref, 37, 3, 6)
+    out.update({"value": v, "cores": best_t, "p50_ms": p50, "p95_ms": p95})
+    sv, sp50, sp95 = run(oloop.infer_once_stateful, 37, 5, 6)
+    out.update({"stateful_value": sv, "stateful_p50_ms": sp50, "stateful_p95_ms": sp95})
+    torch.set_num_threads(1)
+    v1, p1, _ = run(oloop.infer_once_ref, 6, 1, 2)
+    s1, sp1, _ = run(oloop.infer_once_stateful, 8, 3, 2)
+    out["one_thread"] = {"cores": 1, "value": v1, "p50_ms": p1, "stateful_value": s1, "stateful_p50_ms": sp1,
+                         "sample": "ref-semantics: 1 pass over the first 6 chunks (cost grows with the prefix: later chunks are slower); "
+                                   "stateful: median of 3 passes over the first 8 chunks"}
+    torch.set_num_threads(best_t)
+    out["sample"] = (f"oracle loop, B=1, the 3 s utterance (37 full 80 ms chunks), {best_t} threads (probe-chosen of {avail}): reference semantics "
+                     "(prefix re-run per chunk, inference/Conan.py:95-156) median of 3 passes after a 6-chunk warm-up = `value`; stateful "
+                     "variant median of 5 passes; 1-thread figures in `one_thread`")
+    return out
 
-        def tick():
-            stamps.append(time.perf_counter())
-            if stamps[-1] - stamps[0] > budget:
-                raise Stop()
-        try:
-            fn(esd, cfg, csd, chp, vsd, vhp, src, ref, on_chunk=tick)
-        except Stop:
-            pass
-        n = len(stamps) - 1
-        dt = stamps[-1] - stamps[0]
-        lat = sorted(b - a for a, b in zip(stamps[:-1], stamps[1:]))
-        return n, dt, (lat[len(lat) // 2] if lat else float("nan"))
 
-    n_ref, t_ref, p50_ref = run(oloop.infer_once_ref, budget_s * 0.7)
-    n_st, t_st, p50_st = run(oloop.infer_once_stateful, budget_s * 0.3)
-    return {
-        "value": n_ref / t_ref, "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"oracle ref-semantics loop (prefix re-run per chunk, inference/Conan.py:95-156), B=1, first {n_ref} of 38 "
-                  f"chunks of the 3 s utterance in {t_ref:.1f} s; stateful CPU variant over {n_st} chunks",
-        "p50_ms": p50_ref * 1e3,
-        "stateful_value": n_st / t_st, "stateful_p50_ms": p50_st * 1e3,
-    }
+def pmc_summary(tag):
+    """The committed summary of the separate rocprofv3 --pmc passes for this workload (PMC counters cannot be collected
+    from inside the benchmark): profiles/r2_<tag>_pmc.json, made by tools/collect_profiles.sh + tools/summarize_pmc.py."""
+    path = os.path.join(REPO, "profiles", f"r2_{tag}_pmc.json")
+    try:
+        return json.load(open(path)), f"profiles/r2_{tag}_pmc.json"
+    except (OSError, ValueError):
+        return None, None
 
 
 def main():
@@ -136,7 +175,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-steps", type=int, default=40)
-    ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency leg (keeps profiler summaries B=64 only)")
+    ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency leg (keeps profiler summaries to one workload)")
+    ap.add_argument("--marks", action="store_true", help="bracket the timed steps with cnk::profile_mark_kernel dispatches and skip "
+                                                         "every other leg (rocprofv3 --pmc passes: tools/summarize_pmc.py keeps the dispatches between the marks)")
     args = ap.parse_args()
 
     from conan_amd.engine import gather_audio_equal, init_distributed
@@ -147,19 +188,22 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
-    B = args.streams or WORKLOADS[args.workload]["streams"]
+    wl = WORKLOADS[args.workload]
+    B = args.streams or wl["streams"]
+    window = wl["window"]
 
-    ctx, chp, vhp = build_context(local)
-    eng, chunks = make_engine(ctx, B, first_stream=rank * B)
+    ctx, chp, vhp = build_context(local, wl["chunk_ms"])
+    eng, chunks = make_engine(ctx, B, first_stream=rank * B, window=window)
     hop, seg = ctx.hop, eng.seg
     codes = torch.empty(B, seg, dtype=torch.int32, device="cuda")
     mel_out = torch.empty(B, seg, 80, device="cuda")
     wav = torch.empty(B, seg * hop, device="cuda")
     gbufs = [torch.empty_like(wav) for _ in range(world)] if (world > 1 and rank == 0) else None
 
-    # Throughput leg: pipelined steps (conan_step_async) - the front-end of chunk t+1 overlaps the vocoder of chunk t on
-    # the library's two internal HIP streams.  Audio goes to a small ring of buffers; with more than one rank the RCCL
-    # gather of chunk t runs on its own stream so that it does not serialise the pipeline either.
+    # Throughput leg, stateful workloads: pipelined steps (conan_step_async) - the front-end of chunk t+1 overlaps the
+    # vocoder of chunk t on the library's two internal HIP streams.  Audio goes to a small ring of buffers; with more
+    # than one rank the RCCL gather of chunk t runs on its own stream so that it does not serialise the pipeline either.
+    # Windowed workloads: one blocking windowed step (Emformer step, reset, decoder + vocoder over window + chunk frames).
     NB = 4
     wavs = [torch.empty_like(wav) for _ in range(NB)]
     # CONAN_BENCH_COMM=1 exercises the gather stream / event choreography on a single rank (the gather itself is a
@@ -167,20 +211,30 @@ def main():
     use_comm = world > 1 or os.environ.get("CONAN_BENCH_COMM", "0") == "1"
     comm = torch.cuda.Stream() if use_comm else None
     gdone = [torch.cuda.Event() for _ in range(NB)] if use_comm else None
+    hist = [torch.randint(0, 100, (B, window), dtype=torch.int32, device="cuda")] if window else None
 
     def step(j):
         k = j % NB
         if use_comm and j >= NB:
             torch.cuda.current_stream().wait_event(gdone[k])      # the gather that read this buffer has finished
-        eng.st.step_async(eng.slots, chunks[j % len(chunks)], wavs[k], emit=seg, codes=codes, mel_out=mel_out)
+        if window:
+            c, w = eng.windowed_step(chunks[j % len(chunks)], hist[0])
+            hist[0] = torch.cat([hist[0][:, seg:], c], 1)
+            wavs[k].copy_(w)
+        else:
+            eng.st.step_async(eng.slots, chunks[j % len(chunks)], wavs[k], emit=seg, codes=codes, mel_out=mel_out)
         if use_comm:
             with torch.cuda.stream(comm):
-                eng.st.join()
+                if window:
+                    comm.wait_stream(torch.cuda.default_stream())
+                else:
+                    eng.st.join()
                 gather_audio_equal(wavs[k], world, rank, gbufs)
                 gdone[k].record(comm)
 
     def barrier():
-        eng.st.join()
+        if not window:
+            eng.st.join()
         if use_comm:
             comm.synchronize()
         if world > 1:
@@ -191,63 +245,80 @@ def main():
     for _ in range(args.warmup):
         step(j); j += 1
     barrier()
+    if args.marks:
+        eng.st.profile_mark()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(j); j += 1
     barrier()
     dt = time.perf_counter() - t0
+    if args.marks:
+        eng.st.profile_mark()
+        torch.cuda.synchronize()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    ms_step = dt / args.steps * 1e3
+    frames_per_step = (window + seg) if window else seg           # decoder / vocoder frames computed per stream per step
 
-    # per-chunk latency: one step for all B streams, host submit -> audio complete on device
-    lats = []
-    for _ in range(args.latency_steps):
-        torch.cuda.synchronize()
-        a = time.perf_counter()
-        eng.st.step(eng.slots, chunks[j % len(chunks)], emit=seg, codes=codes, mel_out=mel_out, wav_out=wav); j += 1
-        torch.cuda.synchronize()
-        lats.append((time.perf_counter() - a) * 1e3)
-    p50 = statistics.median(lats)
+    def one_blocking_step(e, ch, c_, m_, w_, h_):
+        if window:
+            cc, ww = e.windowed_step(ch, h_[0])
+            h_[0] = torch.cat([h_[0][:, seg:], cc], 1)
+        else:
+            e.st.step(e.slots, ch, emit=seg, codes=c_, mel_out=m_, wav_out=w_)
 
-    # roofline of the dominant kernel family (conv_mfma): HIP events around every launch on its stream
-    roof = None
-    b1 = None
-    cpu = None
-    fe = None
-    if rank == 0:
+    roof = b1 = cpu = fe = None
+    p50 = None
+    if not args.marks:
+        # per-chunk latency: one step for all B streams, host submit -> audio complete on device
+        lats = []
+        for _ in range(args.latency_steps):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            one_blocking_step(eng, chunks[j % len(chunks)], codes, mel_out, wav, hist); j += 1
+            torch.cuda.synchronize()
+            lats.append((time.perf_counter() - a) * 1e3)
+        p50 = statistics.median(lats)
+
+    if rank == 0 and not args.marks:
+        # roofline of the dominant kernel: HIP events around every launch of the matrix kernels on their stream
         nprof = 5
         torch.cuda.synchronize()
         eng.st.profile_begin()
         for _ in range(nprof):
-            eng.st.step(eng.slots, chunks[j % len(chunks)], emit=seg, codes=codes, mel_out=mel_out, wav_out=wav); j += 1
+            one_blocking_step(eng, chunks[j % len(chunks)], codes, mel_out, wav, hist); j += 1
         conv_ms, conv_flops, conv_launches = eng.st.profile_end()
-        # the dominant kernel = the template instantiation with the largest summed time (the vocoder's streaming tiles)
+        # the dominant kernel = the instantiation with the largest summed time
         name, k_ms, k_fl, k_n = max(eng.st.profile_kernels(), key=lambda r: r[1])
         ach = k_fl / (k_ms * 1e-3) / 1e12
         fam = conv_flops / (conv_ms * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the benchmark, so the figure
-        # comes from the committed summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_b64_pmc_hbm.json")
-        if os.path.exists(pmc):
-            try:
-                kern = json.load(open(pmc))["kernels"]
-                hit = [v for k, v in kern.items() if name in k]
-                if hit:
-                    traffic = hit[0]["fetch"] + hit[0]["write"]
-                    traffic_src = "profiles/r1_b64_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
-            except (OSError, ValueError, KeyError):
-                pass
+        pmc, pmc_src = pmc_summary(args.workload)
+        traffic = step_bytes = mfma_busy = None
+        if pmc:
+            hit = [v for k, v in pmc.get("kernels", {}).items() if name in k]
+            if hit:
+                traffic = hit[0]["fetch"] + hit[0]["write"]
+                mfma_busy = hit[0].get("mfma_busy_frac")
+            step_bytes = pmc.get("bytes_per_step")
+        flops_step = B * frames_per_step * GFLOP_PER_FRAME * 1e9
+        bytes_alg = WEIGHT_BYTES_PER_STEP + B * STATE_BYTES_PER_STREAM * (frames_per_step / seg)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+                "mfma_busy_frac_pmc": mfma_busy,
                 "kernel": name, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
-                "gflop_per_launch": k_fl / k_n / 1e9, "share_of_step_time": (k_ms / nprof) / (dt / args.steps * 1e3),
-                "all_conv_kernels": {"achieved": fam, "frac": fam / PEAK_F32_MFMA_TFLOPS, "launches_per_step": conv_launches / nprof,
-                                     "ms_per_step": conv_ms / nprof, "gflop_per_chunk_per_stream": conv_flops / nprof / B / 1e9}}
+                "gflop_per_launch": k_fl / k_n / 1e9, "share_of_step_time": (k_ms / nprof) / ms_step,
+                "all_matrix_kernels": {"achieved": fam, "frac": fam / PEAK_F32_MFMA_TFLOPS, "launches_per_step": conv_launches / nprof,
+                                       "ms_per_step": conv_ms / nprof, "gflop_per_frame_per_stream": conv_flops / nprof / B / frames_per_step / 1e9},
+                # the whole step against both rooflines (report both, the binding one is the larger fraction)
+                "step": {"gflop_algorithmic": flops_step / 1e9, "tflops": flops_step / (ms_step * 1e-3) / 1e12,
+                         "mfma_frac": flops_step / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                "hbm": {"bytes_algorithmic": bytes_alg, "bytes_counter": step_bytes, "source": pmc_src if step_bytes is not None else None,
+                        "GB/s": bytes_alg / (ms_step * 1e-3) / 1e9, "frac": bytes_alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "counter_GB/s": (step_bytes / (ms_step * 1e-3) / 1e9) if step_bytes else None, "peak": PEAK_HBM_GBS}}
         # batch=1 latency configuration (BASELINE.json configs[1]) beside the throughput one
-        if B != 1 and not args.no_b1:
+        if args.workload == "b64" and not args.streams and not args.no_b1:
             e1, ch1 = make_engine(ctx, 1, first_stream=100000)
             c1 = torch.empty(1, seg, dtype=torch.int32, device="cuda")
             m1 = torch.empty(1, seg, 80, device="cuda")
@@ -264,7 +335,6 @@ def main():
                   "chunks_per_s": 1e3 / statistics.median(l1)}
             e1.st.close()
         # the step before the path: GPU mel front-end rate for B x 3 s of audio (not part of `value`)
-        fe = None
         try:
             w = torch.rand(B, 48000, device="cuda") * 2 - 1
             ctx.wav2mel(w)
@@ -285,17 +355,19 @@ def main():
     if rank == 0:
         total_chunks = world * B * args.steps
         out = {
-            "metric": "chunks/sec (80 ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it",
+            "metric": "chunks/sec (%d ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it" % wl["chunk_ms"],
             "value": total_chunks / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload]["desc"] if not args.streams else f"batch={B} streams per GPU, 80 ms chunk, stateful",
-                       "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": 80, "sample_rate": 16000,
+            "config": {"workload": wl["desc"] if not args.streams else f"batch={B} streams per GPU, {wl['chunk_ms']} ms chunk" + (", windowed" if window else ", stateful"),
+                       "name": args.workload, "baseline_config": wl["config"],
+                       "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
                        "architecture": "egs/conan_emformer.yaml + egs/hifi_16k320_shuffle.yaml shapes, random-init weights",
                        "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1"},
             "p50_latency_ms": p50,
-            "schedule": "throughput: pipelined steps (front-end of chunk t+1 overlaps the vocoder of chunk t on two HIP streams); latency: one blocking fused step",
-            "realtime_streams_supported": (total_chunks / dt) / 12.5,
+            "schedule": ("throughput and latency: one blocking windowed step" if window else
+                         "throughput: pipelined steps (front-end of chunk t+1 overlaps the vocoder of chunk t on two HIP streams); latency: one blocking fused step"),
+            "realtime_streams_supported": (total_chunks / dt) / (1000.0 / wl["chunk_ms"]),
             "roofline": roof, "cpu_baseline": cpu,
         }
         if b1 is not None:

@@ -418,6 +418,14 @@ int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, 
   return rc != CONAN_OK ? rc : found;
 }
 
+int conan_profile_mark(conan_streams* s, void* stream) {
+  return guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    cnk::launch_profile_mark((hipStream_t)stream);
+  });
+}
+
 int conan_hop_size(const conan_ctx* ctx) { return ctx ? ctx->hop : 0; }
 int64_t conan_ctx_weight_bytes(const conan_ctx* ctx) { return ctx ? ctx->weight_bytes : 0; }
 int64_t conan_streams_state_bytes(const conan_streams* s) { return s ? s->state_bytes : 0; }

@@ -203,6 +203,7 @@ void launch_argmax(const ArgmaxArgs& a, hipStream_t st);
 void launch_advance(int* pos, const int* slots, int n, int delta, hipStream_t st);
 void launch_fill_int(int* p, const int* slots, int n, int value, hipStream_t st);
 void launch_copy_int_rows(int* dst, const int* src, int n, int T, int S, hipStream_t st);
+void launch_profile_mark(hipStream_t st);
 void launch_scatter_int(int* dst, const int* slots, const int* src, int n, hipStream_t st);
 void launch_scatter_ids(int* dst, const int* slots, const int* src, const int* lens, int n, int S_max, hipStream_t st);   // dst[slot][s] = s < lens[i] ? src[i][s] : -1
 void launch_gather_ids(int* dst, int* cnt, const int* src, const int* slen, const int* slots, int n, int S_max, hipStream_t st);

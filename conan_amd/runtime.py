@@ -277,6 +277,10 @@ class Streams:
         _lib.check(self.lib.conan_streams_join(self.h, _stream()))
         self._release()
 
+    def profile_mark(self):
+        """One cnk::profile_mark_kernel dispatch on the current stream (marker for rocprofv3 post-processing)."""
+        _lib.check(self.lib.conan_profile_mark(self.h, _stream()))
+
     def profile_begin(self):
         _lib.check(self.lib.conan_profile_begin(self.h))
 

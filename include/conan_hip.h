@@ -227,6 +227,10 @@ int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int
  * outputs, 0 past the last one).  `name` is the kernel name as rocprofv3 prints it. */
 int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, double* ms, double* flops, int64_t* launches);
 
+/* Enqueue one dispatch of the empty kernel cnk::profile_mark_kernel on `stream`: a marker that tools/summarize_pmc.py
+ * uses to keep only the timed steps of a rocprofv3 counter-collection run (bench.py --marks). */
+int conan_profile_mark(conan_streams* s, void* stream);
+
 /* Introspection for tests / INTEGRATION.md. */
 int conan_hop_size(const conan_ctx* ctx);             /* prod(upsample_rates) */
 int64_t conan_ctx_weight_bytes(const conan_ctx* ctx); /* packed device weight bytes */
