@@ -394,8 +394,8 @@ int conan_profile_end(conan_streams* s, double* conv_ms, double* conv_flops, int
       ms += t;
       const auto& r = s->prof_rec[i];
       bool found = false;
-      for (auto& k : s->prof_kernels) if (k.cfg == r.cfg) { k.ms += t; k.flops += r.flops; k.n += 1; found = true; break; }
-      if (!found) s->prof_kernels.push_back({r.cfg, (double)t, r.flops, 1});
+      for (auto& k : s->prof_kernels) if (k.name == r.name) { k.ms += t; k.flops += r.flops; k.n += 1; found = true; break; }
+      if (!found) s->prof_kernels.push_back({r.name, (double)t, r.flops, 1});
     }
     if (conv_ms) *conv_ms = ms;
     if (conv_flops) *conv_flops = s->prof_flops;
@@ -409,7 +409,7 @@ int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, 
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
     if (index < 0 || index >= (int)s->prof_kernels.size()) return;
     const auto& k = s->prof_kernels[index];
-    if (name && name_cap > 0) snprintf(name, name_cap, "%s", cnk::conv_cfg_name(k.cfg));
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", k.name.c_str());
     if (ms) *ms = k.ms;
     if (flops) *flops = k.flops;
     if (launches) *launches = k.n;

@@ -121,6 +121,28 @@ void conan_ctx::pack_weightnorm(const std::string& name, const std::string& pref
   pack_conv(name, W, b.data(), Cout, Cin, k, shuffle_r);
 }
 
+// Weights of a C -> C conv for resblock_fused.hip: per 16-column tile, per tap (k taps + one zero tap), per 16-deep K
+// group one 1 KiB MFMA B operand: lane (g = lane >> 4, n = lane & 15) holds W[tap][cin = 16 q + 4 g + s][cout = 16 ct + n],
+// s = 0..3.  vecs[name + ".w"], vecs[name + ".b"].
+void conan_ctx::pack_fragments(const std::string& name, const std::string& prefix) {
+  std::vector<float> W, b;
+  int Cout, Cin, k;
+  fold_weightnorm(prefix, W, b, Cout, Cin, k);
+  if (Cout != Cin || Cin % 16) throw Error(CONAN_ERR_SHAPE, "fused resblock conv must be C -> C with C a multiple of 16: " + prefix);
+  const int C = Cin, KQ = C / 16, NCT = C / 16;
+  std::vector<float> out((size_t)NCT * (k + 1) * KQ * 256, 0.f);
+  for (int ct = 0; ct < NCT; ++ct)
+    for (int j = 0; j < k; ++j)
+      for (int q = 0; q < KQ; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int ci = q * 16 + 4 * (lane >> 4) + s, co = ct * 16 + (lane & 15);
+            out[(((size_t)ct * (k + 1) + j) * KQ + q) * 256 + lane * 4 + s] = W[((size_t)co * C + ci) * k + j];
+          }
+  vecs[name + ".w"] = upload(out);
+  vecs[name + ".b"] = upload(b);
+}
+
 void conan_ctx::upload_vec(const std::string& name, const std::string& key) { vecs[name] = upload(get(key).data); }
 
 void conan_ctx::finalize_hifigan() {
@@ -161,6 +183,11 @@ void conan_ctx::finalize_hifigan() {
         } else {
           pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
           pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
+          const int Cs = c.voc_initial_channel >> (i + 1);
+          if (cnk::resblock_fused_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d])) {
+            pack_fragments("voc.rbf." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
+            pack_fragments("voc.rbf." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
+          }
         }
       }
   }

@@ -85,6 +85,30 @@ int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);
 void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num_cu = 256);
 
+// One ResBlock1 unit (hifigan_causal.py:230-238) as ONE tile pass (resblock_fused.hip):
+//   y = c2(leaky_relu(c1(leaky_relu(x)))) + x,  c1: k taps, dilation dil;  c2: k taps, dilation 1, both causal.
+struct RBProb {
+  const float* w1; const float* w2;   // fragment-major: [C/16 column tiles][k + 1 taps (last zero)][C/16 K groups][64 lanes][4]
+  const float* b1; const float* b2;   // [C]
+  TRef x;                             // raw input (c1 operand after LeakyReLU, residual operand as it is)
+  TRef y;                             // raw output
+  int k, dil;
+};
+struct RBArgs {
+  RBProb p[3];                        // the branches of a stage at one dilation index (inputs / outputs share their ring geometry's mode and rate)
+  const int* slots; const int* pos;
+  const int* tiles;                   // filled by launch_resblock_fused: [grid][per] {branch, slot index, first row, 0}, branch -1 terminates
+  int per;
+  int nprob, n, T;                    // branches, slots in this batch, output rows per slot
+  int tiles_per_slot;
+  float slope;
+  unsigned long long* dbg;            // developer builds only (tools/rb_bench -DRB_ABLATE=4): cycle stamps per block
+};
+bool resblock_fused_supported(int C, int kmax, int span_max);
+int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu);   // output rows per tile to launch with
+bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
+const char* resblock_fused_name(int C, int rows);
+
 // LayerNorm over the channel axis of each row:
 //   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])
 // optionally writing mask_out[i][t] = (sum_c |x| > 0).

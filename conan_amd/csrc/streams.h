@@ -20,6 +20,7 @@ struct VocStage {
   std::vector<std::vector<Ring>> xt, xo;    // [branch][dilation]; xt is stored activated
   std::vector<std::vector<Ring>> xa;        // leaky_relu(xo) for the outputs that feed another c1
   int C = 0, rate = 1;
+  bool fused = false;                       // ResBlock1 units run as one tile pass each (resblock_fused.hip): no xt / activated twins
 };
 
 // Small host tables (slot lists, reference lengths) go to the device through a ring of pinned staging buffers: an
@@ -151,11 +152,13 @@ struct conan_streams {
   size_t prof_used = 0;
   double prof_flops = 0.0;
   long long prof_launches = 0;
-  struct ProfRec { int cfg; double flops; };
+  struct ProfRec { std::string name; double flops; };
   std::vector<ProfRec> prof_rec;                 // one per recorded launch (same order as prof_ev)
-  struct ProfKernel { int cfg; double ms, flops; long long n; };
+  struct ProfKernel { std::string name; double ms, flops; long long n; };
   std::vector<ProfKernel> prof_kernels;          // filled by conan_profile_end: per template instantiation
   void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
+  void launch_rb(const cnk::RBArgs& a, int C, hipStream_t st);
+  template <typename F> void profiled(const std::string& name, double flops, hipStream_t st, F&& launch);
   void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;
 

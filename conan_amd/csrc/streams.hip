@@ -74,7 +74,16 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     // split only when it removes at least a dozen steps from the critical path
     if (S >= 2 && tiles <= sk_max_tiles && nks - nks / S >= 12) g.ksplit = S;
   }
-  if (!prof_on) { cnk::launch_conv(g, nprob, cfg, st, ctx->num_cu); return; }
+  double fl = 0.0;
+  for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
+  profiled(cnk::conv_cfg_name(cfg), fl, st, [&] { cnk::launch_conv(g, nprob, cfg, st, ctx->num_cu); });
+}
+
+// every launch of the matrix kernels goes through here: between conan_profile_begin / _end it is bracketed by HIP
+// events on its launch stream and booked under the kernel's name with its algorithmic FLOPs
+template <typename F>
+void conan_streams::profiled(const std::string& name, double flops, hipStream_t st, F&& launch) {
+  if (!prof_on) { launch(); return; }
   if (prof_used == prof_ev.size()) {
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
@@ -82,13 +91,23 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   }
   auto& ev = prof_ev[prof_used++];
   HIP_CHECK(hipEventRecord(ev.first, st));
-  cnk::launch_conv(g, nprob, cfg, st, ctx->num_cu);
+  launch();
   HIP_CHECK(hipEventRecord(ev.second, st));
-  double fl = 0.0;
-  for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
-  prof_flops += fl;
+  prof_flops += flops;
   prof_launches += 1;
-  prof_rec.push_back({cfg, fl});
+  prof_rec.push_back({name, flops});
+}
+
+// one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
+void conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st) {
+  cnk::RBArgs a = ain;
+  int ksum = 0, kmax = 0;
+  double fl = 0.0;
+  for (int p = 0; p < a.nprob; ++p) { ksum += a.p[p].k; kmax = std::max(kmax, a.p[p].k); fl += 2.0 * 2.0 * (double)a.n * a.T * C * C * a.p[p].k; }
+  const int rows = cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, ctx->num_cu);
+  profiled(cnk::resblock_fused_name(C, rows), fl, st, [&] {
+    if (!cnk::launch_resblock_fused(a, C, rows, ctx->num_cu, st)) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
+  });
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
@@ -144,20 +163,28 @@ void conan_streams::build_vocoder() {
     rate *= c.voc_up_rates[i];
     ch_ /= 2;
     s.C = ch_; s.rate = rate;
-    s.up = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
+    // ResBlock1 stages whose width the fused tile pass covers: c1's halo rows of xt are recomputed from the input ring,
+    // so an input keeps (k-1)*(dil+1) rows of history and neither xt nor activated twins exist
+    s.fused = c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr;
+    for (int b = 0; b < c.voc_num_resblocks && s.fused; ++b)
+      for (int d = 0; d < c.voc_rb_num_dil; ++d)
+        s.fused = s.fused && cnk::resblock_fused_supported(ch_, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
+    int up_hist = (maxk - 1) * c.voc_rb_dilations[0][0];
+    if (s.fused) for (int b = 0; b < c.voc_num_resblocks; ++b) up_hist = std::max(up_hist, (c.voc_rb_kernels[b] - 1) * (c.voc_rb_dilations[b][0] + 1));
+    s.up = mk_ring(ch_, rate, up_hist, &voc_state);
     const int next_pad = (i + 1 < c.voc_num_ups) ? c.voc_up_kernels[i + 1] - 1 : 6;
     s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
     // LeakyReLU'd twins of `up` and of the resblock outputs that feed another c1: the producer's epilogue writes both
     // (ConvArgs::y2_base), c1 reads the activated copy, the residual add reads the raw one
-    s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
+    if (!s.fused) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
     s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks); s.xa.resize(c.voc_num_resblocks);
     for (int b = 0; b < c.voc_num_resblocks; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d) {
         const int k = c.voc_rb_kernels[b];
-        s.xt[b].push_back(mk_ring(ch_, rate, k - 1, &voc_state));
-        const int h = (d + 1 < c.voc_rb_num_dil) ? (k - 1) * c.voc_rb_dilations[b][d + 1] : next_pad;
+        if (!s.fused) s.xt[b].push_back(mk_ring(ch_, rate, k - 1, &voc_state));
+        const int h = (d + 1 < c.voc_rb_num_dil) ? (k - 1) * (c.voc_rb_dilations[b][d + 1] + (s.fused ? 1 : 0)) : next_pad;
         s.xo[b].push_back(mk_ring(ch_, rate, h, &voc_state));
-        if (d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
+        if (!s.fused && d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
       }
   }
 }
@@ -194,9 +221,23 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322): the input (v_pre / branch mean xs) is stored
        // activated; the output goes out raw (residual operand) and activated (c1 operand)
       ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos);
-      a.y2_base = s.upa.base; a.y2_slope = LR;
+      if (!s.fused) { a.y2_base = s.upa.base; a.y2_slope = LR; }
       conv(a, st);
       if (taps) tap(taps->ups[i], s.up, T);
+    }
+    for (int d = 0; d < ND && s.fused; ++d) {   // ResBlock1 (hifigan_causal.py:230-238): c1 -> lrelu -> c2 -> + x in one tile pass per branch
+      cnk::RBArgs ra; memset(&ra, 0, sizeof(ra));
+      for (int b = 0; b < NB; ++b) {
+        const std::string base = "voc.rbf." + std::to_string(ridx + b);
+        cnk::RBProb& pr = ra.p[b];
+        pr.w1 = ctx->vec(base + ".c1." + std::to_string(d) + ".w"); pr.b1 = ctx->vec(base + ".c1." + std::to_string(d) + ".b");
+        pr.w2 = ctx->vec(base + ".c2." + std::to_string(d) + ".w"); pr.b2 = ctx->vec(base + ".c2." + std::to_string(d) + ".b");
+        pr.x = d == 0 ? s.up.ref() : s.xo[b][d - 1].ref();
+        pr.y = s.xo[b][d].ref();
+        pr.k = c.voc_rb_kernels[b]; pr.dil = c.voc_rb_dilations[b][d];
+      }
+      ra.slots = d_slots; ra.pos = pos; ra.nprob = NB; ra.n = n; ra.T = T; ra.slope = LR;
+      launch_rb(ra, s.C, st);
     }
     for (int d = 0; d < ND && c.voc_resblock == 2; ++d) {  // ResBlock2 (hifigan_causal.py:255-261): x = conv_d(lrelu(x)) + x
       ConvGroup g1;
@@ -211,7 +252,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       }
       launch_group(g1, NB, pick_cfg(n * T, s.C, NB), st);
     }
-    for (int d = 0; d < ND && c.voc_resblock != 2; ++d) {  // ResBlock1 (hifigan_causal.py:230-238), the NB branches as one grouped launch
+    for (int d = 0; d < ND && c.voc_resblock != 2 && !s.fused; ++d) {  // ResBlock1 as two grouped conv launches (widths the fused pass does not cover)
       ConvGroup g1, g2;
       for (int b = 0; b < NB; ++b) {
         // xt = c1(leaky_relu(x)); x = c2(leaky_relu(xt)) + x: both activations are applied where the tensor is written
