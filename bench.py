@@ -48,13 +48,17 @@ WORKLOADS = {
                    desc="batch=128 streams, 40 ms chunk (seg 2 + rc 2 frames), stateful full pipeline"),
     "b128s2win": dict(streams=128, chunk_ms=40, window=16, config="BASELINE.json configs[4], 320 ms context window",
                       desc="batch=128 streams, 40 ms chunk + 320 ms context: Conan/vocoder reset + 18 frames per step, Emformer stateful"),
+    # extra, non-parity datapoint: the Emformer with torchaudio's memory bank enabled, which the
+    # reference's constructor never does (modules/Emformer/emformer.py:14-22)
+    "b128s2mem4": dict(streams=128, chunk_ms=40, window=0, memory=4, config="BASELINE.json configs[4] + Emformer max_memory_size=4 (not a reference configuration)",
+                       desc="batch=128 streams, 40 ms chunk (seg 2 + rc 2 frames), stateful, Emformer memory bank of 4 segments"),
 }
 
 
-def build_context(device, chunk_ms=80):
+def build_context(device, chunk_ms=80, memory=0):
     from conan_amd import configs, synth
     from conan_amd.runtime import Context
-    chp, vhp = dict(configs.conan_hparams(), chunk_size=chunk_ms), configs.hifigan_hparams()
+    chp, vhp = dict(configs.conan_hparams(), chunk_size=chunk_ms, emformer_max_memory_size=memory), configs.hifigan_hparams()
     ctx = Context(chp, vhp, device)
     ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0))
     ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
@@ -192,7 +196,7 @@ def main():
     B = args.streams or wl["streams"]
     window = wl["window"]
 
-    ctx, chp, vhp = build_context(local, wl["chunk_ms"])
+    ctx, chp, vhp = build_context(local, wl["chunk_ms"], wl.get("memory", 0))
     eng, chunks = make_engine(ctx, B, first_stream=rank * B, window=window)
     hop, seg = ctx.hop, eng.seg
     codes = torch.empty(B, seg, dtype=torch.int32, device="cuda")

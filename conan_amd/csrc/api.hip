@@ -38,8 +38,8 @@ static void validate_cfg(const conan_cfg& c) {
     if (c.emf_input_dim % 4 || c.emf_input_dim > 512) throw Error(CONAN_ERR_UNSUPPORTED, "emformer input_dim");
     if (c.emf_segment < 1 || c.emf_right_context < 0) throw Error(CONAN_ERR_INVALID, "emformer segment/right context");
     if (c.emf_max_memory_size < 0) throw Error(CONAN_ERR_INVALID, "emf_max_memory_size");
-    if (c.emf_max_memory_size > 0) throw Error(CONAN_ERR_UNSUPPORTED, "Emformer memory bank (max_memory_size > 0) is not built yet");
-    if (c.emf_right_context + c.emf_left_context + c.emf_segment > 128 || c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer attention supports <= 128 keys, <= 16 heads");
+    if (c.emf_max_memory_size > 32) throw Error(CONAN_ERR_UNSUPPORTED, "emf_max_memory_size > 32");
+    if (c.emf_max_memory_size + c.emf_right_context + c.emf_left_context + c.emf_segment > 128 || c.emf_heads > 16) throw Error(CONAN_ERR_UNSUPPORTED, "emformer attention supports <= 128 keys, <= 16 heads");
   }
   if (c.models & CONAN_MODEL_CONAN) {
     if (c.hidden_size % 8 || c.hidden_size > 512) throw Error(CONAN_ERR_UNSUPPORTED, "hidden_size must be a multiple of 8 and <= 512");

@@ -141,20 +141,39 @@ struct EmbedArgs {       // y[i][t][:] = table[idx[i][t]][:]
 };
 void launch_embed(const EmbedArgs& a, hipStream_t st);
 
-// Emformer attention for one layer (torchaudio _EmformerAttention.infer, no memory bank):
-// queries = R+U tokens; keys = rc(R) | cached left context (min(LC, past)) | utt(U); then the U
-// new utterance keys/values are appended to the per-slot rings.
+// Emformer attention for one layer (torchaudio _EmformerAttention.infer):
+// queries = R+U tokens (+ the summary token when M > 0); keys = valid memory entries (min(M, ceil(past/seg))) | rc(R) |
+// cached left context (min(LC, past)) | utt(U); the summary query does not see the memory columns; then the U new
+// utterance keys/values are appended to the per-slot rings.
 struct EmfAttnArgs {
-  const float* q;      // [n][R+U][D]      (emb_to_query output, unscaled)
-  const float* kv;     // [n][R+U][2D]     (emb_to_key_value output)
-  float* out;          // [n][R+U][D]
+  const float* q;      // [n][R+U(+1)][D]  (emb_to_query output, unscaled; last row = summary query when M > 0)
+  const float* kv;     // [n][M+R+U][2D]   (emb_to_key_value output; rows [0,M) = memory bank entries, right-aligned)
+  float* out;          // [n][R+U(+1)][D]
   float* kring; float* vring;   // [slot][LR][D]
   long long ring_slot_stride;
   const int* slots; const int* past;   // past[slot]
   int n, R, U, D, H, LC, lmask;
   float scaling;
+  int M, seg;          // memory bank size (0: none) and segment length
 };
 void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st);
+
+// Memory-bank bookkeeping of one Emformer layer (torchaudio _EmformerLayer._unpack_state / _pack_state, memory_op):
+//   ln[i][M+R+U]   = mean over the U utterance rows of ln (the summary token)
+//   ln[i][0..M)    = the bank's last min(M, ceil(past/seg)) entries, right-aligned, zeros before them
+//   bank[slot]    <- append mems_in[i]   (entry of segment number ceil(past/seg); ring of MB >= M+1 rows)
+struct EmfMemArgs {
+  float* ln;            // [n][M+R+U+1][D]
+  float* bank;          // [slot][MB][D]
+  const float* mems_in; // [n][D]
+  const int* slots; const int* past;
+  int n, R, U, D, M, MB, seg;
+};
+void launch_emf_mem_prep(const EmfMemArgs& a, hipStream_t st);
+// out[i][:] = mean over rows [row0, row0+U) of x[i] ([n][rows][D])
+void launch_emf_seg_mean(const float* x, float* out, int n, int rows, int row0, int U, int D, hipStream_t st);
+// out[i][:] = tanh_on_mem ? tanh(x[i][row][:]) : clamp(x[i][row][:], -10, 10)
+void launch_emf_mem_out(const float* x, float* out, int n, int rows, int row, int D, int tanh_on_mem, hipStream_t st);
 
 // Whole streaming Emformer step in one launch (emformer_fused.hip): all layers + projection + arg-max.
 constexpr int EMF_MAX_LAYERS = 12;

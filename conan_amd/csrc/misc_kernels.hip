@@ -126,29 +126,34 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
   const int i = blockIdx.x;
   const int slot = a.slots[i];
   const int Q = a.R + a.U;
+  const int Qq = Q + (a.M > 0 ? 1 : 0);       // + the summary query
+  const int KVR = a.M + Q;                    // rows of this step's key/value projections
   const int dh = a.D / a.H;
   const int past = a.past[slot];
   const int Lc = past < a.LC ? past : a.LC;
-  const int nk = a.R + Lc + a.U;
+  int nm = 0;
+  if (a.M > 0) { const int nseg = (past + a.seg - 1) / a.seg; nm = nseg < a.M ? nseg : a.M; }
+  const int nk = nm + a.R + Lc + a.U;
   const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* sq = esm;                    // [Q][D]
-  float* skv = esm + Q * a.D;         // [Q][2D]
-  float* so = skv + Q * 2 * a.D;      // [Q][D]
-  float* sprob = so + Q * a.D;        // [H][Q][KPL*64] normalised attention weights
-  float* sval = sprob + a.H * Q * EMF_MAX_KPL * 64;   // [H][KPL*64][MAX_DH] values of each head
-  const float* kvb = a.kv + (long long)i * Q * 2 * a.D;
-  const float* qb = a.q + (long long)i * Q * a.D;
-  for (int e = threadIdx.x; e < Q * a.D; e += blockDim.x) sq[e] = qb[e] * a.scaling;
-  for (int e = threadIdx.x; e < Q * 2 * a.D; e += blockDim.x) skv[e] = kvb[e];
+  float* sq = esm;                    // [Qq][D]
+  float* skv = esm + Qq * a.D;        // [KVR][2D]
+  float* so = skv + KVR * 2 * a.D;    // [Qq][D]
+  float* sprob = so + Qq * a.D;       // [H][Qq][KPL*64] normalised attention weights
+  float* sval = sprob + a.H * Qq * EMF_MAX_KPL * 64;   // [H][KPL*64][MAX_DH] values of each head
+  const float* kvb = a.kv + (long long)i * KVR * 2 * a.D;
+  const float* qb = a.q + (long long)i * Qq * a.D;
+  for (int e = threadIdx.x; e < Qq * a.D; e += blockDim.x) sq[e] = qb[e] * a.scaling;
+  for (int e = threadIdx.x; e < KVR * 2 * a.D; e += blockDim.x) skv[e] = kvb[e];
   const float* kr = a.kring + (long long)slot * a.ring_slot_stride;
   const float* vr = a.vring + (long long)slot * a.ring_slot_stride;
   float kreg[EMF_MAX_KPL][EMF_MAX_DH], vreg[EMF_MAX_KPL][EMF_MAX_DH];
+  const int c0 = nm + a.R;            // first cached left-context key
   if (h < a.H) {     // cached left-context keys come straight from the rings (issued before the barrier)
 #pragma unroll
     for (int s = 0; s < EMF_MAX_KPL; ++s) {
       const int kk = lane + 64 * s;
-      const bool cached = kk >= a.R && kk < a.R + Lc;
-      const unsigned r = (unsigned)(past - Lc + (kk - a.R)) & (unsigned)a.lmask;
+      const bool cached = kk >= c0 && kk < c0 + Lc;
+      const unsigned r = (unsigned)(past - Lc + (kk - c0)) & (unsigned)a.lmask;
       const float* kp = kr + (long long)(cached ? r : 0) * a.D + h * dh;
       const float* vp = vr + (long long)(cached ? r : 0) * a.D + h * dh;
 #pragma unroll
@@ -161,20 +166,22 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
   __syncthreads();
   if (h < a.H) {
 #pragma unroll
-    for (int s = 0; s < EMF_MAX_KPL; ++s) {   // this step's right-context / utterance keys from LDS
+    for (int s = 0; s < EMF_MAX_KPL; ++s) {   // memory / right-context / utterance keys of this step from LDS
       const int kk = lane + 64 * s;
-      int tok = -1;
-      if (kk < a.R) tok = kk;
-      else if (kk >= a.R + Lc && kk < nk) tok = a.R + (kk - a.R - Lc);
+      int tok = -1;                            // row of skv
+      if (kk < nm) tok = (a.M - nm) + kk;
+      else if (kk < c0) tok = a.M + (kk - nm);
+      else if (kk >= c0 + Lc && kk < nk) tok = a.M + a.R + (kk - c0 - Lc);
       if (tok >= 0) {
 #pragma unroll
         for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) { kreg[s][d] = skv[tok * 2 * a.D + h * dh + d]; vreg[s][d] = skv[tok * 2 * a.D + a.D + h * dh + d]; }
       }
     }
     // scores: lanes own keys; two shuffle reductions per query (max, normaliser); the probabilities go to LDS
-    float* sp = sprob + h * Q * EMF_MAX_KPL * 64;
-    for (int qi = 0; qi < Q; ++qi) {
+    float* sp = sprob + h * Qq * EMF_MAX_KPL * 64;
+    for (int qi = 0; qi < Qq; ++qi) {
       const float* qp = sq + qi * a.D + h * dh;
+      const int kmin = qi >= Q ? nm : 0;      // the summary query does not attend to the memory columns
       float sc[EMF_MAX_KPL];
       float mx = -INFINITY;
 #pragma unroll
@@ -182,13 +189,14 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
         float acc = 0.f;
 #pragma unroll
         for (int d = 0; d < EMF_MAX_DH; ++d) if (d < dh) acc += qp[d] * kreg[s][d];
-        sc[s] = (lane + 64 * s) < nk ? acc : -INFINITY;
+        const int kk = lane + 64 * s;
+        sc[s] = (kk < nk && kk >= kmin) ? acc : -INFINITY;
         mx = fmaxf(mx, sc[s]);
       }
       mx = wave_max(mx);
       float sum = 0.f;
 #pragma unroll
-      for (int s = 0; s < EMF_MAX_KPL; ++s) { sc[s] = (lane + 64 * s) < nk ? expf(sc[s] - mx) : 0.f; sum += sc[s]; }
+      for (int s = 0; s < EMF_MAX_KPL; ++s) { const int kk = lane + 64 * s; sc[s] = (kk < nk && kk >= kmin) ? expf(sc[s] - mx) : 0.f; sum += sc[s]; }
       sum = wave_sum(sum);
       const float inv = 1.0f / sum;
 #pragma unroll
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
 #pragma unroll
       for (int d = 0; d < EMF_MAX_DH; ++d) sv[(s * 64 + lane) * EMF_MAX_DH + d] = vreg[s][d];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int pair = lane; pair < Q * dh; pair += 64) {
+    for (int pair = lane; pair < Qq * dh; pair += 64) {
       const int qi = pair / dh, d = pair - qi * dh;
       float o = 0.f;
       for (int kk = 0; kk < nk; ++kk) {
@@ -212,23 +220,74 @@ __global__ __launch_bounds__(1024) void emf_attn_kernel(const EmfAttnArgs a) {
     }
   }
   __syncthreads();
-  float* ob = a.out + (long long)i * Q * a.D;
-  for (int e = threadIdx.x; e < Q * a.D; e += blockDim.x) ob[e] = so[e];
+  float* ob = a.out + (long long)i * Qq * a.D;
+  for (int e = threadIdx.x; e < Qq * a.D; e += blockDim.x) ob[e] = so[e];
   // append the U new utterance keys/values (rows past .. past+U-1; not read above)
   float* kw = a.kring + (long long)slot * a.ring_slot_stride;
   float* vw = a.vring + (long long)slot * a.ring_slot_stride;
   for (int e = threadIdx.x; e < a.U * a.D; e += blockDim.x) {
     const int u = e / a.D, c = e - u * a.D;
     const unsigned r = (unsigned)(past + u) & (unsigned)a.lmask;
-    kw[(long long)r * a.D + c] = skv[(a.R + u) * 2 * a.D + c];
-    vw[(long long)r * a.D + c] = skv[(a.R + u) * 2 * a.D + a.D + c];
+    kw[(long long)r * a.D + c] = skv[(a.M + a.R + u) * 2 * a.D + c];
+    vw[(long long)r * a.D + c] = skv[(a.M + a.R + u) * 2 * a.D + a.D + c];
   }
 }
 void launch_emf_attn(const EmfAttnArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
-  const int Q = a.R + a.U;
-  const size_t smem = ((size_t)Q * a.D * 4 + (size_t)a.H * Q * EMF_MAX_KPL * 64 + (size_t)a.H * EMF_MAX_KPL * 64 * EMF_MAX_DH) * sizeof(float);
+  const int Q = a.R + a.U, Qq = Q + (a.M > 0 ? 1 : 0), KVR = a.M + Q;
+  const size_t smem = ((size_t)Qq * a.D * 2 + (size_t)KVR * 2 * a.D + (size_t)a.H * Qq * EMF_MAX_KPL * 64 + (size_t)a.H * EMF_MAX_KPL * 64 * EMF_MAX_DH) * sizeof(float);
   hipLaunchKernelGGL(emf_attn_kernel, dim3(a.n), dim3(64 * a.H), smem, st, a);
+}
+
+// ------------------------------------------------------------------------------------ Emformer memory bank
+__global__ __launch_bounds__(256) void emf_mem_prep_kernel(const EmfMemArgs a) {
+  const int i = blockIdx.x, slot = a.slots[i];
+  const int Q = a.R + a.U, rows = a.M + Q + 1;
+  const int past = a.past[slot];
+  const int nseg = (past + a.seg - 1) / a.seg;
+  const int nm = nseg < a.M ? nseg : a.M;
+  float* ln = a.ln + (long long)i * rows * a.D;
+  float* bank = a.bank + (long long)slot * a.MB * a.D;
+  for (int c = threadIdx.x; c < a.D; c += blockDim.x) {
+    // summary = AvgPool1d(kernel = stride = segment) of the normalised utterance (_EmformerLayer.memory_op), first row
+    float s = 0.f;
+    for (int u = 0; u < a.U; ++u) s += ln[(long long)(a.M + a.R + u) * a.D + c];
+    ln[(long long)(a.M + Q) * a.D + c] = s / (float)a.U;
+    // the bank as it was before this step (_unpack_state), right-aligned; the entry of segment j lives in ring row j % MB
+    for (int m = 0; m < a.M; ++m) {
+      const int j = nseg - (a.M - m);
+      ln[(long long)m * a.D + c] = (m >= a.M - nm) ? bank[(long long)(j & (a.MB - 1)) * a.D + c] : 0.f;
+    }
+    // _pack_state: append this step's memory input (MB >= M + 1: the row written is none of those read above)
+    bank[(long long)(nseg & (a.MB - 1)) * a.D + c] = a.mems_in[(long long)i * a.D + c];
+  }
+}
+void launch_emf_mem_prep(const EmfMemArgs& a, hipStream_t st) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(emf_mem_prep_kernel, dim3(a.n), dim3(a.D >= 256 ? 256 : 128), 0, st, a);
+}
+__global__ void emf_seg_mean_kernel(const float* x, float* out, int rows, int row0, int U, int D) {
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float s = 0.f;
+    for (int u = 0; u < U; ++u) s += x[((long long)i * rows + row0 + u) * D + c];
+    out[(long long)i * D + c] = s / (float)U;
+  }
+}
+void launch_emf_seg_mean(const float* x, float* out, int n, int rows, int row0, int U, int D, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(emf_seg_mean_kernel, dim3(n), dim3(128), 0, st, x, out, rows, row0, U, D);
+}
+__global__ void emf_mem_out_kernel(const float* x, float* out, int rows, int row, int D, int tanh_on_mem) {
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const float v = x[((long long)i * rows + row) * D + c];
+    out[(long long)i * D + c] = tanh_on_mem ? tanhf(v) : fminf(fmaxf(v, -10.f), 10.f);
+  }
+}
+void launch_emf_mem_out(const float* x, float* out, int n, int rows, int row, int D, int tanh_on_mem, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(emf_mem_out_kernel, dim3(n), dim3(128), 0, st, x, out, rows, row, D, tanh_on_mem);
 }
 
 // ------------------------------------------------------------------------------------ cross attention

@@ -83,6 +83,9 @@ struct conan_streams {
   std::vector<VocStage> v_st;
   // --- emformer
   std::vector<Ring> e_k, e_v;
+  std::vector<float*> e_bank;     // memory bank per layer: [slot][e_bank_rows][D] (max_memory_size > 0)
+  int e_bank_rows = 0;
+  float* e_mems[2] = {nullptr, nullptr};   // memory input / output of a layer, [n][D]
   Lin e_x[2], e_ln, e_q, e_kv, e_att, e_r1, e_ffn, e_h, e_r2, e_logits;
   bool emf_fused = false;
   cnk::EmfFusedArgs emf_fused_args;

@@ -301,9 +301,23 @@ void conan_streams::build_emformer() {
     r.base = alloc((size_t)max_slots * r.slot_stride); emf_state.push_back({r.base, r.slot_stride}); e_k.push_back(r);
     Ring v = r; v.base = alloc((size_t)max_slots * r.slot_stride); emf_state.push_back({v.base, v.slot_stride}); e_v.push_back(v);
   }
-  e_x[0] = mk_lin(Q, D); e_x[1] = mk_lin(Q, D); e_ln = mk_lin(Q, D); e_q = mk_lin(Q, D); e_kv = mk_lin(Q, 2 * D);
-  e_att = mk_lin(Q, D); e_r1 = mk_lin(Q, D); e_ffn = mk_lin(Q, D); e_h = mk_lin(Q, c.emf_ffn_dim); e_r2 = mk_lin(Q, D);
+  // Memory bank (torchaudio max_memory_size = M > 0): every per-token buffer gets one more row for the summary token
+  // (row Q; in e_x it stays zero, so the shared residual add leaves the summary's attention output untouched), the
+  // normalised input is laid out [bank entries (M) | rc | utt | summary] so that the query rows [M, M+Q] and the
+  // key/value rows [0, M+Q) are both contiguous; one bank ring of >= M+1 entries per layer and slot.
+  const int M = c.emf_max_memory_size, QP = Q + (M > 0 ? 1 : 0);
+  e_x[0] = mk_lin(QP, D); e_x[1] = mk_lin(QP, D); e_ln = mk_lin(M + QP, D); e_q = mk_lin(QP, D); e_kv = mk_lin(M + Q, 2 * D);
+  e_att = mk_lin(QP, D); e_r1 = mk_lin(QP, D); e_ffn = mk_lin(QP, D); e_h = mk_lin(QP, c.emf_ffn_dim); e_r2 = mk_lin(QP, D);
   e_logits = mk_lin(c.emf_segment, c.emf_output_dim);
+  if (M > 0) {
+    e_bank_rows = ch::next_pow2(M + 1);
+    for (int l = 0; l < c.emf_layers; ++l) {
+      float* b = alloc((size_t)max_slots * e_bank_rows * D);
+      emf_state.push_back({b, (long long)e_bank_rows * D});
+      e_bank.push_back(b);
+    }
+    e_mems[0] = alloc((size_t)max_slots * D); e_mems[1] = alloc((size_t)max_slots * D);
+  }
   // plan of the fused step; the per-op path below stays for shapes it does not cover (and CONAN_EMF_UNFUSED=1)
   cnk::EmfFusedArgs& a = emf_fused_args; memset(&a, 0, sizeof(a));
   if (c.emf_layers <= cnk::EMF_MAX_LAYERS) {
@@ -333,7 +347,7 @@ void conan_streams::build_emformer() {
     a.F = c.emf_ffn_dim; a.K = c.emf_output_dim; a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
     { const unsigned long long per_g = (unsigned long long)std::max(c.emf_left_context, 1) * (D / 4); a.magic_per_g = (unsigned)(((1ull << 32) + per_g - 1) / per_g); }
     const char* off = getenv("CONAN_EMF_UNFUSED");
-    emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1');
+    emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1') && M == 0;   // the one-launch step has no memory tokens
   }
 }
 
@@ -347,13 +361,16 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
     return;
   }
   // token order inside the layers is [right_context | utterance] (torchaudio _EmformerLayer.infer): reorder the chunk
+  const int M = c.emf_max_memory_size, QP = Q + (M > 0 ? 1 : 0);
   {
     cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.slots = nullptr; ca.pos = nullptr; ca.lens = nullptr; ca.n = n; ca.C = D;
     ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, U); ca.y = e_x[0].ref(0); ca.T = R; if (R > 0) cnk::launch_copy_rows(ca, st);
     ca.x = ch::lin_ref(const_cast<float*>(chunk), Q, D, 0); ca.y = e_x[0].ref(R); ca.T = U; cnk::launch_copy_rows(ca, st);
   }
-  int cur = 0;
+  // _EmformerImpl.infer: the first layer's memory input is the mean of the raw segment
+  if (M > 0) cnk::launch_emf_seg_mean(e_x[0].base, e_mems[0], n, QP, R, U, D, st);
+  int cur = 0, mcur = 0;
   auto ln = [&](const TRef& x, const TRef& y, float* g, float* b, const TRef* pre) {
     cnk::LNArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.gamma = g; a.beta = b; a.slots = nullptr; a.pos = nullptr; a.lens = nullptr; a.T = Q; a.n = n; a.C = D; a.eps = 1e-5f;
@@ -363,21 +380,32 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
   for (int l = 0; l < c.emf_layers; ++l) {
     const std::string nm = "emf." + std::to_string(l);
     Lin& x = e_x[cur];
-    ln(x.ref(), e_ln.ref(), ctx->vec(nm + ".ln_in.g"), ctx->vec(nm + ".ln_in.b"), nullptr);
-    conv(mk(ctx->conv(nm + ".q"), e_ln.ref(), e_q.ref(), n, Q, nullptr), st);
-    conv(mk(ctx->conv(nm + ".kv"), e_ln.ref(), e_kv.ref(), n, Q, nullptr), st);
+    ln(x.ref(), e_ln.ref(M), ctx->vec(nm + ".ln_in.g"), ctx->vec(nm + ".ln_in.b"), nullptr);
+    if (M > 0) {   // summary token, bank entries -> key/value rows, bank update with this layer's memory input
+      cnk::EmfMemArgs ma; memset(&ma, 0, sizeof(ma));
+      ma.ln = e_ln.base; ma.bank = e_bank[l]; ma.mems_in = e_mems[mcur]; ma.slots = d_slots; ma.past = pos_emf;
+      ma.n = n; ma.R = R; ma.U = U; ma.D = D; ma.M = M; ma.MB = e_bank_rows; ma.seg = c.emf_segment;
+      cnk::launch_emf_mem_prep(ma, st);
+    }
+    conv(mk(ctx->conv(nm + ".q"), e_ln.ref(M), e_q.ref(), n, QP, nullptr), st);          // queries: rc | utt | summary
+    conv(mk(ctx->conv(nm + ".kv"), e_ln.ref(0), e_kv.ref(), n, M + Q, nullptr), st);     // keys/values: bank | rc | utt
     {
       cnk::EmfAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = e_q.base; a.kv = e_kv.base; a.out = e_att.base; a.kring = e_k[l].base; a.vring = e_v[l].base;
       a.ring_slot_stride = e_k[l].slot_stride; a.slots = d_slots; a.past = pos_emf;
       a.n = n; a.R = R; a.U = U; a.D = D; a.H = c.emf_heads; a.LC = c.emf_left_context; a.lmask = e_k[l].L - 1;
       a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
+      a.M = M; a.seg = c.emf_segment;
       cnk::launch_emf_attn(a, st);
     }
-    {  // out_proj + residual with the un-normalised layer input
-      ConvArgs a = mk(ctx->conv(nm + ".out"), e_att.ref(), e_r1.ref(), n, Q, nullptr);
+    {  // out_proj + residual with the un-normalised layer input (the summary row's residual row is zero)
+      ConvArgs a = mk(ctx->conv(nm + ".out"), e_att.ref(), e_r1.ref(), n, QP, nullptr);
       a.res = x.ref(); a.has_res = 1;
       conv(a, st);
+    }
+    if (M > 0) {   // output_mems = clamp / tanh of the summary row: the next layer's memory input
+      cnk::launch_emf_mem_out(e_r1.base, e_mems[mcur ^ 1], n, QP, Q, D, c.emf_tanh_on_mem, st);
+      mcur ^= 1;
     }
     ln(e_r1.ref(), e_ffn.ref(), ctx->vec(nm + ".ln_ff.g"), ctx->vec(nm + ".ln_ff.b"), nullptr);
     { ConvArgs a = mk(ctx->conv(nm + ".ff1"), e_ffn.ref(), e_h.ref(), n, Q, nullptr); a.out_act = cnk::ACT_RELU; conv(a, st); }

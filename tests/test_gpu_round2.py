@@ -33,7 +33,7 @@ def _ctx(chp=None, vhp=None, tiny=False, emformer=True, conan=True, hifigan=True
 
 
 # ---------------------------------------------------------------------------------------------- Emformer pin
-@pytest.mark.parametrize("variant", ["rc2_seg4", "rc0_seg4", "rc2_seg2"])
+@pytest.mark.parametrize("variant", ["rc2_seg4", "rc0_seg4", "rc2_seg2", "rc2_seg4_mem4"])
 def test_emformer_against_torchaudio(variant):
     """The Emformer arithmetic is third-party (torchaudio==2.5.1, requirements.txt:3; call sites
     modules/Emformer/emformer.py:14-22, inference/Conan.py:115-124).  Where the public torchaudio package is installed,
@@ -47,13 +47,15 @@ def test_emformer_against_torchaudio(variant):
     from oracle import emformer as oemf
     from oracle.common import to_torch_sd
     rc = 0 if variant.startswith("rc0") else 2
-    seg = 2 if variant.endswith("seg2") else 4
-    chp = dict(configs.conan_hparams(), right_context=rc, chunk_size=20 * seg)
+    seg = 2 if "seg2" in variant else 4
+    mem = 4 if variant.endswith("mem4") else 0
+    chp = dict(configs.conan_hparams(), right_context=rc, chunk_size=20 * seg, emformer_max_memory_size=mem)
     ctx, chp, _ = _ctx(chp, conan=False, hifigan=False)
     sd_np = synth.emformer_state_dict(chp, 0)
     sd = to_torch_sd(sd_np)
     cfg = oemf.EmformerCfg(chp)
-    em = torchaudio.models.Emformer(80, 8, 2048, chp["emformer_layers"], seg, left_context_length=50, right_context_length=rc)
+    em = torchaudio.models.Emformer(80, 8, 2048, chp["emformer_layers"], seg, left_context_length=50, right_context_length=rc,
+                                    max_memory_size=mem)
     em.load_state_dict({k[len("emformer."):]: v for k, v in sd.items() if k.startswith("emformer.")}, strict=True)
     em.eval()
     B, T = 3, 18 * seg + 3           # ragged tail: the last chunk is padded by repeating the last frame
@@ -74,6 +76,42 @@ def test_emformer_against_torchaudio(variant):
         np.testing.assert_allclose(o_or.numpy(), o_ta.numpy(), atol=2e-5, rtol=1e-5)
         np.testing.assert_allclose(o_hip.cpu().numpy(), o_ta.numpy(), atol=1e-4, rtol=1e-4)
     print(f"\n[emformer-pin] RAN against torchaudio {torchaudio.__version__} ({variant}): oracle max|d| {worst_or:.2e}, HIP max|d| {worst_hip:.2e}")
+    st.close(); ctx.close()
+
+
+@pytest.mark.parametrize("M,tanh", [(4, False), (2, True)])
+def test_emformer_memory_bank_vs_oracle(M, tanh):
+    """The memory bank of torchaudio's Emformer (max_memory_size > 0: summary token, per-layer bank of the last M segment
+    memories as extra attention keys, clamp / tanh on the produced memory) - BASELINE.json north_star "memory-bank
+    update".  modules/Emformer/emformer.py:14-22 never enables it, so this is an extra, non-parity datapoint: the HIP
+    per-op step against the oracle restatement (itself checked against a whole-sequence formulation on the CPU) over
+    20 chunks: bank ramp-up, saturation and roll-over, left-context wrap, a stream restarted half way."""
+    from oracle import emformer as oemf
+    from oracle.common import to_torch_sd
+    chp = dict(configs.conan_hparams(), emformer_max_memory_size=M, emformer_tanh_on_mem=tanh)
+    ctx, chp, _ = _ctx(chp, conan=False, hifigan=False)
+    assert ctx.cfg.emf_max_memory_size == M
+    sd = to_torch_sd(synth.emformer_state_dict(chp, 0))
+    cfg = oemf.EmformerCfg(chp)
+    B, T = 3, 80
+    mel = torch.from_numpy(synth.mel(T, 33, B))
+    st = ctx.streams(4, max_frames=4, max_ref_frames=16)
+    slots = [3, 0, 2]
+    st.reset(slots)
+    state = None
+    for n_chunk, (pos, emit, chunk) in enumerate(oemf.chunk_iter(mel, 4, 2)):
+        if n_chunk == 11:      # all three streams restart (the oracle's batch shares one past_length): state and bank cleared
+            st.reset(slots, which=1)
+            state = None
+        lengths = torch.full((B,), 6, dtype=torch.long)
+        o_ref, _, state = oemf.emformer_infer(sd, cfg, chunk, lengths, state)
+        lg_ref, codes_ref = oemf.logits_and_codes(sd, o_ref)
+        o, lg, codes = st.emformer_step(slots, chunk.cuda())
+        np.testing.assert_allclose(o.cpu().numpy(), o_ref.numpy(), atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(lg.cpu().numpy(), lg_ref.numpy(), atol=2e-4, rtol=1e-4)
+        top2 = lg_ref.topk(2, -1).values
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert torch.equal(codes.cpu().long()[safe], codes_ref[safe])
     st.close(); ctx.close()
 
 

@@ -60,3 +60,27 @@ def test_against_torchaudio_if_installed(model):
             o1, _, s1 = em.infer(chunk, lengths, s1)
         o2, _, s2 = model.infer(chunk, lengths, s2)
         np.testing.assert_allclose(o1.numpy(), o2.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("M,tanh,T", [(4, False, 8), (4, False, 40), (3, True, 28), (1, False, 16)])
+def test_memory_bank_streaming_equals_dense(M, tanh, T):
+    """torchaudio's memory bank (max_memory_size > 0; the reference leaves it off, modules/Emformer/emformer.py:14-22):
+    the rolling-state restatement against the whole-sequence formulation with explicit per-segment memory columns -
+    bank ramp-up (fewer than M past segments), saturation and roll-over (> M segments), clamp and tanh variants."""
+    hp = dict(configs.conan_hparams(), emformer_layers=3, emformer_max_memory_size=M, emformer_tanh_on_mem=tanh)
+    m = oemf.Model(synth.emformer_state_dict(hp, 0), hp)
+    assert m.cfg.max_memory_size == M and m.cfg.tanh_on_mem == tanh
+    mel = torch.from_numpy(synth.mel(T, 9, 2))
+    state, outs = None, []
+    for pos, emit, chunk in oemf.chunk_iter(mel, 4, 2):
+        o, _, state = m.infer(chunk, torch.full((2,), 6, dtype=torch.long), state)
+        outs.append(o[:, :emit])
+    stream = torch.cat(outs, 1)
+    dense = oemf.dense_reference(m.sd, m.cfg, mel)
+    np.testing.assert_allclose(stream.numpy(), dense.numpy(), atol=2e-5, rtol=1e-5)
+    assert state[0][0].shape == (M, 2, 80)
+    # the bank matters: the same weights without it give a different output once a past segment exists
+    m0 = oemf.Model(synth.emformer_state_dict(hp, 0), dict(hp, emformer_max_memory_size=0))
+    d0 = oemf.dense_reference(m0.sd, m0.cfg, mel)
+    assert float((d0[:, 4:] - dense[:, 4:]).abs().max()) > 1e-3
+    np.testing.assert_allclose(d0[:, :4].numpy(), dense[:, :4].numpy(), atol=2e-5)   # first segment: empty bank
