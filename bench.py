@@ -184,7 +184,7 @@ def main():
                                                          "every other leg (rocprofv3 --pmc passes: tools/summarize_pmc.py keeps the dispatches between the marks)")
     args = ap.parse_args()
 
-    from conan_amd.engine import gather_audio_equal, init_distributed
+    from conan_amd.engine import init_distributed
     rank, local, world = init_distributed()
     if world != args.gpus:
         if rank == 0:
@@ -202,45 +202,31 @@ def main():
     codes = torch.empty(B, seg, dtype=torch.int32, device="cuda")
     mel_out = torch.empty(B, seg, 80, device="cuda")
     wav = torch.empty(B, seg * hop, device="cuda")
-    gbufs = [torch.empty_like(wav) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     # Throughput leg, stateful workloads: pipelined steps (conan_step_async) - the front-end of chunk t+1 overlaps the
     # vocoder of chunk t on the library's two internal HIP streams.  Audio goes to a small ring of buffers; with more
-    # than one rank the RCCL gather of chunk t runs on its own stream so that it does not serialise the pipeline either.
+    # than one rank the RCCL gather of chunk t runs on its own stream so that it does not serialise the pipeline either
+    # (conan_amd.engine.AudioGatherRing; CONAN_BENCH_COMM=1 exercises that choreography on a single rank).
     # Windowed workloads: one blocking windowed step (Emformer step, reset, decoder + vocoder over window + chunk frames).
-    NB = 4
-    wavs = [torch.empty_like(wav) for _ in range(NB)]
-    # CONAN_BENCH_COMM=1 exercises the gather stream / event choreography on a single rank (the gather itself is a
-    # no-op there); used to check that path on a one-GPU box
-    use_comm = world > 1 or os.environ.get("CONAN_BENCH_COMM", "0") == "1"
-    comm = torch.cuda.Stream() if use_comm else None
-    gdone = [torch.cuda.Event() for _ in range(NB)] if use_comm else None
+    from conan_amd.engine import AudioGatherRing
+    ring = AudioGatherRing(lambda: torch.empty_like(wav), world, rank, nb=4, always=os.environ.get("CONAN_BENCH_COMM", "0") == "1")
     hist = [torch.randint(0, 100, (B, window), dtype=torch.int32, device="cuda")] if window else None
 
     def step(j):
-        k = j % NB
-        if use_comm and j >= NB:
-            torch.cuda.current_stream().wait_event(gdone[k])      # the gather that read this buffer has finished
+        buf = ring.acquire(j)
         if window:
             c, w = eng.windowed_step(chunks[j % len(chunks)], hist[0])
             hist[0] = torch.cat([hist[0][:, seg:], c], 1)
-            wavs[k].copy_(w)
+            buf.copy_(w)
+            ring.submit(j, wait_current=True)
         else:
-            eng.st.step_async(eng.slots, chunks[j % len(chunks)], wavs[k], emit=seg, codes=codes, mel_out=mel_out)
-        if use_comm:
-            with torch.cuda.stream(comm):
-                if window:
-                    comm.wait_stream(torch.cuda.default_stream())
-                else:
-                    eng.st.join()
-                gather_audio_equal(wavs[k], world, rank, gbufs)
-                gdone[k].record(comm)
+            eng.st.step_async(eng.slots, chunks[j % len(chunks)], buf, emit=seg, codes=codes, mel_out=mel_out)
+            ring.submit(j, join=eng.st.join)
 
     def barrier():
         if not window:
             eng.st.join()
-        if use_comm:
-            comm.synchronize()
+        ring.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -63,6 +63,88 @@ def gather_audio_equal(wav_local, world, rank, bufs=None, dst=0):
     return bufs
 
 
+class _HostStream:
+    """Stand-in for torch.cuda.Stream / Event on a host-only process group (gloo): everything is synchronous, so
+    waits and records are no-ops.  Lets the CPU tests drive the very choreography the GPU benchmark runs."""
+
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, s):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def record(self, stream=None):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class AudioGatherRing:
+    """Per-step collection of finished audio on rank 0 (the path's only exchange) without serialising
+    the chunk pipeline: audio of step j goes to buffer j % nb; its gather (RCCL on GPUs, gloo on CPU) is enqueued on a
+    side stream behind `join()` (= "step j's audio is complete"), and a buffer is handed out again only after the
+    gather that read it has finished (one event per buffer).
+
+        ring = AudioGatherRing(lambda: torch.empty(B, samples, device=dev), world, rank)
+        for j in range(steps):
+            buf = ring.acquire(j)          # current stream waits for the gather that last read this buffer
+            ... enqueue the step that writes buf ...
+            ring.submit(j, join)           # side stream: join(); gather(buf); record
+        ring.drain()
+    """
+
+    def __init__(self, make_buffer, world, rank, nb=4, always=False, on_gathered=None):
+        self.world, self.rank, self.nb = world, rank, nb
+        self.bufs = [make_buffer() for _ in range(nb)]
+        self.active = world > 1 or always
+        self.cuda = self.bufs[0].is_cuda
+        self.on_gathered = on_gathered
+        self.gbufs = [torch.empty_like(self.bufs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+        if self.active and self.cuda:
+            self.comm = torch.cuda.Stream()
+            self.done = [torch.cuda.Event() for _ in range(nb)]
+        else:
+            self.comm = _HostStream()
+            self.done = [_HostStream() for _ in range(nb)]
+        self.submitted = 0
+
+    def acquire(self, j):
+        k = j % self.nb
+        if self.active and j >= self.nb:
+            (torch.cuda.current_stream() if self.cuda else _HostStream()).wait_event(self.done[k])
+        return self.bufs[k]
+
+    def submit(self, j, join=None, wait_current=False):
+        """join: callable making the CURRENT stream wait for step j's audio (Streams.join); wait_current: the audio was
+        produced on the stream that is current now (blocking steps) - the side stream waits for it."""
+        if not self.active:
+            return
+        k = j % self.nb
+        cur = torch.cuda.current_stream() if self.cuda else None
+        ctxm = torch.cuda.stream(self.comm) if self.cuda else self.comm
+        with ctxm:
+            if wait_current and self.cuda:
+                self.comm.wait_stream(cur)
+            if join is not None:
+                join()
+            out = gather_audio_equal(self.bufs[k], self.world, self.rank, self.gbufs)
+            if self.on_gathered is not None and self.rank == 0:
+                self.on_gathered(j, out if self.world > 1 else [self.bufs[k]])
+            self.done[k].record(self.comm) if self.cuda else None
+        self.submitted += 1
+
+    def drain(self):
+        if self.active:
+            self.comm.synchronize()
+
+
 class StreamingVoiceConversionEngine:
     """The chunk loop of StreamingVoiceConversion.infer_once (inference/Conan.py:72-166) for many
     streams at once: mel in -> (wav, mel, codes) out, state carried in a conan_streams handle."""

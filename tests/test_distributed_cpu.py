@@ -52,3 +52,46 @@ def test_gather_audio_world2(total):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _ring_worker(rank, world, port, steps, q):
+    """The benchmark's step / gather choreography (bench.py: AudioGatherRing) on a gloo group with a stub engine: step j
+    of rank r "computes" audio filled with 1000 r + j into the ring buffer it was handed; rank 0 must receive every
+    rank's audio of every step, in step order, although buffers are reused every `nb` steps."""
+    from conan_amd.engine import AudioGatherRing
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def on_gathered(j, bufs):
+        seen.append((j, [float(b[0, 0]) for b in bufs], all(bool((b == b[0, 0]).all()) for b in bufs)))
+
+    ring = AudioGatherRing(lambda: torch.zeros(3, 16), world, rank, nb=4, on_gathered=on_gathered)
+    joined = []
+    for j in range(steps):
+        buf = ring.acquire(j)
+        buf.fill_(1000.0 * rank + j)                  # the "vocoder" of step j
+        ring.submit(j, join=lambda j=j: joined.append(j))
+    ring.drain()
+    dist.barrier()
+    dist.destroy_process_group()
+    ok = joined == list(range(steps)) and ring.submitted == steps
+    if rank == 0:
+        ok = ok and [s[0] for s in seen] == list(range(steps))
+        ok = ok and all(vals == [1000.0 * r + j for r in range(world)] and uniform for j, vals, uniform in seen)
+    else:
+        ok = ok and seen == []
+    q.put((rank, bool(ok)))
+
+
+def test_bench_gather_choreography_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
