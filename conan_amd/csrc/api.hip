@@ -122,7 +122,7 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
       s->sk_slab_floats = 8ll << 20; s->sk_max_tiles = 4096;
-      for (int w = 0; w < 2; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); }
+      for (int w = 0; w < 2; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); s->rb_sched[w] = (int*)s->alloc(4); }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);

@@ -97,8 +97,10 @@ struct RBProb {
 struct RBArgs {
   RBProb p[3];                        // the branches of a stage at one dilation index (inputs / outputs share their ring geometry's mode and rate)
   const int* slots; const int* pos;
-  const int* tiles;                   // filled by launch_resblock_fused: [grid][per] {branch, slot index, first row, 0}, branch -1 terminates
-  int per;
+  const int* tiles;                   // filled by launch_resblock_fused: [ntiles] {branch, slot index, first row, 0}, most expensive first
+  int ntiles;
+  int* sched;                         // work-queue state owned by the caller: 2 ints, zero before the first launch (re-armed by the kernel);
+                                      // one per stream that may have a fused launch in flight
   int nprob, n, T;                    // branches, slots in this batch, output rows per slot
   int tiles_per_slot;
   float slope;

@@ -147,17 +147,20 @@ template <int C, int NR2>
 __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) {
   using G = RBGeom<C, NR2>;
   constexpr int LDX = G::LDX;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 4];
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 4];      // + meta: {zero rows, next tile, its branch, draw generation}
   float* const win = lds;                              // [WR_MAX][LDX] leaky_relu(x) window
   float* const xt = lds + G::WR_MAX * LDX;             // [XT_ROWS][LDX] leaky_relu(c1 + b1); then c2's accumulators
-  int* const meta = reinterpret_cast<int*>(lds + G::LDS_FLOATS);   // [0]: zero rows of the staged tile's xt (stream start)
+  int* const meta = reinterpret_cast<int*>(lds + G::LDS_FLOATS);   // [0]: zero rows of the staged tile's xt (stream start); [1]: next tile index; [2]: its branch (-1: none)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // tile list of this block: {branch, slot index, first output row, -} per entry, branch = -1 terminates (two terminators)
+  // Work queue: a.tiles lists every tile {branch, slot index, first output row, -}, most expensive first.  Block b starts
+  // with tile b (the launch has at most one block per CU and no more blocks than tiles); further tiles are drawn from
+  // an agent-scope counter, so a block that was dispatched late (a CU held by another stream's kernel) simply takes
+  // fewer tiles instead of holding the launch back.  One helper lane draws, the block learns the tile through LDS.
   typedef const int __attribute__((address_space(1)))* gci;
-  const int* const mine = a.tiles + (long long)blockIdx.x * a.per * 4;
-  auto tile_word = [&](int it, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(mine + it * 4 + w)); };
+  auto tile_word = [&](int idx, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(a.tiles + (long long)idx * 4 + w)); };
+  const int ntiles = a.ntiles;
   const float slope = a.slope;
   const int T = a.T;
 
@@ -240,36 +243,58 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
                   make_float4((oacc[u].x + ob2.x) + ores[u].x, (oacc[u].y + ob2.y) + ores[u].y, (oacc[u].z + ob2.z) + ores[u].z, (oacc[u].w + ob2.w) + ores[u].w));
       }
     };
-    int p = tile_word(0, 0), i = tile_word(0, 1), t0 = tile_word(0, 2);
+    int p = tile_word(blockIdx.x, 0), i = tile_word(blockIdx.x, 1), t0 = tile_word(blockIdx.x, 2);
     int slot = slot_of(i), pos = pos_of(slot);
+    if (ht == 0) meta[3] = 0;
 #if !(RB_ABLATE & 1)
     load_window(p, i, t0, slot, pos);
 #endif
     hbar();                                              // B0: first window staged
     bool pending = false;                                // a fetched output tile waits for its stores
-    for (int it = 0;; ++it) {
-      // the next tile's descriptor: plain loads now, scalarised (waited for) only after B3
-      const int pn_v = *(gci)(mine + (it + 1) * 4), in_v = *(gci)(mine + (it + 1) * 4 + 1), t0n_v = *(gci)(mine + (it + 1) * 4 + 2);
+    int gen = 1;                                         // generation of the published draw (meta[3])
+    for (;;) {
       hbar();                                            // B3: the previous tile's accumulators are in registers (out_fetch)
-      const int pn = __builtin_amdgcn_readfirstlane(pn_v), in = __builtin_amdgcn_readfirstlane(in_v), t0n = __builtin_amdgcn_readfirstlane(t0n_v);
-      int slotn = 0, posn = 0;
-      if (pn >= 0) { slotn = slot_of(in); posn = pos_of(slotn); }
       hbar();                                            // B1: xt complete, window free
+      // Draw the next tile now - half way through this one, not at its start: blocks on short tiles then draw before
+      // blocks on long ones, which keeps the longest-first list scheduling balanced (drawn at the start, the blocks
+      // still busy with an 11-tap tile would take the last 3-tap tiles from those that finish early).  Every helper
+      // wave's lane 0 would be one draw too many: wave 4 draws and publishes {index, branch} through LDS; the other
+      // helper waves poll the generation word (s_barrier is block wide, there is no helper-only rendezvous); the
+      // matrix waves read it after B4.
+      int nv = 0;
+      if (wave == 4 && lane == 0) nv = (int)gridDim.x + __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if RB_ABLATE & 4
       const unsigned long long h0 = __builtin_amdgcn_s_memtime();
 #endif
 #if !(RB_ABLATE & 2)
-      if (pending) out_store();                          // (its loads were issued a whole c1 phase ago)
+      if (pending) out_store();                          // (its loads were issued a whole c1 phase ago); the draw returns meanwhile
 #endif
 #if RB_ABLATE & 4
       const unsigned long long h1 = __builtin_amdgcn_s_memtime();
 #endif
+      int nidx, pn;
+      if (wave == 4) {
+        int pv = -1;
+        if (lane == 0) pv = nv < ntiles ? *(gci)(a.tiles + (long long)nv * 4) : -1;
+        nidx = __builtin_amdgcn_readfirstlane(nv); pn = __builtin_amdgcn_readfirstlane(pv);
+        if (lane == 0) {
+          meta[1] = nidx; meta[2] = pn;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(&meta[3], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        while (__hip_atomic_load(&meta[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen) __builtin_amdgcn_s_sleep(8);
+        nidx = __builtin_amdgcn_readfirstlane(meta[1]); pn = __builtin_amdgcn_readfirstlane(meta[2]);
+      }
+      ++gen;
+      int in = 0, t0n = 0, slotn = 0, posn = 0;
+      if (pn >= 0) { in = tile_word(nidx, 1); t0n = tile_word(nidx, 2); slotn = slot_of(in); posn = pos_of(slotn); }
 #if !(RB_ABLATE & 1)
       if (pn >= 0) load_window(pn, in, t0n, slotn, posn);
 #endif
 #if RB_ABLATE & 4
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (a.dbg && blockIdx.x == 0 && ht == 0 && it < 4) { unsigned long long* q = a.dbg + 256 * 4 + 4 + it * 2; q[0] = h1 - h0; q[1] = __builtin_amdgcn_s_memtime() - h1; }
+      if (a.dbg && blockIdx.x == 0 && ht == 0) { unsigned long long* q = a.dbg + 256 * 4 + 4; q[0] = h1 - h0; q[1] = __builtin_amdgcn_s_memtime() - h1; }
 #endif
       hbar();                                            // B4
       hbar();                                            // B2: c2 accumulators in LDS, next window staged
@@ -283,6 +308,14 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #if !(RB_ABLATE & 2)
     if (pending) out_store();
 #endif
+    // the last block to leave re-arms the queue for the next launch
+    if (ht == 0) {
+      const int d = __hip_atomic_fetch_add(a.sched + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == (int)gridDim.x - 1) {
+        __hip_atomic_store(a.sched, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sched + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
 
@@ -299,19 +332,18 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #define RB_T() __builtin_amdgcn_s_memtime()
 #endif
   float4 bw[G::KQ][G::NCW];
-  int p = tile_word(0, 0);
+  int p = tile_word(blockIdx.x, 0);
   {
     const long long cs = (long long)(RB_SEL(p, k) + 1) * G::KQ * 256;
     rb_prefetch_w<G::NCW, G::KQ>(bw, RB_SEL(p, w1) + (long long)ct0 * cs + lane * 4, cs);
   }
   bar();                                                 // B0: first window staged
-  for (int it = 0; p >= 0; ++it) {
+  while (p >= 0) {
     const int k = RB_SEL(p, k), d = RB_SEL(p, dil);
     const float* const w1 = RB_SEL(p, w1);
     const float* const w2 = RB_SEL(p, w2);
     const float* const b1 = RB_SEL(p, b1);
     const long long ct_stride = (long long)(k + 1) * G::KQ * 256;       // floats per column tile (k taps + one zero tap)
-    const int pn_v = *(gci)(mine + (it + 1) * 4);        // next tile's branch: the load flies until it is used after c2
     const int zrows = __builtin_amdgcn_readfirstlane(meta[0]);
     float b1v[G::NCW];
     int pn;
@@ -373,12 +405,10 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #if RB_ABLATE & 4
       unsigned long long s0 = RB_T();
 #endif
-      // the next tile's branch (loaded at the top of this tile): its first c1 weights follow this phase's last tap
-      pn = __builtin_amdgcn_readfirstlane(pn_v);
-      const int pq = pn >= 0 ? pn : p;
-      const long long csn = (long long)(RB_SEL(pq, k) + 1) * G::KQ * 256;
+      // (behind the last tap the weight registers are refilled with this phase's tap 0 again: harmless, the next tile
+      // is only known after B4)
       rb_gemm<G::NRW2, G::NCW, LDX, G::KQ>(xt, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 4, ct_stride,
-                                           RB_SEL(pq, w1) + (long long)ct0 * csn + lane * 4, csn, acc, bw, lane);
+                                           w2 + (long long)ct0 * ct_stride + lane * 4, ct_stride, acc, bw, lane);
 #if RB_ABLATE & 4
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
       unsigned long long s1 = RB_T(); st_gemm += s1 - s0;
@@ -388,6 +418,12 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #else
       bar();                                             // B4: every matrix wave is done reading xt
 #endif
+      // the next tile (drawn by the helpers after B1): its first c1 weight fragments fly across the accumulator hand-off
+      pn = __builtin_amdgcn_readfirstlane(meta[2]);
+      if (pn >= 0) {
+        const long long csn = (long long)(RB_SEL(pn, k) + 1) * G::KQ * 256;
+        rb_prefetch_w<G::NCW, G::KQ>(bw, RB_SEL(pn, w1) + (long long)ct0 * csn + lane * 4, csn);
+      }
 #pragma unroll
       for (int c = 0; c < G::NCW; ++c) {
         const int col = (ct0 + c) * 16 + lr;
@@ -440,46 +476,34 @@ int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu) {
   return best;
 }
 
-// Balanced static schedule: tiles sorted by cost, longest first, each to the least loaded block; per block a list of
-// {branch, slot index, first row, 0} descriptors closed by two {-1,..} entries; cached per shape in device memory (a
-// handful of shapes per model and device, never freed).
-static const int* rb_schedule(const RBArgs& a, int grid, int ro, int* per_out) {
+// Tile list of a launch shape: {branch, slot index, first row, 0} per tile, most expensive branch first (the blocks draw
+// from it in order: longest-processing-time-first list scheduling); cached per shape in device memory (a handful of
+// shapes per model and device, never freed).
+static const int* rb_tiles(const RBArgs& a, int ro, int* total_out) {
   struct Key { int v[10]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
   static std::map<Key, std::pair<const int*, int>> cache;
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
-  Key key = {{grid, a.nprob, a.n, a.tiles_per_slot, a.p[0].k, a.nprob > 1 ? a.p[1].k : 0, a.nprob > 2 ? a.p[2].k : 0, dev, ro, 0}};
+  Key key = {{a.nprob, a.n, a.tiles_per_slot, a.p[0].k, a.nprob > 1 ? a.p[1].k : 0, a.nprob > 2 ? a.p[2].k : 0, dev, ro, 0, 0}};
   auto it = cache.find(key);
-  if (it != cache.end()) { *per_out = it->second.second; return it->second.first; }
+  if (it != cache.end()) { *total_out = it->second.second; return it->second.first; }
   const int per_prob = a.n * a.tiles_per_slot, total = a.nprob * per_prob;
   std::vector<int> order(total);
   for (int i = 0; i < total; ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a.p[x / per_prob].k > a.p[y / per_prob].k; });
-  typedef std::pair<long long, int> Bin;
-  std::priority_queue<Bin, std::vector<Bin>, std::greater<Bin>> heap;
-  for (int b = 0; b < grid; ++b) heap.push({0, b});
-  std::vector<std::vector<int>> lists(grid);
-  for (int id : order) {
-    Bin top = heap.top(); heap.pop();
-    lists[top.second].push_back(id);
-    heap.push({top.first + a.p[id / per_prob].k * 8 + 3, top.second});
+  std::vector<int> flat((size_t)(total + 1) * 4, -1);
+  for (int e = 0; e < total; ++e) {
+    const int id = order[e], p = id / per_prob, rem = id - p * per_prob, i = rem / a.tiles_per_slot;
+    int* d = flat.data() + (size_t)e * 4;
+    d[0] = p; d[1] = i; d[2] = (rem - i * a.tiles_per_slot) * ro; d[3] = 0;
   }
-  size_t per = 1;
-  for (auto& l : lists) per = std::max(per, l.size() + 2);
-  std::vector<int> flat((size_t)grid * per * 4, -1);
-  for (int b = 0; b < grid; ++b)
-    for (size_t e = 0; e < lists[b].size(); ++e) {
-      const int id = lists[b][e], p = id / per_prob, rem = id - p * per_prob, i = rem / a.tiles_per_slot;
-      int* d = flat.data() + ((size_t)b * per + e) * 4;
-      d[0] = p; d[1] = i; d[2] = (rem - i * a.tiles_per_slot) * ro; d[3] = 0;
-    }
   int* d = nullptr;
-  if (hipMalloc(&d, flat.size() * sizeof(int)) != hipSuccess) { *per_out = 0; return nullptr; }
+  if (hipMalloc(&d, flat.size() * sizeof(int)) != hipSuccess) { *total_out = 0; return nullptr; }
   (void)hipMemcpy(d, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice);
-  cache[key] = {d, (int)per};
-  *per_out = (int)per;
+  cache[key] = {d, total};
+  *total_out = total;
   return d;
 }
 
@@ -490,8 +514,9 @@ static bool launch_rb(const RBArgs& ain, int num_cu, hipStream_t st) {
   a.tiles_per_slot = (a.T + ro - 1) / ro;
   const int total = a.nprob * a.n * a.tiles_per_slot;
   if (total <= 0) return true;
+  if (!a.sched) return false;
   const int grid = std::min(total, num_cu);
-  a.tiles = rb_schedule(a, grid, ro, &a.per);
+  a.tiles = rb_tiles(a, ro, &a.ntiles);
   if (!a.tiles) return false;
   hipLaunchKernelGGL((resblock_fused_kernel<C, NR2>), dim3(grid), dim3(512), 0, st, a);
   return true;

@@ -70,6 +70,7 @@ struct conan_streams {
   // two concurrently, and both split K at small batch sizes)
   float* sk_slab[2] = {nullptr, nullptr};
   int* sk_counters[2] = {nullptr, nullptr};
+  int* rb_sched[2] = {nullptr, nullptr};   // work-queue counters of the fused resblock launches, per stream like the split-K workspaces
   long long sk_slab_floats = 0;
   int sk_max_tiles = 0;
   std::vector<int> h_slots;

@@ -101,6 +101,7 @@ void conan_streams::profiled(const std::string& name, double flops, hipStream_t 
 // one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
 void conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st) {
   cnk::RBArgs a = ain;
+  a.sched = rb_sched[(st_voc != nullptr && st == st_voc) ? 1 : 0];
   int ksum = 0, kmax = 0;
   double fl = 0.0;
   for (int p = 0; p < a.nprob; ++p) { ksum += a.p[p].k; kmax = std::max(kmax, a.p[p].k); fl += 2.0 * 2.0 * (double)a.n * a.T * C * C * a.p[p].k; }

@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
       unsigned long long* ddbg = nullptr;
       CHECK(hipMalloc(&ddbg, 260 * 4 * 8)); CHECK(hipMemset(ddbg, 0, 260 * 4 * 8));
       a.dbg = ddbg;
+      int* dsched; CHECK(hipMalloc(&dsched, 8)); CHECK(hipMemset(dsched, 0, 8)); a.sched = dsched;
       const int rows = getenv("RB_ROWS") && C == 64 ? atoi(getenv("RB_ROWS")) : cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu);
       if (!cnk::launch_resblock_fused(a, C, rows, num_cu, 0)) { printf("launch failed\n"); return 1; }
       CHECK(hipDeviceSynchronize());
@@ -139,7 +140,7 @@ int main(int argc, char** argv) {
           printf("   stamps (%d blocks): gemm %.0f cyc = %.1f%% of block life, barriers %.1f%%, life %.0f cyc = %.1f us avg / %.1f us max, clock %.2f GHz\n", nb, g / nb, 100 * g / t,
                  100 * bw / t, t / nb, r / nb / 100.0, tmax / 100.0, (t / nb) / (r / nb / 100.0) / 1e3);
           printf("   block 0 barrier cycles: B3 %llu  B1 %llu  B4 %llu  B2 %llu\n", hd[1024], hd[1025], hd[1026], hd[1027]);
-          printf("   block 0 helper after B1: store/window cycles per tile: %llu/%llu %llu/%llu %llu/%llu\n", hd[1028], hd[1029], hd[1030], hd[1031], hd[1032], hd[1033]);
+
         }
       }
       CHECK(hipFree(ddbg));
