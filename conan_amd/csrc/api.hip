@@ -122,7 +122,9 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
       s->sk_slab_floats = 8ll << 20; s->sk_max_tiles = 4096;
-      for (int w = 0; w < 2; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); s->rb_sched[w] = (int*)s->alloc(4); }
+      for (int w = 0; w < 3; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); }
+      for (int w = 0; w < 2; ++w) s->rb_sched[w] = (int*)s->alloc(4);
+      { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
@@ -326,19 +328,34 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     HIP_CHECK(hipSetDevice(s->ctx->device));
     s->async_init();
     const long long t = s->async_steps;
-    const int p = (int)(t & 1);
+    constexpr int NP = conan_streams::NP;
+    const int p = (int)(t % NP), pl = (int)((t + NP - 1) % NP);      // hand-off ring positions of this step and of the previous one
+    // Three stages on three internal streams: Emformer(t) -> codes, decoder(t) -> mel, vocoder(t) -> audio.  With steps
+    // issued back to back the stages work on consecutive chunks at the same time (Emformer of chunk t+2 beside the decoder
+    // of t+1 beside the vocoder of t): the decoder's ~50 latency-bound launches no longer queue behind the Emformer's
+    // one long launch, and their tail no longer leaves the vocoder stream idle.
     // inputs are ready in the caller's stream order
     HIP_CHECK(hipEventRecord(s->ev_in, (hipStream_t)stream));
-    HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_in, 0));
-    // the hand-off buffer of this parity is free once the vocoder of step t-2 has copied it into its ring
-    if (t >= 2) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p], 0));
-    // a changed slot list rewrites the table the in-flight vocoder still reads: drain it first
+    HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_in, 0));
+    // a changed slot list rewrites the table the in-flight decoder / vocoder still read: drain them first
     bool same = (int)s->h_slots.size() == n;
     for (int i = 0; same && i < n; ++i) same = s->h_slots[i] == slots[i];
-    if (!same && t >= 1) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p ^ 1], 0));
-    s->set_slots(slots, n, s->st_front);
-    int* codes_seg = codes_dev ? codes_dev : s->d_codes;
-    s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_front);
+    if (!same && t >= 1) {
+      HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_front[pl], 0));
+      HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_voc[pl], 0));
+    }
+    s->set_slots(slots, n, s->st_emf);
+    // the code buffer at this ring position is free once the decoder of step t-NP has read it: the Emformer may run
+    // NP steps ahead of the decoder (it is dispatched late - its 129 KB of LDS per block only fit on CUs that a vocoder
+    // launch has left - so the decoder must not have to wait for the Emformer of its own chunk)
+    if (t >= NP) HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_front[p], 0));
+    int* codes_seg = s->codes_hand[p];
+    s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_emf);
+    HIP_CHECK(hipEventRecord(s->ev_emf[p], s->st_emf));
+    HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_emf[p], 0));
+    // the mel hand-off buffer at this ring position is free once the vocoder of step t-NP has copied it into its ring
+    if (t >= NP) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p], 0));
+    if (codes_dev) HIP_CHECK(hipMemcpyAsync(codes_dev, codes_seg, (size_t)n * seg * sizeof(int), hipMemcpyDeviceToDevice, s->st_front));
     const int* codes_emit = codes_seg;
     if (emit != seg && n > 1) {
       int* compact = s->d_codes + (size_t)s->max_slots * s->max_frames;

@@ -66,10 +66,11 @@ struct conan_streams {
   int* d_lens2 = nullptr;
   int* d_codes = nullptr;   // [max_slots][max_frames] codes scratch for the fused step
   // inter-block split-K workspaces (partial tiles + ticket counters), one per stream that can have conv launches in
-  // flight: [0] the caller's stream and the pipelined front-end, [1] the pipelined vocoder (conan_step_async runs the
-  // two concurrently, and both split K at small batch sizes)
-  float* sk_slab[2] = {nullptr, nullptr};
-  int* sk_counters[2] = {nullptr, nullptr};
+  // flight (ws_index): the caller's stream / pipelined decoder, the pipelined vocoder, the pipelined Emformer
+  // (conan_step_async runs the three concurrently, and all split K at small batch sizes)
+  float* sk_slab[3] = {nullptr, nullptr, nullptr};
+  int* sk_counters[3] = {nullptr, nullptr, nullptr};
+  int reserve_cus = 0;                     // CUs the pipelined vocoder's persistent launches leave to the front-end stream (CONAN_RESERVE_CUS)
   int* rb_sched[2] = {nullptr, nullptr};   // work-queue counters of the fused resblock launches, per stream like the split-K workspaces
   long long sk_slab_floats = 0;
   int sk_max_tiles = 0;
@@ -129,18 +130,23 @@ struct conan_streams {
     return l;
   }
   // --- pipelined stepping (conan_step_async): front-end (Emformer + decoder) and vocoder on two internal streams
-  hipStream_t st_front = nullptr, st_voc = nullptr;
-  hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_voc[2] = {nullptr, nullptr};
-  float* mel_hand[2] = {nullptr, nullptr};     // mel hand-off buffers [max_slots][max_frames][num_mels]
+  hipStream_t st_emf = nullptr, st_front = nullptr, st_voc = nullptr;
+  static constexpr int NP = 4;                 // depth of the hand-off rings: a stage may run up to NP steps ahead of its consumer
+  hipEvent_t ev_in = nullptr, ev_emf[NP] = {}, ev_front[NP] = {}, ev_voc[NP] = {};
+  int* codes_hand[NP] = {};                    // code hand-off buffers Emformer -> decoder [max_slots][segment]
+  // workspace index of a stream: 0 caller / pipelined decoder, 1 pipelined vocoder, 2 pipelined Emformer
+  int ws_index(hipStream_t st) const { return (st_voc && st == st_voc) ? 1 : ((st_emf && st == st_emf) ? 2 : 0); }
+  float* mel_hand[NP] = {};                    // mel hand-off buffers decoder -> vocoder [max_slots][max_frames][num_mels]
   long long async_steps = 0;                   // steps enqueued since creation
   void async_init();
   void join(hipStream_t st);                   // make `st` wait for everything enqueued by conan_step_async
 
   ~conan_streams() {
+    if (st_emf) (void)hipStreamDestroy(st_emf);
     if (st_front) (void)hipStreamDestroy(st_front);
     if (st_voc) (void)hipStreamDestroy(st_voc);
     if (ev_in) (void)hipEventDestroy(ev_in);
-    for (int i = 0; i < 2; ++i) { if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
+    for (int i = 0; i < NP; ++i) { if (ev_emf[i]) (void)hipEventDestroy(ev_emf[i]); if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }

@@ -58,7 +58,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
-  const int wsi = (st_voc != nullptr && st == st_voc) ? 1 : 0;
+  const int wsi = ws_index(st);
   g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1;
   if (nprob == 1 && cnk::conv_cfg_tm(cfg) == 32) {
     const ConvArgs& a = g.p[0];
@@ -76,7 +76,9 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   }
   double fl = 0.0;
   for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
-  profiled(cnk::conv_cfg_name(cfg), fl, st, [&] { cnk::launch_conv(g, nprob, cfg, st, ctx->num_cu); });
+  // (pipelined vocoder: its persistent launches leave `reserve_cus` CUs to the other internal streams, see launch_rb)
+  const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
+  profiled(cnk::conv_cfg_name(cfg), fl, st, [&] { cnk::launch_conv(g, nprob, cfg, st, cus); });
 }
 
 // every launch of the matrix kernels goes through here: between conan_profile_begin / _end it is bracketed by HIP
@@ -101,13 +103,17 @@ void conan_streams::profiled(const std::string& name, double flops, hipStream_t 
 // one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
 void conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st) {
   cnk::RBArgs a = ain;
-  a.sched = rb_sched[(st_voc != nullptr && st == st_voc) ? 1 : 0];
+  a.sched = rb_sched[ws_index(st) == 1 ? 1 : 0];
   int ksum = 0, kmax = 0;
   double fl = 0.0;
   for (int p = 0; p < a.nprob; ++p) { ksum += a.p[p].k; kmax = std::max(kmax, a.p[p].k); fl += 2.0 * 2.0 * (double)a.n * a.T * C * C * a.p[p].k; }
-  const int rows = cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, ctx->num_cu);
+  // CUs left to the other internal stream while a pipelined step is in flight (conan_step_async): the persistent
+  // blocks of this launch hold their CU for its whole duration, so without a few free CUs every one of the ~60
+  // dependent front-end launches of the next chunk waits for a vocoder kernel boundary
+  const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
+  const int rows = cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
   profiled(cnk::resblock_fused_name(C, rows), fl, st, [&] {
-    if (!cnk::launch_resblock_fused(a, C, rows, ctx->num_cu, st)) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
+    if (!cnk::launch_resblock_fused(a, C, rows, cus, st)) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
   });
 }
 
@@ -132,10 +138,26 @@ void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
 
 void conan_streams::async_init() {
   if (st_front) return;
-  HIP_CHECK(hipStreamCreateWithFlags(&st_front, hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&st_voc, hipStreamNonBlocking));
+  {
+    // CONAN_FRONT_PRIO: 1 = front-end stream at the highest priority, -1 = at the lowest, 0 = default (experiment knob)
+    int lo = 0, hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* e = getenv("CONAN_FRONT_PRIO");
+    const int mode = e ? atoi(e) : 0;
+    if (mode == 0) {
+      HIP_CHECK(hipStreamCreateWithFlags(&st_front, hipStreamNonBlocking));
+      HIP_CHECK(hipStreamCreateWithFlags(&st_voc, hipStreamNonBlocking));
+      HIP_CHECK(hipStreamCreateWithFlags(&st_emf, hipStreamNonBlocking));
+    } else {
+      HIP_CHECK(hipStreamCreateWithPriority(&st_emf, hipStreamNonBlocking, mode > 0 ? hi : lo));
+      HIP_CHECK(hipStreamCreateWithPriority(&st_front, hipStreamNonBlocking, mode > 0 ? hi : lo));
+      HIP_CHECK(hipStreamCreateWithPriority(&st_voc, hipStreamNonBlocking, mode > 0 ? lo : hi));
+    }
+  }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NP; ++i) {
+    HIP_CHECK(hipEventCreateWithFlags(&ev_emf[i], hipEventDisableTiming));
+    codes_hand[i] = (int*)alloc((size_t)max_slots * max_frames);
     HIP_CHECK(hipEventCreateWithFlags(&ev_front[i], hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_voc[i], hipEventDisableTiming));
     mel_hand[i] = alloc((size_t)max_slots * max_frames * ctx->cfg.num_mels);
@@ -144,7 +166,8 @@ void conan_streams::async_init() {
 
 void conan_streams::join(hipStream_t st) {
   if (async_steps == 0) return;
-  const int last = (int)((async_steps - 1) & 1);       // both internal streams are in-order: the last step covers all
+  const int last = (int)((async_steps - 1) % NP);       // the internal streams are in-order: the last step covers all
+  HIP_CHECK(hipStreamWaitEvent(st, ev_emf[last], 0));
   HIP_CHECK(hipStreamWaitEvent(st, ev_front[last], 0));
   HIP_CHECK(hipStreamWaitEvent(st, ev_voc[last], 0));
 }
