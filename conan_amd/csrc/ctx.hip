@@ -78,6 +78,29 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
   convs[name] = pc;
 }
 
+// Fragment-major copy of an already packed conv for rowconv.hip: per 16-column tile, per tap (k taps + one zero tap),
+// per 16-deep K group one 1 KiB MFMA B operand (lane (g, n): W[tap][cin = 16 q + 4 g + s][cout = 16 ct + n], s = 0..3);
+// columns padded to a multiple of 64 (256 for the wide layers, which run 4 column tiles per wave).
+void conan_ctx::add_rowconv_weights(const std::string& name, const std::vector<float>& W) {
+  PackedConv& pc = convs.at(name);
+  const int Cin = pc.Cin, Cout = pc.Cout, k = pc.k;
+  if (Cin % 64 || Cin > 512 || pc.shuffle_r != 1) return;
+  const int KQ = Cin / 16;
+  if (KQ & (KQ - 1)) return;
+  const int cpad = ch::round_up(Cout, Cout >= 1024 ? 256 : 64), NCT = cpad / 16;
+  std::vector<float> out((size_t)NCT * (k + 1) * KQ * 256, 0.f);
+  for (int ct = 0; ct < NCT; ++ct)
+    for (int j = 0; j < k; ++j)
+      for (int q = 0; q < KQ; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int ci = q * 16 + 4 * (lane >> 4) + s, co = ct * 16 + (lane & 15);
+            if (co < Cout) out[(((size_t)ct * (k + 1) + j) * KQ + q) * 256 + lane * 4 + s] = W[((size_t)co * Cin + ci) * k + j];
+          }
+  pc.wf = upload(out);
+  pc.wf_cout_pad = cpad;
+}
+
 void conan_ctx::pack_from_keys(const std::string& name, const std::string& wkey, const std::string& bkey, int shuffle_r) {
   const HostTensor& w = get(wkey);
   if (w.shape.size() != 2 && w.shape.size() != 3) throw Error(CONAN_ERR_SHAPE, "bad weight rank: " + wkey);
@@ -85,6 +108,10 @@ void conan_ctx::pack_from_keys(const std::string& name, const std::string& wkey,
   const float* b = nullptr;
   if (!bkey.empty()) { const HostTensor& bt = get(bkey); if (bt.numel() != Cout) throw Error(CONAN_ERR_SHAPE, "bad bias: " + bkey); b = bt.data.data(); }
   pack_conv(name, w.data, b, Cout, Cin, k, shuffle_r);
+  // the frame-rate layers of the decoder step also get the rowconv layout
+  if (name.rfind("conan.dec.", 0) == 0 || name.rfind("conan.uv.", 0) == 0 || name == "conan.content_proj" || name == "conan.mel_out" ||
+      (name.rfind("conan.align.", 0) == 0 && name.find(".kv") == std::string::npos))
+    add_rowconv_weights(name, w.data);
 }
 
 // weight_norm fold: w = g * v / ||v||_2 per output channel (torch._weight_norm(v, g, 0));
@@ -286,6 +313,7 @@ void conan_ctx::finalize_conan() {
     std::vector<float> wq(w.data.begin(), w.data.begin() + (size_t)H * H);
     std::vector<float> wkv(w.data.begin() + (size_t)H * H, w.data.end());
     pack_conv(n + ".q", wq, b.data.data(), H, H, 1);
+    add_rowconv_weights(n + ".q", wq);
     pack_conv(n + ".kv", wkv, b.data.data() + H, 2 * H, H, 1);
     pack_from_keys(n + ".out", p + ".multihead_attn.out_proj.weight", p + ".multihead_attn.out_proj.bias");
     pack_from_keys(n + ".ff1", p + ".linear1.weight", p + ".linear1.bias");

@@ -25,7 +25,16 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     cnk::launch_embed(a, st);
   }
   // content_proj: CausalConv1d k3 + LeakyReLU(0.01) (Conan.py:57-60, :142); pitch_inp = content + style (Conan.py:162)
-  {
+  if (rowconv_ok(ctx->conv("conan.content_proj"), 1, T)) {
+    cnk::RowConvArgs a = mk_rc(ctx->conv("conan.content_proj"), c_emb.ref(), c_pin.ref(), n, T);
+    a.out_act = cnk::ACT_LRELU; a.out_slope = 0.01f; a.bvec = c_style; a.bvec_stride = H;
+    rowconv(a, st);
+    if (taps.content_embed_proj) {
+      cnk::RowConvArgs t = mk_rc(ctx->conv("conan.content_proj"), c_emb.ref(), ch::lin_ref(taps.content_embed_proj, T, H), n, T);
+      t.out_act = cnk::ACT_LRELU; t.out_slope = 0.01f;
+      rowconv(t, st);
+    }
+  } else {
     ConvArgs a = mk(ctx->conv("conan.content_proj"), c_emb.ref(), c_pin.ref(), n, T, pos);
     a.out_act = cnk::ACT_LRELU; a.out_slope = 0.01f; a.bvec = c_style; a.bvec_stride = H;
     conv(a, st);
@@ -40,16 +49,19 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   Lin* src = &c_pin;
   for (int l = 0; l < 2; ++l) {
     const std::string nm = "conan.align." + std::to_string(l);
-    { ConvArgs a = mk(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T, pos); a.out_scale = (float)std::sqrt(1.0 / (double)dh); conv(a, st); }
+    if (rowconv_ok(ctx->conv(nm + ".q"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T); a.out_scale = (float)std::sqrt(1.0 / (double)dh); rowconv(a, st); }
+    else { ConvArgs a = mk(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T, pos); a.out_scale = (float)std::sqrt(1.0 / (double)dh); conv(a, st); }
     {
       cnk::XAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = c_q.ref(); a.out = c_att.ref(); a.kv = c_kv + (size_t)l * S_max * 2 * H; a.kv_slot_stride = (long long)2 * S_max * 2 * H;
       a.kmask = c_kmask; a.slen = c_slen; a.attn_avg = taps.attn[l]; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.E = H; a.H = nh; a.S_max = S_max;
       cnk::launch_xattn(a, st);
     }
-    { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }
+    if (rowconv_ok(ctx->conv(nm + ".out"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T); a.res = src->ref(); a.has_res = 1; rowconv(a, st); }
+    else { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }
     cnk::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
-    { ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st); }
+    if (rowconv_ok(ctx->conv(nm + ".ff1"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T); a.out_act = cnk::ACT_RELU; rowconv(a, st); }
+    else { ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st); }
     { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
     cnk::LNArgs ln = mk_ln(c_q.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
     if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
@@ -60,7 +72,9 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   for (int i = 0; i < 5; ++i) {
     const TRef xin = i == 0 ? c_pin2.ref() : c_uvh[i - 1].ref();
     const TRef yout = i == 4 ? c_uv5.ref() : c_uvh[i].ref();
-    ConvArgs a = mk(ctx->conv("conan.uv." + std::to_string(i)), xin, yout, n, T, pos);
+    const PackedConv& pc = ctx->conv("conan.uv." + std::to_string(i));
+    if (rowconv_ok(pc, 1, T)) { cnk::RowConvArgs a = mk_rc(pc, xin, yout, n, T); a.out_act = cnk::ACT_RELU; rowconv(a, st); continue; }
+    ConvArgs a = mk(pc, xin, yout, n, T, pos);
     a.out_act = cnk::ACT_RELU;
     conv(a, st);
   }
@@ -85,6 +99,21 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     for (int j = 0; j < c.dec_layers_in_block; ++j) {
       const std::string nm = "conan.dec." + std::to_string(b) + "." + std::to_string(j);
       Ring& lr = c_lnrs[b * c.dec_layers_in_block + j];
+      const bool last_sub = b == c.dec_num_blocks - 1 && j == c.dec_layers_in_block - 1;
+      if (rowconv_ok(ctx->conv(nm + ".c1"), c.dec_dilations[b], T) && rowconv_ok(ctx->conv(nm + ".c2"), 1, T)) {
+        // LayerNorm (prologue: new rows normalised in LDS and appended to the layer's ring) -> k5 conv -> x k^-0.5 -> GELU
+        cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".c1"), c_x[cur].ref(), c_h.ref(), n, T, c.dec_dilations[b]);
+        a.ln = 1; a.hist = lr.ref(); a.gamma = ctx->vec(nm + ".ln.g"); a.beta = ctx->vec(nm + ".ln.b");
+        if (j == 0) { a.mask_out = blkmask; a.has_mask_out = 1; }
+        a.out_scale = kscale; a.out_act = cnk::ACT_GELU;
+        rowconv(a, st);
+        cnk::RowConvArgs a2 = mk_rc(ctx->conv(nm + ".c2"), c_h.ref(), c_x[cur ^ 1].ref(), n, T);
+        a2.res = c_x[cur].ref(); a2.has_res = 1; a2.m1 = blkmask; a2.has_m1 = 1;
+        if (last_sub) { a2.m2 = c_mask_out.ref(); a2.has_m2 = 1; }
+        rowconv(a2, st);
+        cur ^= 1;
+        continue;
+      }
       cnk::LNArgs ln = mk_ln(c_x[cur].ref(), lr.ref(), ctx->vec(nm + ".ln.g"), ctx->vec(nm + ".ln.b"), d_slots, pos, n, T, H);
       if (j == 0) { ln.mask_out = blkmask; ln.has_mask_out = 1; }
       cnk::launch_layernorm(ln, st);
@@ -92,19 +121,25 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
       {
         ConvArgs a = mk(ctx->conv(nm + ".c2"), c_h.ref(), c_x[cur ^ 1].ref(), n, T, pos);
         a.res = c_x[cur].ref(); a.has_res = 1; a.m1 = blkmask; a.has_m1 = 1;
-        if (b == c.dec_num_blocks - 1 && j == c.dec_layers_in_block - 1) { a.m2 = c_mask_out.ref(); a.has_m2 = 1; }
+        if (last_sub) { a.m2 = c_mask_out.ref(); a.has_m2 = 1; }
         conv(a, st);
       }
       cur ^= 1;
     }
   }
-  {
+  if (rowconv_ok(ctx->conv("conan.dec.post"), 1, T)) {   // last LayerNorm (x mask) as the prologue of the post conv
+    cnk::RowConvArgs a = mk_rc(ctx->conv("conan.dec.post"), c_x[cur].ref(), c_post.ref(), n, T);
+    a.ln = 1; a.hist = c_lastr.ref(); a.gamma = ctx->vec("conan.dec.last.g"); a.beta = ctx->vec("conan.dec.last.b");
+    a.lnmask = c_mask_out.ref(); a.has_lnmask = 1; a.m1 = c_mask_out.ref(); a.has_m1 = 1;
+    rowconv(a, st);
+  } else {
     cnk::LNArgs ln = mk_ln(c_x[cur].ref(), c_lastr.ref(), ctx->vec("conan.dec.last.g"), ctx->vec("conan.dec.last.b"), d_slots, pos, n, T, H);
     ln.m1 = c_mask_out.ref(); ln.has_m1 = 1;
     cnk::launch_layernorm(ln, st);
+    ConvArgs a = mk(ctx->conv("conan.dec.post"), c_lastr.ref(), c_post.ref(), n, T, pos); a.m1 = c_mask_out.ref(); a.has_m1 = 1; conv(a, st);
   }
-  { ConvArgs a = mk(ctx->conv("conan.dec.post"), c_lastr.ref(), c_post.ref(), n, T, pos); a.m1 = c_mask_out.ref(); a.has_m1 = 1; conv(a, st); }
-  conv(mk(ctx->conv("conan.mel_out"), c_post.ref(), ch::lin_ref(mel_out, T, c.num_mels), n, T, pos), st);
+  if (rowconv_ok(ctx->conv("conan.mel_out"), 1, T)) rowconv(mk_rc(ctx->conv("conan.mel_out"), c_post.ref(), ch::lin_ref(mel_out, T, c.num_mels), n, T), st);
+  else conv(mk(ctx->conv("conan.mel_out"), c_post.ref(), ch::lin_ref(mel_out, T, c.num_mels), n, T, pos), st);
   cnk::launch_advance(pos_dec, d_slots, n, T, st);
 }
 

@@ -37,6 +37,8 @@ struct PackedConv {
   float* bias = nullptr;   // [Cout_pad] (zeros when the layer has no bias)
   int Cin = 0, Cin_pad = 0, Cin_alloc = 0, Cout = 0, Cout_pad = 0, k = 1;
   int shuffle_r = 1;
+  float* wf = nullptr;     // fragment-major copy for rowconv.hip (decoder-step layers only), Cout padded to wf_cout_pad
+  int wf_cout_pad = 0;
 };
 
 struct Ring {
@@ -90,6 +92,7 @@ struct conan_ctx {
   float* vec(const std::string& name) const;
   void pack_conv(const std::string& name, const std::vector<float>& W, const float* bias, int Cout, int Cin, int k,
                  int shuffle_r = 1);
+  void add_rowconv_weights(const std::string& name, const std::vector<float>& W);   // second, fragment-major copy
   void pack_from_keys(const std::string& name, const std::string& wkey, const std::string& bkey, int shuffle_r = 1);
   void pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r = 1);
   void pack_fragments(const std::string& name, const std::string& prefix);   // resblock_fused.hip operand layout

@@ -111,6 +111,24 @@ int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu);   
 bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
 const char* resblock_fused_name(int C, int rows);
 
+// Frame-rate conv / linear of the decoder step with an optional LayerNorm in front (rowconv.hip).
+struct RowConvArgs {
+  TRef x;               // input rows; with ln: the raw rows of THIS step (earlier rows come from `hist`)
+  TRef hist;            // ln only: the layer's ring of normalised rows (read for t < 0, written for t >= 0)
+  TRef y, res, m1, m2, lnmask, mask_out;
+  const float* w;       // fragment-major: [Cout_pad/16][ktaps + 1][Cin/16][64 lanes][4]
+  const float* bias;    // [Cout_pad] or nullptr
+  const float* bvec; long long bvec_stride;   // per-slot broadcast vector or nullptr
+  const float* gamma; const float* beta; float eps;
+  const int* slots; const int* pos;
+  int ln, has_res, has_m1, has_m2, has_lnmask, has_mask_out;
+  int Cin, Cout, Cout_pad, ktaps, dil, T, n;
+  int out_act; float out_scale, out_slope;
+  int wr_max;           // filled by launch_rowconv: window rows of a tile
+};
+bool rowconv_supported(int Cin, int ktaps, int dil, int T);
+void launch_rowconv(const RowConvArgs& a, hipStream_t st);
+
 // LayerNorm over the channel axis of each row:
 //   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])
 // optionally writing mask_out[i][t] = (sum_c |x| > 0).

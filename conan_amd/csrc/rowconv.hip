@@ -1,0 +1,259 @@
+// rowconv: causal conv / linear for the frame-rate layers of the Conan decoder step (a few hundred rows: streams x
+// frames), with an optional LayerNorm fused in front (gfx950, exact-f32 MFMA v_mfma_f32_16x16x4_f32).
+//
+//   y[i][t][co] = epilogue( sum_j sum_ci W[j][ci][co] * f(x)[i][t - (k-1-j)*dil][ci] )
+//   f = identity, or LayerNorm over the channels (gamma, beta, eps) of the NEW rows - rows of earlier steps come out of
+//       the layer's ring already normalised, and the new normalised rows are appended to it (first column tile only);
+//   epilogue(a) = ((act((a + bias) * scale) + bvec[slot]) + res) * m1 * m2
+//
+// Why not conv_mfma: at M = streams x frames = 256 rows its 32x32 tiles need inter-block split-K to fill the chip, a
+// 96 KB LDS ring and 256 blocks per launch; beside the persistent vocoder launches of a pipelined step (one block per CU,
+// 100+ KB of LDS each) such a launch waits for a vocoder kernel boundary.  Here a block is 4 waves with <= 36 KB of LDS
+// and < 100 VGPRs - it fits on a CU NEXT to a resident vocoder block - and a launch has 16-128 blocks:
+//   * the block owns 16 output rows (MFMA row tile) x 64*NCW output columns; the rows of up to a few streams with their
+//     (k-1)*dil rows of left context are gathered ONCE into an LDS window (row stride Cin + 8 floats: conflict-free
+//     ds_read_b128), LayerNorm is applied there, and the k taps are row-shifted fragment reads of that window;
+//   * a wave owns whole 16-column strips, so its weights (fragment-major, 1 KiB per 16x16 operand, the layout of
+//     resblock_fused.hip) stream from L2 straight into registers through a 4-deep ring; the K loop has no barrier;
+//   * separate LayerNorm launches disappear (13 per decoder step).
+#include "kernels.h"
+
+namespace cnk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* rc_gcf4;
+typedef const int __attribute__((address_space(1)))* rc_gci;
+__device__ __forceinline__ float4 rc_gload4(const float* p) { const f32x4 v = *(rc_gcf4)(p); return make_float4(v[0], v[1], v[2], v[3]); }
+
+__device__ __forceinline__ float rc_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ const float* rc_row(const TRef& r, int i, int slot, int pos, int t) {
+  if (r.mode == 0) return r.base + (long long)slot * r.slot_stride + (long long)(((unsigned)pos * (unsigned)r.rate + (unsigned)(r.off + t)) & (unsigned)r.lmask) * r.C;
+  return r.base + (long long)i * r.slot_stride + (long long)(r.off + t) * r.C;
+}
+
+constexpr int RC_TM = 16;          // output rows per block
+constexpr int RC_MAXSEG = 8;       // streams a tile may touch (T >= 2)
+// depth of the weight-fragment ring (K groups in flight): 8 x 4 MFMAs for one column tile per wave, 4 x 16 for four
+
+template <int NCW>
+__global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
+  constexpr int RC_D = NCW == 1 ? 8 : 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, n = a.n, Mtot = n * T;
+  const int m0 = blockIdx.x * RC_TM;
+  const int ntile = blockIdx.y;                       // 64*NCW output columns
+  const int Cin = a.Cin, LDX = Cin + 8, C4 = Cin >> 2;
+  const int k = a.ktaps, d = a.dil, halo = (k - 1) * d;
+  // ---- window geometry: output row r of the tile is (stream i_r, time t_r); the rows of one stream are consecutive, each
+  // stream segment is preceded by its `halo` rows of left context
+  int* const tab = reinterpret_cast<int*>(lds);        // [0..16): window row of output row r at tap 0; [16..16+WR): packed (seg, tau + halo)
+  float* const win = lds + ((16 + a.wr_max + 3) & ~3);  // [wr_max][LDX], 16-byte aligned
+  __shared__ int seg_i[RC_MAXSEG + 1], seg_t0[RC_MAXSEG + 1], seg_off[RC_MAXSEG + 1], seg_slot[RC_MAXSEG + 1], seg_pos[RC_MAXSEG + 1];
+  __shared__ int s_wr;
+  // one lane per output row (wave 0): rows of one stream are consecutive; a segment starts where the stream changes.
+  // Window layout [halo_0 | rows_0 | halo_1 | rows_1 | ...]: segment s starting at tile row r0 begins at r0 + s*halo and
+  // tap 0 of tile row r reads window row r + s*halo.  The slot / position loads of all segments fly together.
+  if (tid < 64) {
+    if (tid <= RC_MAXSEG) { seg_i[tid] = -1; seg_off[tid] = 0x7fffffff; }
+    const int r = lane, m = m0 + r;
+    const bool valid = r < RC_TM && m < Mtot;
+    const int i = valid ? m / T : -1, t = valid ? m - i * T : 0;
+    const int iprev = __shfl_up(i, 1);
+    const bool start = valid && (r == 0 || i != iprev);
+    const unsigned long long sb = __ballot(start);
+    const int sidx = __popcll(sb & ((2ull << r) - 1ull)) - 1;
+    const int slot = start ? (a.slots ? *(rc_gci)(a.slots + i) : i) : 0;
+    const int pos = start ? (a.pos ? *(rc_gci)(a.pos + slot) : 0) : 0;
+    if (r < RC_TM) tab[r] = valid ? r + sidx * halo : 0;
+    if (start) { seg_i[sidx] = i; seg_t0[sidx] = t; seg_off[sidx] = r + sidx * halo; seg_slot[sidx] = slot; seg_pos[sidx] = pos; }
+    if (lane == 0) { const int nvalid = Mtot - m0 < RC_TM ? Mtot - m0 : RC_TM; s_wr = nvalid + __popcll(sb) * halo; }
+  }
+  __syncthreads();
+  const int WR = s_wr;
+  // ---- gather the window (raw), 8 rows-of-16-bytes per thread in flight at a time
+  auto wseg = [&](int w) __attribute__((always_inline)) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < RC_MAXSEG; ++q) s += (w >= seg_off[q]) ? 1 : 0;      // seg_off of unused segments is INT_MAX
+    return s;
+  };
+  const int total = WR * C4;
+  for (int e0 = 0; e0 < total; e0 += 256 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      const int w = e < total ? e / C4 : 0, c4 = e < total ? e - w * C4 : 0;
+      const int sg = wseg(w);
+      const int tau = seg_t0[sg] - halo + (w - seg_off[sg]);   // time index within this step (negative: earlier steps)
+      const float* src = (a.ln && tau >= 0) ? rc_row(a.x, seg_i[sg], seg_slot[sg], seg_pos[sg], tau)        // new rows: raw layer input
+                                            : rc_row(a.ln ? a.hist : a.x, seg_i[sg], seg_slot[sg], seg_pos[sg], tau);   // ring (history, or plain input)
+      v[u] = rc_gload4(src + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + tid + 256 * u;
+      if (e < total) { const int w = e / C4, c4 = e - w * C4; *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = v[u]; }
+    }
+  }
+  __syncthreads();
+  // ---- LayerNorm of the new rows in place: 16 lanes per row, 4 rows per wave at a time; the first column tile appends
+  // them to the layer's ring and writes the block mask (row has any non-zero input: nonpadding of a residual block)
+  if (a.ln) {
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int w = wave * 4 + sub; w < ((WR + 15) & ~15); w += 16) {
+      const bool inw = w < WR;
+      const int sg = wseg(inw ? w : 0);
+      const int tau = seg_t0[sg] - halo + ((inw ? w : 0) - seg_off[sg]);
+      const bool live = inw && tau >= 0;
+      float* row = win + (inw ? w : 0) * LDX;
+      float4 v[8];                                          // Cin <= 512: 8 float4 per lane
+      float sum = 0.f, sa = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
+      const float mean = sum / (float)Cin;
+      float var = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+      const float rstd = 1.0f / sqrtf(var / (float)Cin + a.eps);
+      if (live) {
+        float mk = 1.f;
+        if (a.has_lnmask) mk = *rc_row(a.lnmask, seg_i[sg], seg_slot[sg], seg_pos[sg], tau);
+        float* hrow = const_cast<float*>(rc_row(a.hist, seg_i[sg], seg_slot[sg], seg_pos[sg], tau));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = (l16 + 16 * q) * 4;
+          if (c < Cin) {
+            const float4 g = *reinterpret_cast<const float4*>(a.gamma + c), bb = *reinterpret_cast<const float4*>(a.beta + c);
+            const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
+                                         ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
+            *reinterpret_cast<float4*>(row + c) = o;
+            if (ntile == 0) *reinterpret_cast<float4*>(hrow + c) = o;
+          }
+        }
+        if (a.has_mask_out && ntile == 0 && l16 == 0) *const_cast<float*>(rc_row(a.mask_out, seg_i[sg], seg_slot[sg], seg_pos[sg], tau)) = sa > 0.f ? 1.f : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- K loop: wave w owns column tiles ct0 .. ct0 + NCW - 1 of this block's strip
+  const int KQ = Cin >> 4;                              // 16-deep K groups per tap (power of two, >= RC_D)
+  const int NG = k * KQ;
+  const int ct0 = (ntile * 4 + wave) * NCW;
+  const int lr = lane & 15, lg = lane >> 4;
+  const float* abase = win + tab[lr] * LDX + 4 * lg;
+  const long long ct_stride = (long long)(k + 1) * KQ * 256;      // floats per column tile (k taps + one zero tap)
+  const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+  const bool active = ct0 * 16 < a.Cout_pad;            // column tiles past the padded width have no weights
+  f32x4 acc[NCW];
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    float4 bw[RC_D][NCW];
+#pragma unroll
+    for (int u = 0; u < RC_D; ++u) {
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) bw[u][c] = rc_gload4(wl + c * ct_stride + (long long)u * 256);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
+    const int tstep = d * LDX;
+    float4 af = *reinterpret_cast<const float4*>(abase);
+    for (int G0 = 0; G0 < NG; G0 += RC_D) {
+#pragma unroll
+      for (int u = 0; u < RC_D; ++u) {
+        const int Gn = G0 + u + 1;                      // next group's A fragment (past the end: an in-bounds dummy)
+        const int jn = Gn >> kqs, qn = Gn & kqm;
+        const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < NG ? jn * tstep + qn * 16 : 0));
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u][c].x, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u][c].y, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u][c].z, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u][c].w, acc[c], 0, 0, 0);
+        // refill this ring slot with group G + RC_D (the packed weights end with a zero tap: reads past the last group stay in bounds)
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) bw[u][c] = rc_gload4(wl + c * ct_stride + (long long)(G0 + u + RC_D) * 256);
+        af = afn;
+      }
+    }
+  }
+  // ---- epilogue: lane (g, n) holds rows 4g .. 4g+3 of column n of each of its column tiles
+  const float scale = a.out_scale;
+  const int act = a.out_act;
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) {
+    const int col = (ct0 + c) * 16 + lr;
+    if (!active || col >= a.Cout) continue;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * lg + e, m = m0 + r;
+      if (m >= Mtot) continue;
+      const int i = m / T, t = m - i * T;
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < RC_MAXSEG; ++q) if (seg_i[q] == i) s = q;
+      const int slot = seg_slot[s], pos = seg_pos[s];
+      float v = (acc[c][e] + bias) * scale;
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+      if (a.bvec) v += a.bvec[(long long)slot * a.bvec_stride + col];
+      if (a.has_res) v += rc_row(a.res, i, slot, pos, t)[col];
+      if (a.has_m1) v *= *rc_row(a.m1, i, slot, pos, t);
+      if (a.has_m2) v *= *rc_row(a.m2, i, slot, pos, t);
+      const_cast<float*>(rc_row(a.y, i, slot, pos, t))[col] = v;
+    }
+  }
+}
+
+int rowconv_lds_bytes(const RowConvArgs& a) {
+  return (((16 + a.wr_max + 3) & ~3) + a.wr_max * (a.Cin + 8)) * 4;
+}
+
+bool rowconv_supported(int Cin, int ktaps, int dil, int T) {
+  const int KQ = Cin / 16;
+  if (Cin % 64 || Cin > 512 || (KQ & (KQ - 1)) || (ktaps * KQ) % 8) return false;   // K groups: a power of two per tap, a multiple of the ring depth in all
+  if (T < 2) return false;                                              // <= 8 streams per 16-row tile
+  const int segs = T >= RC_TM ? 2 : (RC_TM + T - 1) / T + (RC_TM % T ? 1 : 0);
+  const int wr = RC_TM + segs * (ktaps - 1) * dil;
+  return (20 + wr + wr * (Cin + 8)) * 4 <= 60 * 1024;
+}
+
+void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
+  RowConvArgs a = ain;
+  const int T = a.T, M = a.n * T;
+  if (M <= 0) return;
+  const int segs = T >= RC_TM ? 2 : (RC_TM + T - 1) / T + (RC_TM % T ? 1 : 0);
+  a.wr_max = RC_TM + (segs > RC_MAXSEG ? RC_MAXSEG : segs) * (a.ktaps - 1) * a.dil;
+  const int mt = (M + RC_TM - 1) / RC_TM;
+  const int lds = rowconv_lds_bytes(a);
+  // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
+  const int ncols = a.Cout_pad;
+  if (ncols >= 1024) hipLaunchKernelGGL((rowconv_kernel<4>), dim3(mt, (ncols + 255) / 256), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((rowconv_kernel<1>), dim3(mt, (ncols + 63) / 64), dim3(256), lds, st, a);
+}
+
+}  // namespace cnk

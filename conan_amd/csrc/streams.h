@@ -168,6 +168,10 @@ struct conan_streams {
   std::vector<ProfKernel> prof_kernels;          // filled by conan_profile_end: per template instantiation
   void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
   void launch_rb(const cnk::RBArgs& a, int C, hipStream_t st);
+  bool use_rowconv = true;                  // frame-rate decoder layers through rowconv.hip (CONAN_ROWCONV=0: conv_mfma + LayerNorm launches)
+  bool rowconv_ok(const PackedConv& pc, int dil, int T) const { return use_rowconv && pc.wf && cnk::rowconv_supported(pc.Cin, pc.k, dil, T); }
+  cnk::RowConvArgs mk_rc(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, int dil = 1) const;
+  void rowconv(const cnk::RowConvArgs& a, hipStream_t st);
   template <typename F> void profiled(const std::string& name, double flops, hipStream_t st, F&& launch);
   void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;

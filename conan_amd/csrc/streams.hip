@@ -100,6 +100,21 @@ void conan_streams::profiled(const std::string& name, double flops, hipStream_t 
   prof_rec.push_back({name, flops});
 }
 
+cnk::RowConvArgs conan_streams::mk_rc(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, int dil) const {
+  cnk::RowConvArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.hist = ch::null_ref(); a.y = y; a.res = ch::null_ref(); a.m1 = ch::null_ref(); a.m2 = ch::null_ref();
+  a.lnmask = ch::null_ref(); a.mask_out = ch::null_ref();
+  a.w = pc.wf; a.bias = pc.bias; a.slots = d_slots; a.pos = pos_dec;
+  a.Cin = pc.Cin; a.Cout = pc.Cout; a.Cout_pad = pc.wf_cout_pad; a.ktaps = pc.k; a.dil = dil; a.T = T; a.n = n;
+  a.out_act = cnk::ACT_NONE; a.out_scale = 1.f; a.out_slope = 0.f; a.eps = 1e-5f;
+  return a;
+}
+
+void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
+  const double fl = 2.0 * (double)a.n * a.T * a.Cout * a.ktaps * a.Cin;
+  profiled(a.Cout_pad >= 1024 ? "cnk::rowconv_kernel<4>" : "cnk::rowconv_kernel<1>", fl, st, [&] { cnk::launch_rowconv(a, st); });
+}
+
 // one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
 void conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st) {
   cnk::RBArgs a = ain;
