@@ -141,11 +141,12 @@ void conan_ctx::fold_weightnorm(const std::string& prefix, std::vector<float>& W
   }
 }
 
-void conan_ctx::pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r) {
+void conan_ctx::pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r, bool rowconv) {
   std::vector<float> W, b;
   int Cout, Cin, k;
   fold_weightnorm(prefix, W, b, Cout, Cin, k);
   pack_conv(name, W, b.data(), Cout, Cin, k, shuffle_r);
+  if (rowconv) add_rowconv_weights(name, W);
 }
 
 // Weights of a C -> C conv for resblock_fused.hip: per 16-column tile, per tap (k taps + one zero tap), per 16-deep K
@@ -208,9 +209,11 @@ void conan_ctx::finalize_hifigan() {
         if (c.voc_resblock == 2) {
           pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c." + std::to_string(d), P + rb + ".convs." + std::to_string(d) + ".conv");
         } else {
-          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
-          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
           const int Cs = c.voc_initial_channel >> (i + 1);
+          // stages too wide for the fused pass (C = 256) run their convs through rowconv.hip's 32-row stream tiles
+          const bool rc = !cnk::resblock_fused_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
+          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv", 1, rc);
+          pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv", 1, rc);
           if (cnk::resblock_fused_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d])) {
             pack_fragments("voc.rbf." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
             pack_fragments("voc.rbf." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");

@@ -94,7 +94,7 @@ struct conan_ctx {
                  int shuffle_r = 1);
   void add_rowconv_weights(const std::string& name, const std::vector<float>& W);   // second, fragment-major copy
   void pack_from_keys(const std::string& name, const std::string& wkey, const std::string& bkey, int shuffle_r = 1);
-  void pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r = 1);
+  void pack_weightnorm(const std::string& name, const std::string& prefix, int shuffle_r = 1, bool rowconv = false);
   void pack_fragments(const std::string& name, const std::string& prefix);   // resblock_fused.hip operand layout
   void fold_weightnorm(const std::string& prefix, std::vector<float>& W, std::vector<float>& bias, int& Cout, int& Cin, int& k) const;
   void upload_vec(const std::string& name, const std::string& key);

@@ -124,6 +124,8 @@ struct RowConvArgs {
   int ln, has_res, has_m1, has_m2, has_lnmask, has_mask_out;
   int Cin, Cout, Cout_pad, ktaps, dil, T, n;
   int out_act; float out_scale, out_slope;
+  int in_lrelu; float in_slope;   // LeakyReLU applied to the input window (HiFi-GAN resblock convs read raw tensors)
+  int rows32;           // 32-row tiles, two row tiles per wave (requires T % 32 == 0)
   int wr_max;           // filled by launch_rowconv: window rows of a tile
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);

@@ -16,6 +16,8 @@
 //   * a wave owns whole 16-column strips, so its weights (fragment-major, 1 KiB per 16x16 operand, the layout of
 //     resblock_fused.hip) stream from L2 straight into registers through a 4-deep ring; the K loop has no barrier;
 //   * separate LayerNorm launches disappear (13 per decoder step).
+#include <atomic>
+
 #include "kernels.h"
 
 namespace cnk {
@@ -36,25 +38,28 @@ __device__ __forceinline__ const float* rc_row(const TRef& r, int i, int slot, i
   return r.base + (long long)i * r.slot_stride + (long long)(r.off + t) * r.C;
 }
 
-constexpr int RC_TM = 16;          // output rows per block
+constexpr int RC_TM = 16;          // output rows per MFMA row tile
 constexpr int RC_MAXSEG = 8;       // streams a tile may touch (T >= 2)
 // depth of the weight-fragment ring (K groups in flight): 8 x 4 MFMAs for one column tile per wave, 4 x 16 for four
 
-template <int NCW>
+// NCW column tiles x NRW row tiles per wave: <1,1> / <4,1> for the decoder's frame-rate layers, <1,2> for the 32-row
+// stream tiles of the first vocoder stage (C = 256, T = 32: too few rows per stream for the fused resblock pass)
+template <int NCW, int NRW>
 __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
-  constexpr int RC_D = NCW == 1 ? 8 : 4;
+  constexpr int RC_D = (NCW * NRW == 1) ? 8 : 4;
+  constexpr int TMB = RC_TM * NRW;                     // output rows per block
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T, n = a.n, Mtot = n * T;
-  const int m0 = blockIdx.x * RC_TM;
+  const int m0 = blockIdx.x * TMB;
   const int ntile = blockIdx.y;                       // 64*NCW output columns
   const int Cin = a.Cin, LDX = Cin + 8, C4 = Cin >> 2;
   const int k = a.ktaps, d = a.dil, halo = (k - 1) * d;
   // ---- window geometry: output row r of the tile is (stream i_r, time t_r); the rows of one stream are consecutive, each
   // stream segment is preceded by its `halo` rows of left context
-  int* const tab = reinterpret_cast<int*>(lds);        // [0..16): window row of output row r at tap 0; [16..16+WR): packed (seg, tau + halo)
-  float* const win = lds + ((16 + a.wr_max + 3) & ~3);  // [wr_max][LDX], 16-byte aligned
+  int* const tab = reinterpret_cast<int*>(lds);        // [0..32): window row of output row r at tap 0
+  float* const win = lds + 32;                          // [wr_max][LDX]
   __shared__ int seg_i[RC_MAXSEG + 1], seg_t0[RC_MAXSEG + 1], seg_off[RC_MAXSEG + 1], seg_slot[RC_MAXSEG + 1], seg_pos[RC_MAXSEG + 1];
   __shared__ int s_wr;
   // one lane per output row (wave 0): rows of one stream are consecutive; a segment starts where the stream changes.
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
   if (tid < 64) {
     if (tid <= RC_MAXSEG) { seg_i[tid] = -1; seg_off[tid] = 0x7fffffff; }
     const int r = lane, m = m0 + r;
-    const bool valid = r < RC_TM && m < Mtot;
+    const bool valid = r < TMB && m < Mtot;
     const int i = valid ? m / T : -1, t = valid ? m - i * T : 0;
     const int iprev = __shfl_up(i, 1);
     const bool start = valid && (r == 0 || i != iprev);
@@ -71,9 +76,9 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
     const int sidx = __popcll(sb & ((2ull << r) - 1ull)) - 1;
     const int slot = start ? (a.slots ? *(rc_gci)(a.slots + i) : i) : 0;
     const int pos = start ? (a.pos ? *(rc_gci)(a.pos + slot) : 0) : 0;
-    if (r < RC_TM) tab[r] = valid ? r + sidx * halo : 0;
+    if (r < TMB) tab[r] = valid ? r + sidx * halo : 0;
     if (start) { seg_i[sidx] = i; seg_t0[sidx] = t; seg_off[sidx] = r + sidx * halo; seg_slot[sidx] = slot; seg_pos[sidx] = pos; }
-    if (lane == 0) { const int nvalid = Mtot - m0 < RC_TM ? Mtot - m0 : RC_TM; s_wr = nvalid + __popcll(sb) * halo; }
+    if (lane == 0) { const int nvalid = Mtot - m0 < TMB ? Mtot - m0 : TMB; s_wr = nvalid + __popcll(sb) * halo; }
   }
   __syncthreads();
   const int WR = s_wr;
@@ -97,10 +102,13 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
                                             : rc_row(a.ln ? a.hist : a.x, seg_i[sg], seg_slot[sg], seg_pos[sg], tau);   // ring (history, or plain input)
       v[u] = rc_gload4(src + c4 * 4);
     }
+    const float isl = a.in_lrelu ? a.in_slope : 1.0f;      // LeakyReLU on the way in (HiFi-GAN resblock convs)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + tid + 256 * u;
-      if (e < total) { const int w = e / C4, c4 = e - w * C4; *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = v[u]; }
+      float4 q = v[u];
+      q.x *= q.x > 0.f ? 1.0f : isl; q.y *= q.y > 0.f ? 1.0f : isl; q.z *= q.z > 0.f ? 1.0f : isl; q.w *= q.w > 0.f ? 1.0f : isl;
+      if (e < total) { const int w = e / C4, c4 = e - w * C4; *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = q; }
     }
   }
   __syncthreads();
@@ -160,13 +168,17 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
   const int NG = k * KQ;
   const int ct0 = (ntile * 4 + wave) * NCW;
   const int lr = lane & 15, lg = lane >> 4;
-  const float* abase = win + tab[lr] * LDX + 4 * lg;
+  const float* abase[NRW];
+#pragma unroll
+  for (int r = 0; r < NRW; ++r) abase[r] = win + tab[r * RC_TM + lr] * LDX + 4 * lg;
   const long long ct_stride = (long long)(k + 1) * KQ * 256;      // floats per column tile (k taps + one zero tap)
   const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
   const bool active = ct0 * 16 < a.Cout_pad;            // column tiles past the padded width have no weights
-  f32x4 acc[NCW];
+  f32x4 acc[NRW][NCW];
 #pragma unroll
-  for (int c = 0; c < NCW; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < NRW; ++r)
+#pragma unroll
+    for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (active) {
     float4 bw[RC_D][NCW];
 #pragma unroll
@@ -177,25 +189,39 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
     }
     const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
     const int tstep = d * LDX;
-    float4 af = *reinterpret_cast<const float4*>(abase);
+    float4 af[NRW];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) af[r] = *reinterpret_cast<const float4*>(abase[r]);
     for (int G0 = 0; G0 < NG; G0 += RC_D) {
 #pragma unroll
       for (int u = 0; u < RC_D; ++u) {
-        const int Gn = G0 + u + 1;                      // next group's A fragment (past the end: an in-bounds dummy)
+        const int Gn = G0 + u + 1;                      // next group's A fragments (past the end: an in-bounds dummy)
         const int jn = Gn >> kqs, qn = Gn & kqm;
-        const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < NG ? jn * tstep + qn * 16 : 0));
+        const int aoff = Gn < NG ? jn * tstep + qn * 16 : 0;
+        float4 afn[NRW];
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u][c].x, acc[c], 0, 0, 0);
+        for (int r = 0; r < NRW; ++r) afn[r] = *reinterpret_cast<const float4*>(abase[r] + aoff);
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u][c].y, acc[c], 0, 0, 0);
+        for (int r = 0; r < NRW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u][c].z, acc[c], 0, 0, 0);
+          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].x, bw[u][c].x, acc[r][c], 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u][c].w, acc[c], 0, 0, 0);
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].y, bw[u][c].y, acc[r][c], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].z, bw[u][c].z, acc[r][c], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].w, bw[u][c].w, acc[r][c], 0, 0, 0);
         // refill this ring slot with group G + RC_D (the packed weights end with a zero tap: reads past the last group stay in bounds)
 #pragma unroll
         for (int c = 0; c < NCW; ++c) bw[u][c] = rc_gload4(wl + c * ct_stride + (long long)(G0 + u + RC_D) * 256);
-        af = afn;
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) af[r] = afn[r];
       }
     }
   }
@@ -208,15 +234,17 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
     if (!active || col >= a.Cout) continue;
     const float bias = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
+    for (int rr = 0; rr < NRW; ++rr)
+#pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int r = 4 * lg + e, m = m0 + r;
+      const int r = rr * RC_TM + 4 * lg + e, m = m0 + r;
       if (m >= Mtot) continue;
       const int i = m / T, t = m - i * T;
       int s = 0;
 #pragma unroll
       for (int q = 1; q < RC_MAXSEG; ++q) if (seg_i[q] == i) s = q;
       const int slot = seg_slot[s], pos = seg_pos[s];
-      float v = (acc[c][e] + bias) * scale;
+      float v = (acc[rr][c][e] + bias) * scale;
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
@@ -230,30 +258,54 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 }
 
 int rowconv_lds_bytes(const RowConvArgs& a) {
-  return (((16 + a.wr_max + 3) & ~3) + a.wr_max * (a.Cin + 8)) * 4;
+  return (32 + a.wr_max * (a.Cin + 8)) * 4;
+}
+
+static int rc_window_rows(int tm, int T, int halo) {
+  const int segs = T >= tm ? (tm == T ? 1 : 2) : (tm + T - 1) / T + (tm % T ? 1 : 0);
+  return tm + (segs > RC_MAXSEG ? RC_MAXSEG : segs) * halo;
 }
 
 bool rowconv_supported(int Cin, int ktaps, int dil, int T) {
   const int KQ = Cin / 16;
   if (Cin % 64 || Cin > 512 || (KQ & (KQ - 1)) || (ktaps * KQ) % 8) return false;   // K groups: a power of two per tap, a multiple of the ring depth in all
   if (T < 2) return false;                                              // <= 8 streams per 16-row tile
-  const int segs = T >= RC_TM ? 2 : (RC_TM + T - 1) / T + (RC_TM % T ? 1 : 0);
-  const int wr = RC_TM + segs * (ktaps - 1) * dil;
-  return (20 + wr + wr * (Cin + 8)) * 4 <= 60 * 1024;
+  const int wr = rc_window_rows(RC_TM, T, (ktaps - 1) * dil);
+  return (32 + wr * (Cin + 8)) * 4 <= 60 * 1024;
+}
+
+template <int NCW, int NRW>
+static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t st) {
+  if (lds > 64 * 1024) {   // more dynamic LDS than the default cap: once per device
+    static std::atomic<unsigned long long> devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(devs.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute((const void*)rowconv_kernel<NCW, NRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);   // + 240 B static
+      devs.fetch_or(bit, std::memory_order_release);
+    }
+  }
+  hipLaunchKernelGGL((rowconv_kernel<NCW, NRW>), dim3(mt, nt), dim3(256), lds, st, a);
 }
 
 void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
   RowConvArgs a = ain;
   const int T = a.T, M = a.n * T;
   if (M <= 0) return;
-  const int segs = T >= RC_TM ? 2 : (RC_TM + T - 1) / T + (RC_TM % T ? 1 : 0);
-  a.wr_max = RC_TM + (segs > RC_MAXSEG ? RC_MAXSEG : segs) * (a.ktaps - 1) * a.dil;
+  const int halo = (a.ktaps - 1) * a.dil;
+  const int ncols = a.Cout_pad;
+  if (a.rows32) {   // 32-row tiles (T a multiple of 32: a tile never straddles two streams)
+    a.wr_max = rc_window_rows(32, T, halo);
+    rc_launch<1, 2>(a, (M + 31) / 32, (ncols + 63) / 64, rowconv_lds_bytes(a), st);
+    return;
+  }
+  a.wr_max = rc_window_rows(RC_TM, T, halo);
   const int mt = (M + RC_TM - 1) / RC_TM;
   const int lds = rowconv_lds_bytes(a);
   // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
-  const int ncols = a.Cout_pad;
-  if (ncols >= 1024) hipLaunchKernelGGL((rowconv_kernel<4>), dim3(mt, (ncols + 255) / 256), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((rowconv_kernel<1>), dim3(mt, (ncols + 63) / 64), dim3(256), lds, st, a);
+  if (ncols >= 1024) rc_launch<4, 1>(a, mt, (ncols + 255) / 256, lds, st);
+  else rc_launch<1, 1>(a, mt, (ncols + 63) / 64, lds, st);
 }
 
 }  // namespace cnk
