@@ -282,23 +282,33 @@ def main():
         conv_ms, conv_flops, conv_launches = eng.st.profile_end()
         # the dominant kernel = the instantiation with the largest summed time
         kernels = sorted(eng.st.profile_kernels(), key=lambda r: -r[1])
-        name, k_ms, k_fl, k_n = kernels[0]
+        # The dominant kernel = the kernel (template) with the largest summed time; its instantiations (tile shapes per
+        # vocoder stage) are listed separately in `matrix_kernels`, the single instantiation with the largest summed
+        # time in `largest_instantiation`.
+        fams = {}
+        for kn, ms_, fl_, n_ in kernels:
+            f = fams.setdefault(kn.split("<")[0], [0.0, 0.0, 0, []])
+            f[0] += ms_; f[1] += fl_; f[2] += n_; f[3].append(kn)
+        name, (k_ms, k_fl, k_n, insts) = max(fams.items(), key=lambda kv: kv[1][0])
         ach = k_fl / (k_ms * 1e-3) / 1e12
         fam = conv_flops / (conv_ms * 1e-3) / 1e12
         pmc, pmc_src = pmc_summary(args.workload)
         traffic = step_bytes = mfma_busy = None
         if pmc:
             hit = [v for k, v in pmc.get("kernels", {}).items() if name in k]
-            if hit:
-                traffic = hit[0]["fetch"] + hit[0]["write"]
-                mfma_busy = hit[0].get("mfma_busy_frac")
+            if hit:       # per launch of the kernel, averaged over its instantiations by their launch counts
+                w = sum(v["dispatches_per_step"] for v in hit)
+                traffic = sum((v["fetch"] + v["write"]) * v["dispatches_per_step"] for v in hit) / w
+                busy = [v for v in hit if "mfma_busy_frac" in v]
+                mfma_busy = (sum(v["mfma_busy_frac"] * v["dispatches_per_step"] for v in busy) / sum(v["dispatches_per_step"] for v in busy)) if busy else None
             step_bytes = pmc.get("bytes_per_step")
         flops_step = B * frames_per_step * GFLOP_PER_FRAME * 1e9
         bytes_alg = WEIGHT_BYTES_PER_STEP + B * STATE_BYTES_PER_STREAM * (frames_per_step / seg)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
                 "mfma_busy_frac_pmc": mfma_busy,
-                "kernel": name, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
+                "kernel": name, "instantiations": insts, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
+                "largest_instantiation": {"kernel": kernels[0][0], "ms_per_step": kernels[0][1] / nprof, "tflops": kernels[0][2] / (kernels[0][1] * 1e-3) / 1e12},
                 "gflop_per_launch": k_fl / k_n / 1e9, "share_of_step_time": (k_ms / nprof) / ms_step,
                 "matrix_kernels": [{"kernel": kn, "launches_per_step": n_ / nprof, "us_per_launch": ms_ * 1e3 / n_, "ms_per_step": ms_ / nprof,
                                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "frac": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS} for kn, ms_, fl_, n_ in kernels],

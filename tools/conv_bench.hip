@@ -42,6 +42,18 @@ int main(int argc, char** argv) {
     {"ups0 32x64", 64, 4, 512, 2048, 16, 1, 1, cnk::CFG_32x64_K2},
     {"dec c1 (M=256,256->512,k5)", 64, 4, 256, 512, 5, 1, 1, cnk::CFG_32x32_K4},
     {"emf ff2 (M=384,2048->80)", 64, 6, 2048, 80, 1, 1, 1, cnk::CFG_32x32_K4},
+    {"ups1 64x32 K2", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_64x32_K2},
+    {"ups1 128x32", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_128x32},
+    {"ups1 128x64", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_128x64},
+    {"ups1 32x32 K4", 64, 32, 256, 640, 10, 1, 1, cnk::CFG_32x32_K4},
+    {"ups3 128x64", 64, 640, 64, 64, 4, 1, 1, cnk::CFG_128x64},
+    {"ups3 128x32", 64, 640, 64, 64, 4, 1, 1, cnk::CFG_128x32},
+    {"ups3 64x64 KS64", 64, 640, 64, 64, 4, 1, 1, cnk::CFG_64x64_KS64},
+    {"ups2 64x64 KS64", 64, 160, 128, 256, 8, 1, 1, cnk::CFG_64x64_KS64},
+    {"ups2 128x64", 64, 160, 128, 256, 8, 1, 1, cnk::CFG_128x64},
+    {"ups0 32x32 K4", 64, 4, 512, 2048, 16, 1, 1, cnk::CFG_32x32_K4},
+    {"ups0 64x64 KS64", 64, 4, 512, 2048, 16, 1, 1, cnk::CFG_64x64_KS64},
+    {"conv_pre (M=256,80->512,k7) K4", 64, 4, 80, 512, 7, 1, 1, cnk::CFG_32x32_K4},
   };
   int nslots = 64;
   for (auto& s : shapes) {
