@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T, n = a.n, Mtot = n * T;
-  const int m0 = blockIdx.x * TMB;
-  const int ntile = blockIdx.y;                       // 64*NCW output columns
+  // blockIdx.x = column strip (fastest), blockIdx.y = row tile: workgroups are dealt round-robin over the 8 XCDs, so with
+  // 8 (or 4) strips an XCD always draws the same strip(s) and its L2 fetches their weights once for all row tiles
+  const int m0 = blockIdx.y * TMB;
+  const int ntile = blockIdx.x;                       // 64*NCW output columns
   const int Cin = a.Cin, LDX = Cin + 8, C4 = Cin >> 2;
   const int k = a.ktaps, d = a.dil, halo = (k - 1) * d;
   // ---- window geometry: output row r of the tile is (stream i_r, time t_r); the rows of one stream are consecutive, each
@@ -174,11 +176,16 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
   const long long ct_stride = (long long)(k + 1) * KQ * 256;      // floats per column tile (k taps + one zero tap)
   const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
   const bool active = ct0 * 16 < a.Cout_pad;            // column tiles past the padded width have no weights
-  f32x4 acc[NRW][NCW];
+  // one row tile x one column tile per wave: its MFMAs would form ONE dependent chain (40-cycle latency against a 32-cycle
+  // issue interval) - even and odd K groups accumulate separately and are summed at the end
+  constexpr int NACC = (NCW * NRW == 1) ? 2 : 1;
+  f32x4 accs[NACC][NRW][NCW];
 #pragma unroll
-  for (int r = 0; r < NRW; ++r)
+  for (int s2 = 0; s2 < NACC; ++s2)
 #pragma unroll
-    for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < NRW; ++r)
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) accs[s2][r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (active) {
     float4 bw[RC_D][NCW];
 #pragma unroll
@@ -201,6 +208,10 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
         float4 afn[NRW];
 #pragma unroll
         for (int r = 0; r < NRW; ++r) afn[r] = *reinterpret_cast<const float4*>(abase[r] + aoff);
+        f32x4 (&acc)[NRW][NCW] = accs[NACC == 2 ? (u & 1) : 0];
+        // (NACC == 2: the x/z products go to this group's set, the y/w products of the same group to the other one - two
+        // interleaved chains; the sum of the two sets is the same K sum in a different association)
+        f32x4 (&acb)[NRW][NCW] = accs[NACC == 2 ? ((u & 1) ^ 1) : 0];
 #pragma unroll
         for (int r = 0; r < NRW; ++r)
 #pragma unroll
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
         for (int r = 0; r < NRW; ++r)
 #pragma unroll
-          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].y, bw[u][c].y, acc[r][c], 0, 0, 0);
+          for (int c = 0; c < NCW; ++c) acb[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].y, bw[u][c].y, acb[r][c], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < NRW; ++r)
 #pragma unroll
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
         for (int r = 0; r < NRW; ++r)
 #pragma unroll
-          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].w, bw[u][c].w, acc[r][c], 0, 0, 0);
+          for (int c = 0; c < NCW; ++c) acb[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].w, bw[u][c].w, acb[r][c], 0, 0, 0);
         // refill this ring slot with group G + RC_D (the packed weights end with a zero tap: reads past the last group stay in bounds)
 #pragma unroll
         for (int c = 0; c < NCW; ++c) bw[u][c] = rc_gload4(wl + c * ct_stride + (long long)(G0 + u + RC_D) * 256);
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
       for (int q = 1; q < RC_MAXSEG; ++q) if (seg_i[q] == i) s = q;
       const int slot = seg_slot[s], pos = seg_pos[s];
-      float v = (acc[rr][c][e] + bias) * scale;
+      float v = ((NACC == 2 ? accs[0][rr][c][e] + accs[NACC - 1][rr][c][e] : accs[0][rr][c][e]) + bias) * scale;
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
@@ -286,7 +297,7 @@ static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t
       devs.fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL((rowconv_kernel<NCW, NRW>), dim3(mt, nt), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((rowconv_kernel<NCW, NRW>), dim3(nt, mt), dim3(256), lds, st, a);
 }
 
 void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
