@@ -160,6 +160,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   if (is_loader) {
     // ================================================================= loader waves
     {
+#ifndef CK_NO_LOADER_PRIO
+      __builtin_amdgcn_s_setprio(3);       // few instructions, all on the critical path of the next barrier
+#endif
       const int lwave = __builtin_amdgcn_readfirstlane(ltid >> 6);
       const int prow = lane / CPR;                     // row inside one wave instruction
       const int pchunk = lane % CPR;                   // physical chunk written by this lane

@@ -35,7 +35,7 @@ constexpr int EF_MAXJ = 4;        // keys per lane in a 16-lane row -> <= 64 key
 #endif
 #ifdef EF_STAMPS
 #define EF_STAMP(i) do { if (tid == 0 && blockIdx.x == 0 && l == 1) a.dbg[i] = __builtin_readcyclecounter(); } while (0)
-#define EF_STAMPC(i) do { if (c0 == EF_HCHUNK) EF_STAMP(i); } while (0)
+#define EF_STAMPC(i) do { if (c0 == member * EF_HCHUNK) EF_STAMP(i); } while (0)
 #else
 #define EF_STAMP(i) do { } while (0)
 #define EF_STAMPC(i) do { } while (0)
@@ -179,9 +179,14 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const unsigned lane16 = (unsigned)lane * 16;
-  const int i0 = blockIdx.x * G;
+  // cluster mode: cs consecutive workgroups (one per XCD: workgroups are dealt round-robin) own the same streams
+  const int cs = a.cs, csh = 31 - __builtin_clz(cs);
+  const int cluster = (int)(blockIdx.x >> csh), member = (int)(blockIdx.x & (cs - 1));
+  const int i0 = cluster * G;
   const int ng = (a.n - i0) < G ? (a.n - i0) : G;      // streams in this block
   const int nrows = ng * Q;
+  unsigned xtarget = 0;
+  if (cs > 1) xtarget = __hip_atomic_load(a.xepoch + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
   // ---- everything that depends on slots / past is computed once: no global loads other than the prefetches below
   // happen inside the layer loop (vmcnt retires in order, so a late small load would wait for the prefetches)
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     if (g < ng) {
       const int slot = a.slots[i0 + g], past = a.past[slot], Lc = past < a.LC ? past : a.LC;
       tab_off[r4] = (g * nkmax + (tok < R ? tok : R + Lc + (tok - R))) * ldk;
-      if (tok >= R) ring_off[r4] = (int)(slot * a.ring_slot_stride) + (int)((unsigned)(past + tok - R) & (unsigned)a.lmask) * D;
+      if (tok >= R && member == 0) ring_off[r4] = (int)(slot * a.ring_slot_stride) + (int)((unsigned)(past + tok - R) & (unsigned)a.lmask) * D;
     }
   }
   // (b) attention: a 16-lane row per (stream, head)
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
 #pragma unroll
     for (int t = 0; t < T1; ++t)
 #pragma unroll
-      for (int kq = 0; kq < KQD; ++kq) b1[t][kq] = ef_frag(w.w1, (wave * KQD + kq) * T1 + t, lane16);
+      for (int kq = 0; kq < KQD; ++kq) b1[t][kq] = ef_frag(w.w1, ((member * (EF_HCHUNK / 64) + wave) * KQD + kq) * T1 + t, lane16);
     ef_barrier();
     EF_STAMP(4);
     ef_layernorm<KQD>(R1, Y, ld, pb + PB_LNFF, pb + PB_LNFF + D, tid);
@@ -408,10 +413,12 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
 #pragma unroll
     for (int kq = 0; kq < KQ2; ++kq)
 #pragma unroll
-      for (int t = 0; t < KQD; ++t) b2[t][kq] = ef_frag(w.w2, (wave * KQ2 + kq) * KQD + t, lane16);
-    for (int c0 = 0; c0 < a.F; c0 += EF_HCHUNK) {
-      const bool more = c0 + EF_HCHUNK < a.F;
-      const int un = (c0 + EF_HCHUNK) / 64 + wave;               // this wave's 64 hidden columns in the next chunk
+      for (int t = 0; t < KQD; ++t) b2[t][kq] = ef_frag(w.w2, ((member * (EF_HCHUNK / 64) + wave) * KQ2 + kq) * KQD + t, lane16);
+    // (cluster member m runs hidden chunks m, m + cs, ...)
+    const int cstep = cs * EF_HCHUNK;
+    for (int c0 = member * EF_HCHUNK; c0 < a.F; c0 += cstep) {
+      const bool more = c0 + cstep < a.F;
+      const int un = (c0 + cstep) / 64 + wave;                   // this wave's 64 hidden columns in its next chunk
       EF_STAMPC(15);
       EF_STAMPC(9);
       // FF1: this wave's quarter of the chunk's hidden columns
@@ -463,9 +470,61 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     ef_barrier();
     EF_STAMP(7);
     // + bias + residual -> ATT (reused as the pre-LN buffer), then layer_norm_output -> X
-    for (int e = tid; e < EF_ROWS * D; e += 256) {
-      const int r = e / D, c = e - r * D;
-      ATT[r * ld + c] = ((RED[(0 * EF_ROWS + r) * ld + c] + RED[(1 * EF_ROWS + r) * ld + c]) + (RED[(2 * EF_ROWS + r) * ld + c] + RED[(3 * EF_ROWS + r) * ld + c])) + pb[PB_B2 + c] + R1[r * ld + c];
+    if (cs == 1) {
+      for (int e = tid; e < EF_ROWS * D; e += 256) {
+        const int r = e / D, c = e - r * D;
+        ATT[r * ld + c] = ((RED[(0 * EF_ROWS + r) * ld + c] + RED[(1 * EF_ROWS + r) * ld + c]) + (RED[(2 * EF_ROWS + r) * ld + c] + RED[(3 * EF_ROWS + r) * ld + c])) + pb[PB_B2 + c] + R1[r * ld + c];
+      }
+    } else {
+      // Cluster exchange.  The per-XCD L2s are not coherent with each other: partial sums and flags are written
+      // through and read with agent-scope (sc1) accesses, which leaves the weights cached in this XCD's L2 alone (an
+      // acquire fence would invalidate them every layer).  The buffer of layer l is reused by layer l + 2: a member
+      // writes it only after the exchange of layer l + 1, which every member enters after it has read layer l.
+      constexpr int XE = (EF_ROWS * D + 255) / 256;
+      float* const xbase = a.xch + ((long long)cluster * 2 + (l & 1)) * EMF_MAX_CLUSTER * (EF_ROWS * D);
+      unsigned* const fl = a.xflag + ((long long)cluster * EMF_MAX_LAYERS + l) * EMF_MAX_CLUSTER;
+#pragma unroll
+      for (int i = 0; i < XE; ++i) {
+        const int e = tid + 256 * i;
+        if (e < EF_ROWS * D) {
+          const int r = e / D, c = e - r * D;
+          const float v = (RED[(0 * EF_ROWS + r) * ld + c] + RED[(1 * EF_ROWS + r) * ld + c]) + (RED[(2 * EF_ROWS + r) * ld + c] + RED[(3 * EF_ROWS + r) * ld + c]);
+          __hip_atomic_store(xbase + member * (EF_ROWS * D) + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's partial-sum stores are complete ...
+      ef_barrier();
+#ifdef EF_XFENCE
+      if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+      if (tid == 0) __hip_atomic_store(fl + member, xtarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag goes out
+      if (tid < cs) {
+        while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xtarget) __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef EF_XFENCE
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+      ef_barrier();
+      float pv[EMF_MAX_CLUSTER][XE];
+#pragma unroll
+      for (int m = 0; m < EMF_MAX_CLUSTER; ++m)
+#pragma unroll
+        for (int i = 0; i < XE; ++i) {
+          const int e = tid + 256 * i;
+          pv[m][i] = (m < cs && e < EF_ROWS * D) ? __hip_atomic_load(xbase + m * (EF_ROWS * D) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+      for (int i = 0; i < XE; ++i) {
+        const int e = tid + 256 * i;
+        if (e < EF_ROWS * D) {
+          const int r = e / D, c = e - r * D;
+          float sum = pv[0][i];                                   // member order: the same bits in every member
+#pragma unroll
+          for (int m = 1; m < EMF_MAX_CLUSTER; ++m) if (m < cs) sum += pv[m][i];
+          ATT[r * ld + c] = sum + pb[PB_B2 + c] + R1[r * ld + c];
+        }
+      }
     }
     ef_barrier();
     ef_layernorm<KQD>(ATT, X, ld, pb + PB_LNOUT, pb + PB_LNOUT + D, tid);
@@ -478,7 +537,9 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     EF_STAMP(8);
   }
 
-  // ---- outputs: utterance rows
+  // ---- outputs: utterance rows (cluster mode: every member holds the same X; member 0 writes)
+  if (member != 0) return;
+  if (cs > 1 && tid == 0) __hip_atomic_store(a.xepoch + cluster, xtarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.out)
     for (int e = tid; e < ng * U * D; e += 256) {
       const int g = e / (U * D), rem = e - g * U * D, u = rem / D, c = rem - u * D;
@@ -553,8 +614,13 @@ static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)emformer_fused_kernel<KQD, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH>), dim3((a.n + G - 1) / G), dim3(256), emformer_fused_smem(a), st, a);
+  EmfFusedArgs b = a;
+  const int chunks = a.F / EF_HCHUNK;
+  if (b.cs < 1 || b.cs > EMF_MAX_CLUSTER || (b.cs & (b.cs - 1)) || chunks % b.cs || !b.xch || !b.xflag || !b.xepoch) b.cs = 1;
+  hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH>), dim3(((a.n + G - 1) / G) * b.cs), dim3(256), emformer_fused_smem(a), st, b);
 }
+
+int emformer_fused_streams_per_block(const EmfFusedArgs& a) { return ef_streams_per_block(a.R + a.U, a.H); }
 
 // instantiated shapes: (input_dim, head_dim) = (80, 10) is modules/Emformer/emformer.py's only configuration
 void launch_emformer_fused(const EmfFusedArgs& a, hipStream_t st) {

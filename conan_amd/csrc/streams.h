@@ -90,6 +90,7 @@ struct conan_streams {
   float* e_mems[2] = {nullptr, nullptr};   // memory input / output of a layer, [n][D]
   Lin e_x[2], e_ln, e_q, e_kv, e_att, e_r1, e_ffn, e_h, e_r2, e_logits;
   bool emf_fused = false;
+  int emf_cluster = 0;          // workgroups per stream group of the fused step (0: per launch; CONAN_EMF_CLUSTER)
   cnk::EmfFusedArgs emf_fused_args;
   // --- conan decoder
   Ring c_emb, c_pin2, c_uvh[4], c_lastr;

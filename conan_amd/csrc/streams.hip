@@ -406,6 +406,15 @@ void conan_streams::build_emformer() {
     a.L = c.emf_layers; a.R = c.emf_right_context; a.U = c.emf_segment; a.D = D; a.H = c.emf_heads; a.LC = c.emf_left_context;
     a.F = c.emf_ffn_dim; a.K = c.emf_output_dim; a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
     { const unsigned long long per_g = (unsigned long long)std::max(c.emf_left_context, 1) * (D / 4); a.magic_per_g = (unsigned)(((1ull << 32) + per_g - 1) / per_g); }
+    {  // cluster mode workspace (zeroed once: flags and epochs count up from there)
+      const size_t xf = cnk::emformer_cluster_xch_floats(max_slots, D), fw = cnk::emformer_cluster_flag_words(max_slots);
+      a.xch = alloc(xf);
+      unsigned* words = reinterpret_cast<unsigned*>(alloc(fw));
+      HIP_CHECK(hipMemset(words, 0, fw * sizeof(unsigned)));
+      a.xflag = words; a.xepoch = words + (size_t)max_slots * cnk::EMF_MAX_LAYERS * cnk::EMF_MAX_CLUSTER;
+      const char* e = getenv("CONAN_EMF_CLUSTER");
+      emf_cluster = e ? atoi(e) : 0;       // 0: chosen per launch from the stream count
+    }
     const char* off = getenv("CONAN_EMF_UNFUSED");
     emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1') && M == 0;   // the one-launch step has no memory tokens
   }
@@ -417,6 +426,15 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
   if (emf_fused) {   // whole step in one launch (emformer_fused.hip)
     cnk::EmfFusedArgs a = emf_fused_args;
     a.chunk = chunk; a.out = out; a.logits = logits; a.codes = codes; a.n = n;
+    // Workgroups per stream group: the step is a chain of latency-bound phases on one 16-row tile, so a few streams are
+    // spread over up to 8 CUs each (feed-forward hidden units split 8 ways, one exchange per layer); with many streams
+    // the groups themselves fill the CUs and the split only has to keep the launch short beside the vocoder.
+    if (emf_cluster > 0) a.cs = emf_cluster;
+    else {
+      const int groups = (n + cnk::emformer_fused_streams_per_block(a) - 1) / cnk::emformer_fused_streams_per_block(a);
+      a.cs = cnk::EMF_MAX_CLUSTER;
+      while (a.cs > 1 && groups * a.cs > 64) a.cs >>= 1;
+    }
     cnk::launch_emformer_fused(a, st);
     return;
   }

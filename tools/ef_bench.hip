@@ -6,6 +6,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include "emformer_fused.hip"
 
 static float* dev(size_t n, float scale) {
@@ -38,6 +39,10 @@ int main(int argc, char** argv) {
 #ifdef EF_STAMPS
   hipMalloc(&a.dbg, 64 * 8); hipMemset(a.dbg, 0, 64 * 8);
 #endif
+  a.cs = argc > 3 ? atoi(argv[3]) : 1;
+  { const size_t xf = cnk::emformer_cluster_xch_floats(B, D), fw = cnk::emformer_cluster_flag_words(B);
+    hipMalloc(&a.xch, xf * 4); unsigned* words; hipMalloc(&words, fw * 4); hipMemset(words, 0, fw * 4);
+    a.xflag = words; a.xepoch = words + (size_t)B * cnk::EMF_MAX_LAYERS * cnk::EMF_MAX_CLUSTER; }
   if (!cnk::emformer_fused_supported(a)) { printf("unsupported\n"); return 1; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 5; ++it) { hipMemcpy(dp, hp.data(), B * 4, hipMemcpyHostToDevice); cnk::launch_emformer_fused(a, 0); }
@@ -48,6 +53,16 @@ int main(int argc, char** argv) {
     hipEventRecord(e0, 0); cnk::launch_emformer_fused(a, 0); hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
   }
+  { // reference run with one workgroup per group, same state
+    std::vector<float> h1((size_t)B * U * K), h2(h1.size());
+    const int cs_keep = a.cs;
+    hipMemcpy(dp, hp.data(), B * 4, hipMemcpyHostToDevice); cnk::launch_emformer_fused(a, 0); hipMemcpy(h2.data(), lg, h2.size() * 4, hipMemcpyDeviceToHost);
+    a.cs = 1; hipMemcpy(dp, hp.data(), B * 4, hipMemcpyHostToDevice); cnk::launch_emformer_fused(a, 0); hipMemcpy(h1.data(), lg, h1.size() * 4, hipMemcpyDeviceToHost);
+    a.cs = cs_keep;
+    double worst = 0, mx = 0; for (size_t i = 0; i < h1.size(); ++i) { worst = std::max(worst, (double)std::fabs(h1[i] - h2[i])); mx = std::max(mx, (double)std::fabs(h1[i])); }
+    printf("cs=%d vs cs=1: max|diff| %.3e (max|ref| %.3f)\n", a.cs, worst, mx); }
+  { std::vector<float> hl((size_t)B * U * K); hipMemcpy(hl.data(), lg, hl.size() * 4, hipMemcpyDeviceToHost);
+    double cs_ = 0; for (float v : hl) cs_ += (double)v * v; printf("logits sum of squares %.9e (cs=%d)\n", cs_, a.cs); }
   printf("B=%d past=%d  kernel %.1f us (hipGetLastError=%d)\n", B, past0, best * 1e3f, (int)hipGetLastError());
 #ifdef EF_STAMPS
   unsigned long long st[16]; hipMemcpy(st, a.dbg, sizeof(st), hipMemcpyDeviceToHost);
