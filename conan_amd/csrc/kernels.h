@@ -130,6 +130,8 @@ struct RowConvArgs {
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);
 void launch_rowconv(const RowConvArgs& a, hipStream_t st);
+const char* rowconv_kernel_name(const RowConvArgs& a);   // as rocprofv3 prints it
+const char* rowconv_kernel_name(const RowConvArgs& a);   // as rocprofv3 prints it
 
 // LayerNorm over the channel axis of each row:
 //   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])

@@ -17,6 +17,7 @@
 //     resblock_fused.hip) stream from L2 straight into registers through a 4-deep ring; the K loop has no barrier;
 //   * separate LayerNorm launches disappear (13 per decoder step).
 #include <atomic>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -44,9 +45,13 @@ constexpr int RC_MAXSEG = 8;       // streams a tile may touch (T >= 2)
 
 // NCW column tiles x NRW row tiles per wave: <1,1> / <4,1> for the decoder's frame-rate layers, <1,2> for the 32-row
 // stream tiles of the first vocoder stage (C = 256, T = 32: too few rows per stream for the fused resblock pass)
-template <int NCW, int NRW>
+// KW = 4 (one row tile in the whole launch: a handful of streams): the four waves of a block share ONE 16-column strip
+// and split its K groups, partial tiles meet in LDS - the serial MFMA chain and the weight stream per wave shrink 4x and
+// the launch has 4x the blocks.
+template <int NCW, int NRW, int KW = 1>
 __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
-  constexpr int RC_D = (NCW * NRW == 1) ? 8 : 4;
+  static_assert(KW == 1 || (NCW == 1 && NRW == 1), "K split: one tile per wave");
+  constexpr int RC_D = (KW > 1) ? 4 : (NCW * NRW == 1) ? 8 : 4;
   constexpr int TMB = RC_TM * NRW;                     // output rows per block
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
   // ---- K loop: wave w owns column tiles ct0 .. ct0 + NCW - 1 of this block's strip
   const int KQ = Cin >> 4;                              // 16-deep K groups per tap (power of two, >= RC_D)
   const int NG = k * KQ;
-  const int ct0 = (ntile * 4 + wave) * NCW;
+  const int ct0 = KW > 1 ? ntile : (ntile * 4 + wave) * NCW;
+  const int g_lo = KW > 1 ? (NG / KW) * wave : 0, g_hi = KW > 1 ? g_lo + NG / KW : NG;    // NG % (KW * RC_D) == 0 (host)
   const int lr = lane & 15, lg = lane >> 4;
   const float* abase[NRW];
 #pragma unroll
@@ -191,20 +197,20 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
     for (int u = 0; u < RC_D; ++u) {
 #pragma unroll
-      for (int c = 0; c < NCW; ++c) bw[u][c] = rc_gload4(wl + c * ct_stride + (long long)u * 256);
+      for (int c = 0; c < NCW; ++c) bw[u][c] = rc_gload4(wl + c * ct_stride + (long long)(g_lo + u) * 256);
       __builtin_amdgcn_sched_barrier(0);
     }
     const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
     const int tstep = d * LDX;
     float4 af[NRW];
 #pragma unroll
-    for (int r = 0; r < NRW; ++r) af[r] = *reinterpret_cast<const float4*>(abase[r]);
-    for (int G0 = 0; G0 < NG; G0 += RC_D) {
+    for (int r = 0; r < NRW; ++r) af[r] = *reinterpret_cast<const float4*>(abase[r] + (g_lo >> kqs) * tstep + (g_lo & kqm) * 16);
+    for (int G0 = g_lo; G0 < g_hi; G0 += RC_D) {
 #pragma unroll
       for (int u = 0; u < RC_D; ++u) {
         const int Gn = G0 + u + 1;                      // next group's A fragments (past the end: an in-bounds dummy)
         const int jn = Gn >> kqs, qn = Gn & kqm;
-        const int aoff = Gn < NG ? jn * tstep + qn * 16 : 0;
+        const int aoff = Gn < g_hi ? jn * tstep + qn * 16 : 0;
         float4 afn[NRW];
 #pragma unroll
         for (int r = 0; r < NRW; ++r) afn[r] = *reinterpret_cast<const float4*>(abase[r] + aoff);
@@ -236,6 +242,17 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
       }
     }
   }
+  if constexpr (KW > 1) {   // partial tiles of waves 1 .. KW-1 -> LDS (behind the window); wave 0 sums in wave order
+    float* const red = win + a.wr_max * LDX;
+    const f32x4 part = accs[0][0][0] + accs[NACC - 1][0][0];
+    if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = part;
+    __syncthreads();
+    if (wave > 0) return;
+    f32x4 sum = part;
+#pragma unroll
+    for (int w = 1; w < KW; ++w) sum += *reinterpret_cast<const f32x4*>(red + ((w - 1) * 64 + lane) * 4);
+    accs[0][0][0] = sum; accs[NACC - 1][0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   // ---- epilogue: lane (g, n) holds rows 4g .. 4g+3 of column n of each of its column tiles
   const float scale = a.out_scale;
   const int act = a.out_act;
@@ -255,7 +272,7 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 #pragma unroll
       for (int q = 1; q < RC_MAXSEG; ++q) if (seg_i[q] == i) s = q;
       const int slot = seg_slot[s], pos = seg_pos[s];
-      float v = ((NACC == 2 ? accs[0][rr][c][e] + accs[NACC - 1][rr][c][e] : accs[0][rr][c][e]) + bias) * scale;
+      float v = ((NACC == 2 && KW == 1 ? accs[0][rr][c][e] + accs[NACC - 1][rr][c][e] : accs[0][rr][c][e]) + bias) * scale;
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
       else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
 }
 
 int rowconv_lds_bytes(const RowConvArgs& a) {
-  return (32 + a.wr_max * (a.Cin + 8)) * 4;
+  return (32 + a.wr_max * (a.Cin + 8) + 3 * 64 * 4) * 4;    // window + the K-split reduction patch
 }
 
 static int rc_window_rows(int tm, int T, int halo) {
@@ -285,7 +302,7 @@ bool rowconv_supported(int Cin, int ktaps, int dil, int T) {
   return (32 + wr * (Cin + 8)) * 4 <= 60 * 1024;
 }
 
-template <int NCW, int NRW>
+template <int NCW, int NRW, int KW = 1>
 static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t st) {
   if (lds > 64 * 1024) {   // more dynamic LDS than the default cap: once per device
     static std::atomic<unsigned long long> devs{0};
@@ -293,11 +310,26 @@ static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(devs.load(std::memory_order_acquire) & bit)) {
-      (void)hipFuncSetAttribute((const void*)rowconv_kernel<NCW, NRW>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);   // + 240 B static
+      (void)hipFuncSetAttribute((const void*)rowconv_kernel<NCW, NRW, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);   // + 240 B static
       devs.fetch_or(bit, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL((rowconv_kernel<NCW, NRW>), dim3(nt, mt), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((rowconv_kernel<NCW, NRW, KW>), dim3(nt, mt), dim3(256), lds, st, a);
+}
+
+// which instantiation a launch uses: 0 <1,1,1>, 1 <4,1,1>, 2 <1,2,1>, 3 <1,1,4>
+static int rc_variant(const RowConvArgs& a) {
+  static const bool no_ksplit = getenv("CONAN_RC_NOKSPLIT") != nullptr;   // developer switch
+  if (a.rows32) return 2;
+  const int mt = (a.n * a.T + RC_TM - 1) / RC_TM;
+  // a single row tile (<= 16 rows in the launch): K split over the waves of a block, one 16-column strip per block
+  if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 16) == 0 && !no_ksplit) return 3;
+  // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
+  return a.Cout_pad >= 1024 ? 1 : 0;
+}
+const char* rowconv_kernel_name(const RowConvArgs& a) {
+  static const char* names[4] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 2, 1>", "cnk::rowconv_kernel<1, 1, 4>"};
+  return names[rc_variant(a)];
 }
 
 void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
@@ -306,17 +338,16 @@ void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
   if (M <= 0) return;
   const int halo = (a.ktaps - 1) * a.dil;
   const int ncols = a.Cout_pad;
-  if (a.rows32) {   // 32-row tiles (T a multiple of 32: a tile never straddles two streams)
-    a.wr_max = rc_window_rows(32, T, halo);
-    rc_launch<1, 2>(a, (M + 31) / 32, (ncols + 63) / 64, rowconv_lds_bytes(a), st);
-    return;
-  }
-  a.wr_max = rc_window_rows(RC_TM, T, halo);
-  const int mt = (M + RC_TM - 1) / RC_TM;
+  const int v = rc_variant(a);
+  a.wr_max = rc_window_rows(v == 2 ? 32 : RC_TM, T, halo);   // (32-row tiles: T a multiple of 32, a tile never straddles two streams)
   const int lds = rowconv_lds_bytes(a);
-  // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
-  if (ncols >= 1024) rc_launch<4, 1>(a, mt, (ncols + 255) / 256, lds, st);
-  else rc_launch<1, 1>(a, mt, (ncols + 63) / 64, lds, st);
+  const int mt = (M + RC_TM - 1) / RC_TM;
+  switch (v) {
+    case 2: rc_launch<1, 2>(a, (M + 31) / 32, (ncols + 63) / 64, lds, st); break;
+    case 3: rc_launch<1, 1, 4>(a, 1, (ncols + 15) / 16, lds, st); break;
+    case 1: rc_launch<4, 1>(a, mt, (ncols + 255) / 256, lds, st); break;
+    default: rc_launch<1, 1>(a, mt, (ncols + 63) / 64, lds, st); break;
+  }
 }
 
 }  // namespace cnk

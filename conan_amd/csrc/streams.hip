@@ -112,7 +112,7 @@ cnk::RowConvArgs conan_streams::mk_rc(const PackedConv& pc, const TRef& x, const
 
 void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
   const double fl = 2.0 * (double)a.n * a.T * a.Cout * a.ktaps * a.Cin;
-  profiled(a.rows32 ? "cnk::rowconv_kernel<1, 2>" : (a.Cout_pad >= 1024 ? "cnk::rowconv_kernel<4, 1>" : "cnk::rowconv_kernel<1, 1>"), fl, st, [&] { cnk::launch_rowconv(a, st); });
+  profiled(cnk::rowconv_kernel_name(a), fl, st, [&] { cnk::launch_rowconv(a, st); });
 }
 
 // one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
