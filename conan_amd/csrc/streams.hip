@@ -60,19 +60,25 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
   const int wsi = ws_index(st);
   g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1;
-  if (nprob == 1 && cnk::conv_cfg_tm(cfg) == 32) {
-    const ConvArgs& a = g.p[0];
+  if (cnk::conv_cfg_tm(cfg) == 32) {
+    // (grouped launches: one split factor for all problems, sized by the longest K loop)
     const int TM = cnk::conv_cfg_tm(cfg), TN = cnk::conv_cfg_tn(cfg);
     const int KS = cnk::conv_cfg_ks(cfg);
-    const long long tiles = (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
-    const int nks = a.ktaps * ((a.Cin_pad + KS - 1) / KS);
+    long long tiles = 0;
+    int nks = 0;
+    for (int p = 0; p < nprob; ++p) {
+      const ConvArgs& a = g.p[p];
+      tiles += (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
+      nks = std::max(nks, a.ktaps * ((a.Cin_pad + KS - 1) / KS));
+    }
     int S = tiles > 0 ? (int)(ctx->num_cu / tiles) : 1;
     if (S > nks / 2) S = nks / 2;
     if (S > 16) S = 16;
     while (S > 1 && tiles * S * TM * TN > sk_slab_floats) --S;
-    // the hand-off (partial-tile stores, agent-scope release/acquire, ticket) costs about as much as ~6 K-steps:
-    // split only when it removes at least a dozen steps from the critical path
-    if (S >= 2 && tiles <= sk_max_tiles && nks - nks / S >= 12) g.ksplit = S;
+    // the hand-off (partial-tile stores, agent-scope release/acquire, ticket) costs about as much as ~6 K-steps of 32
+    // channels: split only when it removes clearly more than that from the critical path
+    static const int min_saved = getenv("CONAN_SK_MIN") ? atoi(getenv("CONAN_SK_MIN")) : 12;
+    if (S >= 2 && tiles <= sk_max_tiles && (nks - nks / S) * (KS / 32) >= min_saved) g.ksplit = S;
   }
   double fl = 0.0;
   for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
