@@ -439,7 +439,7 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
     else {
       const int groups = (n + cnk::emformer_fused_streams_per_block(a) - 1) / cnk::emformer_fused_streams_per_block(a);
       a.cs = cnk::EMF_MAX_CLUSTER;
-      while (a.cs > 1 && groups * a.cs > 64) a.cs >>= 1;
+      while (a.cs > 1 && groups * a.cs > 128) a.cs >>= 1;     // (B = 64: 128 workgroups, 147 us alone; 256 cost the vocoder 6 %)
     }
     cnk::launch_emformer_fused(a, st);
     return;
