@@ -111,6 +111,7 @@ int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu);   
 bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
 const char* resblock_fused_name(int C, int rows);
 
+
 // Frame-rate conv / linear of the decoder step with an optional LayerNorm in front (rowconv.hip).
 struct RowConvArgs {
   TRef x;               // input rows; with ln: the raw rows of THIS step (earlier rows come from `hist`)
@@ -125,7 +126,6 @@ struct RowConvArgs {
   int Cin, Cout, Cout_pad, ktaps, dil, T, n;
   int out_act; float out_scale, out_slope;
   int in_lrelu; float in_slope;   // LeakyReLU applied to the input window (HiFi-GAN resblock convs read raw tensors)
-  int rows32;           // 32-row tiles, two row tiles per wave (requires T % 32 == 0)
   int wr_max;           // filled by launch_rowconv: window rows of a tile
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);

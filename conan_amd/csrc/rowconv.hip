@@ -43,8 +43,9 @@ constexpr int RC_TM = 16;          // output rows per MFMA row tile
 constexpr int RC_MAXSEG = 8;       // streams a tile may touch (T >= 2)
 // depth of the weight-fragment ring (K groups in flight): 8 x 4 MFMAs for one column tile per wave, 4 x 16 for four
 
-// NCW column tiles x NRW row tiles per wave: <1,1> / <4,1> for the decoder's frame-rate layers, <1,2> for the 32-row
-// stream tiles of the first vocoder stage (C = 256, T = 32: too few rows per stream for the fused resblock pass)
+// NCW column tiles x NRW row tiles per wave: <1,1> / <4,1> for the decoder's frame-rate layers.  (NRW = 2, 32-row tiles,
+// was measured for the decoder at 64 streams and for the first vocoder stage: its 70-100 KB window no longer fits on a
+// CU beside a vocoder block and the step got 14 % slower - see DESIGN.md; only NRW = 1 is instantiated.)
 // KW = 4 (one row tile in the whole launch: a handful of streams): the four waves of a block share ONE 16-column strip
 // and split its K groups, partial tiles meet in LDS - the serial MFMA chain and the weight stream per wave shrink 4x and
 // the launch has 4x the blocks.
@@ -317,18 +318,17 @@ static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t
   hipLaunchKernelGGL((rowconv_kernel<NCW, NRW, KW>), dim3(nt, mt), dim3(256), lds, st, a);
 }
 
-// which instantiation a launch uses: 0 <1,1,1>, 1 <4,1,1>, 2 <1,2,1>, 3 <1,1,4>
+// which instantiation a launch uses: 0 <1,1,1>, 1 <4,1,1>, 2 <1,1,4>
 static int rc_variant(const RowConvArgs& a) {
   static const bool no_ksplit = getenv("CONAN_RC_NOKSPLIT") != nullptr;   // developer switch
-  if (a.rows32) return 2;
   const int mt = (a.n * a.T + RC_TM - 1) / RC_TM;
   // a single row tile (<= 16 rows in the launch): K split over the waves of a block, one 16-column strip per block
-  if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 16) == 0 && !no_ksplit) return 3;
+  if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 16) == 0 && !no_ksplit) return 2;
   // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
   return a.Cout_pad >= 1024 ? 1 : 0;
 }
 const char* rowconv_kernel_name(const RowConvArgs& a) {
-  static const char* names[4] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 2, 1>", "cnk::rowconv_kernel<1, 1, 4>"};
+  static const char* names[3] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 1, 4>"};
   return names[rc_variant(a)];
 }
 
@@ -339,12 +339,11 @@ void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
   const int halo = (a.ktaps - 1) * a.dil;
   const int ncols = a.Cout_pad;
   const int v = rc_variant(a);
-  a.wr_max = rc_window_rows(v == 2 ? 32 : RC_TM, T, halo);   // (32-row tiles: T a multiple of 32, a tile never straddles two streams)
+  a.wr_max = rc_window_rows(RC_TM, T, halo);
   const int lds = rowconv_lds_bytes(a);
   const int mt = (M + RC_TM - 1) / RC_TM;
   switch (v) {
-    case 2: rc_launch<1, 2>(a, (M + 31) / 32, (ncols + 63) / 64, lds, st); break;
-    case 3: rc_launch<1, 1, 4>(a, 1, (ncols + 15) / 16, lds, st); break;
+    case 2: rc_launch<1, 1, 4>(a, 1, (ncols + 15) / 16, lds, st); break;
     case 1: rc_launch<4, 1>(a, mt, (ncols + 255) / 256, lds, st); break;
     default: rc_launch<1, 1>(a, mt, (ncols + 63) / 64, lds, st); break;
   }

@@ -313,27 +313,6 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         if (d + 1 < ND) { a2.y2_base = s.xa[b][d].base; a2.y2_slope = LR; }
         g2.p[b] = a2;
       }
-      // Experiment (CONAN_RC32=1, off by default): C = 256 at 32 rows per stream through rowconv's 32-row stream tiles, one
-      // launch per branch and conv.  Measured at 64 streams: 18 launches x 35 us = 0.64 ms against 6 grouped conv_mfma
-      // launches x 66 us = 0.40 ms (one 86 KB block per CU, every block pays its own window load) - not used.
-      bool rc32 = use_rowconv && T % 32 == 0 && getenv("CONAN_RC32") != nullptr;
-      for (int b = 0; b < NB && rc32; ++b)
-        rc32 = ctx->conv("voc.rb." + std::to_string(ridx + b) + ".c1." + std::to_string(d)).wf != nullptr && s.C % 64 == 0 && s.C <= 512 &&
-               (c.voc_rb_kernels[b] * (s.C / 16)) % 8 == 0 && (32 + (32 + (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]) * (s.C + 8)) * 4 <= 150 * 1024;
-      if (rc32) {
-        for (int pass = 0; pass < 2; ++pass)
-          for (int b = NB - 1; b >= 0; --b) {       // longest kernel first
-            const ConvArgs& ca = pass == 0 ? g1.p[b] : g2.p[b];
-            const TRef xin = pass == 0 ? (d == 0 ? s.up.ref() : s.xo[b][d - 1].ref()) : ca.x;
-            const PackedConv& pc = ctx->conv("voc.rb." + std::to_string(ridx + b) + (pass == 0 ? ".c1." : ".c2.") + std::to_string(d));
-            cnk::RowConvArgs ra = mk_rc(pc, xin, ca.y, n, T, ca.dil);
-            ra.pos = pos; ra.rows32 = 1;
-            if (pass == 0) { ra.in_lrelu = 1; ra.in_slope = LR; ra.out_act = cnk::ACT_LRELU; ra.out_slope = LR; }   // reads the RAW tensor
-            else { ra.res = ca.res; ra.has_res = 1; }
-            rowconv(ra, st);
-          }
-        continue;
-      }
       const int cfg = pick_cfg(n * T, s.C, NB);
       launch_group(g1, NB, cfg, st);
       launch_group(g2, NB, cfg, st);
