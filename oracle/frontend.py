@@ -7,11 +7,14 @@ Restates `librosa_wav2spec` (utils/audio/__init__.py:37-84) as called by `Stream
     mel    = librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) @ |x_stft|
     mel    = clip(log10(max(eps, mel)).T, mel_vmin, mel_vmax)
 
-PARITY UNPINNED: the arithmetic lives in librosa (requirements: librosa==0.9.2 is not installed here and not vendored
-in the reference), so this file restates librosa's published algorithm -- periodic Hann window
-(scipy.signal.get_window(..., fftbins=True)), centred frames with zero padding of n_fft//2, rfft, Slaney mel scale with
-'slaney' area normalisation, float32 filterbank -- and the tests pin it only against an independent formulation
-(explicit DFT sums / triangle construction) and its analytic properties.
+PIN: the arithmetic lives in librosa (requirements: librosa==0.9.2), which is neither installed in this image nor
+vendored in the reference, so the reference's own output cannot be generated here.  This file restates librosa's
+published algorithm -- periodic Hann window (scipy.signal.get_window(..., fftbins=True)), centred frames with zero
+padding of n_fft//2, rfft, Slaney mel scale with 'slaney' area normalisation, float32 filterbank -- and
+tests/test_oracle_frontend.py pins it against two independent public implementations that ARE in the image:
+`transformers.audio_utils.{mel_filter_bank, window_function, spectrogram}` (documented as librosa-equivalent; filterbank
+equal to 2e-9, log-mel to 1e-6) and `torch.stft` (magnitudes to 2e-7 of the peak), besides the explicit DFT sums /
+triangle construction and analytic properties.  Against librosa itself it stays unpinned.
 """
 import numpy as np
 import scipy.signal

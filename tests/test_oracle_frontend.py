@@ -1,7 +1,8 @@
 """The mel front-end oracle (oracle/frontend.py) restates librosa's published algorithm; librosa is not installed here
-and the reference holds no fixture for it (PARITY UNPINNED), so it is pinned against an independently written
-formulation and analytic properties."""
+and the reference holds no fixture for it, so it is pinned against two independent public implementations in the image
+(transformers.audio_utils, torch.stft), an independently written formulation and analytic properties."""
 import numpy as np
+import pytest
 
 from oracle import frontend as fe
 
@@ -52,3 +53,39 @@ def test_wav2mel_shape_clip_and_tone_location():
     loud = int(np.argmax(mel[10]))
     assert abs(fb_centres[loud] - 440) < 60                                       # the 440 Hz partial dominates
     assert np.all(fe.wav2mel(np.zeros(3200, np.float32)) == -6.0)                 # silence sits on the floor
+
+
+def _signal(seed=3, dur=1.3, extra=57):
+    rng = np.random.default_rng(seed)
+    t = np.arange(int(dur * 16000) + extra) / 16000
+    return (0.5 * np.sin(2 * np.pi * 220 * t) * np.exp(-t) + 0.1 * np.sin(2 * np.pi * 3100 * t) + 0.02 * rng.standard_normal(t.shape)).astype(np.float32)
+
+
+def test_pinned_against_transformers_audio_utils():
+    """Independent public implementation #1: transformers.audio_utils (documented as librosa-compatible) - Slaney
+    filterbank, periodic Hann, centred zero-padded amplitude spectrogram, log10 with floor."""
+    au = pytest.importorskip("transformers.audio_utils")
+    p = fe.DEFAULTS
+    fb = au.mel_filter_bank(num_frequency_bins=1 + p["fft_size"] // 2, num_mel_filters=p["num_mels"], min_frequency=p["fmin"],
+                            max_frequency=p["fmax"], sampling_rate=p["sample_rate"], norm="slaney", mel_scale="slaney")
+    mine = fe.mel_filterbank(p["sample_rate"], p["fft_size"], p["num_mels"], p["fmin"], p["fmax"])
+    assert fb.shape == mine.T.shape and np.abs(fb.T - mine).max() < 1e-8
+    # (the pure tone has mel bins 6 decades below its peak: there the oracle carries librosa's complex64 rounding, the
+    # transformers routine computes in float64 - 1e-3 in log10 units covers that noise floor)
+    for wav, tol in ((_signal(), 1e-5), (_signal(5, 0.4, 0), 1e-5), ((0.9 * np.sin(2 * np.pi * 440 * np.arange(9000) / 16000)).astype(np.float32), 1e-3)):
+        win = au.window_function(p["win_length"], "hann", periodic=True)
+        spec = au.spectrogram(wav, win, frame_length=p["win_length"], hop_length=p["hop_size"], fft_length=p["fft_size"], power=1.0, center=True,
+                              pad_mode="constant", onesided=True, mel_filters=fb, mel_floor=p["eps"], log_mel="log10")
+        ref = np.clip(spec.T, p["mel_vmin"], p["mel_vmax"])
+        got = fe.wav2mel(wav)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < tol, np.abs(got - ref).max()
+
+
+def test_stft_pinned_against_torch_stft():
+    """Independent public implementation #2: torch.stft(center=True, pad_mode='constant', periodic Hann)."""
+    import torch
+    wav = _signal()
+    S = torch.stft(torch.from_numpy(wav), 1024, hop_length=320, win_length=1024, window=torch.hann_window(1024, periodic=True), center=True,
+                   pad_mode="constant", return_complex=True).abs().numpy()
+    mag = fe.stft_mag(wav, 1024, 320, 1024)
+    assert S.shape == mag.shape and np.abs(S - mag).max() < 1e-6 * mag.max()
