@@ -345,7 +345,9 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
     const float* const b1 = RB_SEL(p, b1);
     const long long ct_stride = (long long)(k + 1) * G::KQ * 256;       // floats per column tile (k taps + one zero tap)
     const int zrows = __builtin_amdgcn_readfirstlane(meta[0]);
-    float b1v[G::NCW];
+    float b1v[G::NCW];            // c1's bias: loaded now, needed behind the first GEMM
+#pragma unroll
+    for (int c = 0; c < G::NCW; ++c) b1v[c] = gload1(b1 + (ct0 + c) * 16 + lr);
     int pn;
     // ---------------- c1 over the halo-extended rows
     {
@@ -364,9 +366,6 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
       unsigned long long s1 = RB_T(); st_gemm += s1 - s0;
 #endif
-      // c1's bias: in flight across the barrier
-#pragma unroll
-      for (int c = 0; c < G::NCW; ++c) b1v[c] = gload1(b1 + (ct0 + c) * 16 + lr);
 #if RB_ABLATE & 4
       { unsigned long long q0 = RB_T(); bar(); unsigned long long q1 = RB_T(); st_b3 += q1 - q0; st_bar += q1 - s1; }
 #else
