@@ -15,6 +15,17 @@
 //   16-lane rows per (stream, head), K/V rows in registers, DPP row reductions -> out_proj + residual -> LN -> FFN in
 //   256-wide hidden chunks (FF1 -> ReLU -> LDS -> FF2 accumulate, K split over the 4 waves) -> + residual -> LN.
 // Token order inside a stream is [right context | utterance] like torchaudio's _EmformerLayer.infer.
+//
+// Cluster mode (EmfFusedArgs::cs = 2, 4, 8): the step is a chain of latency-bound phases on ONE 16-row tile, 69 % of it
+// the feed-forward GEMMs, so with few streams most of the chip idles for 245 us.  cs consecutive workgroups (dealt
+// round-robin over the XCDs: one per XCD) then own the same streams; each runs every phase redundantly except the
+// feed-forward, of which it takes hidden chunks m, m + cs, ...; the partial [16 x D] sums meet in global memory once per
+// layer (agent-scope write-through stores / sc1 loads, a per-member flag word carrying the launch epoch - no fence, so
+// the weights in this XCD's L2 survive; with release / acquire fences the step measured 181 us instead of 141) and are
+// summed in member order, so every member continues with identical bits.  Member 0 alone writes rings, outputs and
+// past lengths.  One stream: 245 -> 121 us; 64 streams as 32 groups x 4: 147 us.  Forward progress does not need all
+// workgroups resident at once: workgroups are dispatched in index order on every XCD, so the members of the earliest
+// unfinished cluster are always dispatched before any member of a later one.
 #include <atomic>
 #include "kernels.h"
 
@@ -494,17 +505,11 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's partial-sum stores are complete ...
       ef_barrier();
-#ifdef EF_XFENCE
-      if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
       if (tid == 0) __hip_atomic_store(fl + member, xtarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag goes out
       if (tid < cs) {
         while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xtarget) __builtin_amdgcn_s_sleep(2);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef EF_XFENCE
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
       ef_barrier();
       float pv[EMF_MAX_CLUSTER][XE];
 #pragma unroll

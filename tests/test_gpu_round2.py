@@ -115,6 +115,45 @@ def test_emformer_memory_bank_vs_oracle(M, tanh):
     st.close(); ctx.close()
 
 
+def test_emformer_cluster_mode_matches_single_workgroup(monkeypatch):
+    """The fused Emformer step spread over clusters of 8 / 4 / 2 workgroups per stream group (feed-forward hidden units
+    split over the cluster, one write-through exchange of partial sums per layer, emformer_fused.hip) against the same
+    step with one workgroup per group, over 30 chunks (left-context ring wraps, a stream restarts half way): logits within
+    fp32 re-association noise (1e-5), codes equal off the decision margin, and bit-identical run to run.  Stream sets
+    read CONAN_EMF_CLUSTER when they are created, so one process can hold all variants."""
+    from oracle import emformer as oemf
+    ctx, chp, _ = _ctx(conan=False, hifigan=False)
+    B, T = 5, 120
+    mel = torch.from_numpy(synth.mel(T, 41, B))
+    slots = [4, 1, 0, 3, 2]
+    sets = {}
+    for cs in ("1", "2", "4", "8", "8"):
+        monkeypatch.setenv("CONAN_EMF_CLUSTER", cs)
+        sets.setdefault(cs, []).append(ctx.streams(6, max_frames=4, max_ref_frames=16))
+    monkeypatch.delenv("CONAN_EMF_CLUSTER")
+    allsets = [st for v in sets.values() for st in v]
+    for st in allsets:
+        st.reset(slots)
+    for n_chunk, (pos, emit, chunk) in enumerate(oemf.chunk_iter(mel, 4, 2)):
+        if n_chunk == 13:
+            for st in allsets:
+                st.reset([slots[1]], which=1)
+        x = chunk.cuda()
+        o1, lg1, c1 = sets["1"][0].emformer_step(slots, x)
+        for cs in ("2", "4", "8"):
+            o, lg, c = sets[cs][0].emformer_step(slots, x)
+            np.testing.assert_allclose(lg.cpu().numpy(), lg1.cpu().numpy(), atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(o.cpu().numpy(), o1.cpu().numpy(), atol=1e-5, rtol=1e-5)
+            top2 = lg1.topk(2, -1).values
+            safe = ((top2[..., 0] - top2[..., 1]) > 1e-4).cpu()
+            assert torch.equal(c.cpu()[safe], c1.cpu()[safe])
+        o8b, lg8b, c8b = sets["8"][1].emformer_step(slots, x)
+        assert torch.equal(lg8b, lg) and torch.equal(c8b, c) and torch.equal(o8b, o)      # same cluster size: same bits
+    for st in allsets:
+        st.close()
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------- loop fixture
 @pytest.mark.parametrize("tag,tiny", [("tiny", True), ("full", False)])
 def test_loop_golden_through_hip_steps(tag, tiny):
