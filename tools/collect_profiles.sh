@@ -18,6 +18,6 @@ python3 tools/summarize_pmc.py --cmd "$CMD" --steps $STEPS --out $O/pmc.json $O/
 mkdir -p profiles
 cp $O/stats/run_kernel_stats.csv profiles/r2_${W}_kernel_stats.csv 2>/dev/null
 cp $O/pmc.json profiles/r2_${W}_pmc.json; cp $O/pmc.txt profiles/r2_${W}_pmc.txt
-mkdir -p gpurun_out/profiles_r2; cp profiles/r2_${W}_* gpurun_out/profiles_r2/
+mkdir -p gpurun_out/profiles_r2; cp profiles/r2_${W}_kernel_stats.csv profiles/r2_${W}_pmc.json profiles/r2_${W}_pmc.txt gpurun_out/profiles_r2/
 rm -f $O/*/run_kernel_trace.csv
 head -8 $O/stats/run_kernel_stats.csv | cut -c1-160; head -20 $O/pmc.txt
