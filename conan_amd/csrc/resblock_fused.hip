@@ -144,7 +144,12 @@ __device__ __forceinline__ void rb_gemm(const float* __restrict__ src, const int
 #define RB_SEL(br_, f) ((br_) == 0 ? a.p[0].f : ((br_) == 1 ? a.p[1].f : a.p[2].f))
 
 template <int C, int NR2>
-__global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) {
+// Launch bound 768 for C = 64 (the launch still has 512 threads): it caps the kernel at 168 VGPRs instead of 215 (3 spills,
+// -2 % alone), so two of its waves leave 176 of a SIMD's 512 registers free - room for a wave of another stream's
+// small-block kernels (rowconv: 112) to run on the same CU while this persistent block holds it: the pipelined step
+// gains more than the kernel loses.  <32,20> has that room already (198), <128,*> needs its 224-233 registers (44+ spills
+// under the cap) and its 131 KB of LDS leave no room for a second block anyway.
+__global__ __launch_bounds__(C == 64 ? 768 : 512) void resblock_fused_kernel(const RBArgs a) {
   using G = RBGeom<C, NR2>;
   constexpr int LDX = G::LDX;
   __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 4];      // + meta: {zero rows, next tile, its branch, draw generation}
@@ -207,40 +212,50 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
       if (ht == 0) meta[0] = abs0 >= 0 ? 0 : (abs0 < -(long long)G::XT_ROWS ? G::XT_ROWS : (int)-abs0);
     };
     // Output of a tile in two halves so that the matrix waves never wait for it: out_fetch() right after B2 moves c2's
-    // accumulators from LDS to registers and issues the residual loads (B3 then needs nothing but those LDS reads);
-    // out_store() adds bias + residual and stores, after the next window's loads have been issued.
+    // accumulators from LDS to registers (B3 then needs nothing but those LDS reads); out_store() - during the next tile's
+    // c2, after its window loads have been issued - reads the residual rows in two batches (fewer live registers: the
+    // kernel's VGPR count is what decides whether another stream's blocks fit on the CU beside this one), adds bias +
+    // residual and stores.
     constexpr int NOUT = (G::RO * G::C4) / 256;
     static_assert((G::RO * G::C4) % 256 == 0 && 256 % G::C4 == 0, "output tile / helper threads");
+    constexpr int NOB = (NOUT + 1) / 2;                            // residual rows per batch
     const int oc4 = ht % G::C4;                                    // a thread keeps its channel quad
-    float4 oacc[NOUT], ores[NOUT], ob2;
+    float4 oacc[NOUT];
+    const float* oxb = nullptr; const float* ob2p = nullptr;
     float* oyb = nullptr;
-    unsigned oyr0 = 0, oym = 0;
+    unsigned oyr0 = 0, oym = 0, oxr0 = 0, oxm = 0;
     int ot0 = 0;
     auto out_fetch = [&](const int p, const int i, const int t0, const int slot, const int pos) __attribute__((always_inline)) {
       const int xmode = a.p[0].x.mode, xrate = a.p[0].x.rate, ymode = a.p[0].y.mode, yrate = a.p[0].y.rate;
-      const float* xb = RB_SEL(p, x.base) + (long long)(xmode == 0 ? slot : i) * RB_SEL(p, x.slot_stride);
+      oxb = RB_SEL(p, x.base) + (long long)(xmode == 0 ? slot : i) * RB_SEL(p, x.slot_stride);
       oyb = RB_SEL(p, y.base) + (long long)(ymode == 0 ? slot : i) * RB_SEL(p, y.slot_stride);
-      const unsigned xr0 = (xmode == 0 ? (unsigned)pos * (unsigned)xrate : 0u) + (unsigned)(RB_SEL(p, x.off) + t0);
+      oxr0 = (xmode == 0 ? (unsigned)pos * (unsigned)xrate : 0u) + (unsigned)(RB_SEL(p, x.off) + t0);
       oyr0 = (ymode == 0 ? (unsigned)pos * (unsigned)yrate : 0u) + (unsigned)(RB_SEL(p, y.off) + t0);
-      const unsigned xm = xmode == 0 ? (unsigned)RB_SEL(p, x.lmask) : 0xffffffffu;
+      oxm = xmode == 0 ? (unsigned)RB_SEL(p, x.lmask) : 0xffffffffu;
       oym = ymode == 0 ? (unsigned)RB_SEL(p, y.lmask) : 0xffffffffu;
       ot0 = t0;
+      ob2p = RB_SEL(p, b2) + oc4 * 4;
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) oacc[u] = *reinterpret_cast<const float4*>(xt + ((ht + 256 * u) / G::C4) * LDX + oc4 * 4);
-      ob2 = gload4(RB_SEL(p, b2) + oc4 * 4);
-#pragma unroll
-      for (int u = 0; u < NOUT; ++u) {
-        const int r = (ht + 256 * u) / G::C4;
-        ores[u] = (t0 + r < T) ? gload4(xb + (long long)((xr0 + (unsigned)r) & xm) * C + oc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
     };
     auto out_store = [&]() __attribute__((always_inline)) {
+      const float4 ob2 = gload4(ob2p);
 #pragma unroll
-      for (int u = 0; u < NOUT; ++u) {
-        const int r = (ht + 256 * u) / G::C4;
-        if (ot0 + r < T)
-          gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4,
-                  make_float4((oacc[u].x + ob2.x) + ores[u].x, (oacc[u].y + ob2.y) + ores[u].y, (oacc[u].z + ob2.z) + ores[u].z, (oacc[u].w + ob2.w) + ores[u].w));
+      for (int h = 0; h < 2; ++h) {
+        float4 ores[NOB];
+#pragma unroll
+        for (int q = 0; q < NOB; ++q) {
+          const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
+          ores[q] = (u < NOUT && ot0 + r < T) ? gload4(oxb + (long long)((oxr0 + (unsigned)r) & oxm) * C + oc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NOB; ++q) {
+          const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
+          if (u < NOUT && ot0 + r < T)
+            gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4,
+                    make_float4((oacc[u].x + ob2.x) + ores[q].x, (oacc[u].y + ob2.y) + ores[q].y, (oacc[u].z + ob2.z) + ores[q].z, (oacc[u].w + ob2.w) + ores[q].w));
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     int p = tile_word(blockIdx.x, 0), i = tile_word(blockIdx.x, 1), t0 = tile_word(blockIdx.x, 2);
