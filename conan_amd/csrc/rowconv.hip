@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
   }
 }
 
-int rowconv_lds_bytes(const RowConvArgs& a) {
-  return (32 + a.wr_max * (a.Cin + 8) + 3 * 64 * 4) * 4;    // window + the K-split reduction patch
+int rowconv_lds_bytes(const RowConvArgs& a, bool ksplit) {
+  return (32 + a.wr_max * (a.Cin + 8) + (ksplit ? 3 * 64 * 4 : 0)) * 4;    // window (+ the K-split reduction patch)
 }
 
 static int rc_window_rows(int tm, int T, int halo) {
@@ -340,7 +340,7 @@ void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
   const int ncols = a.Cout_pad;
   const int v = rc_variant(a);
   a.wr_max = rc_window_rows(RC_TM, T, halo);
-  const int lds = rowconv_lds_bytes(a);
+  const int lds = rowconv_lds_bytes(a, v == 2);
   const int mt = (M + RC_TM - 1) / RC_TM;
   switch (v) {
     case 2: rc_launch<1, 1, 4>(a, 1, (ncols + 15) / 16, lds, st); break;

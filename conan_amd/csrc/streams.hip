@@ -421,7 +421,11 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       a.cs = cnk::EMF_MAX_CLUSTER;
       while (a.cs > 1 && groups * a.cs > 128) a.cs >>= 1;     // (B = 64: 128 workgroups, 147 us alone; 256 cost the vocoder 6 %)
     }
-    cnk::launch_emformer_fused(a, st);
+    // algorithmic FLOPs of the step: per stream and layer Q = R + U query rows against the four D x D projections, the
+    // D x F x 2 feed-forward, and attention over R + LC + U keys; plus the output projection
+    const double Q = R + U, Dd = D, F = c.emf_ffn_dim, keys = R + c.emf_left_context + U;
+    const double fl = (double)n * (c.emf_layers * (2.0 * Q * Dd * (4.0 * Dd + 2.0 * F) + 4.0 * Q * keys * Dd) + 2.0 * U * Dd * c.emf_output_dim);
+    profiled(D == 80 ? "cnk::emformer_fused_kernel<5, 10>" : "cnk::emformer_fused_kernel<4, 8>", fl, st, [&] { cnk::launch_emformer_fused(a, st); });
     return;
   }
   // token order inside the layers is [right_context | utterance] (torchaudio _EmformerLayer.infer): reorder the chunk
