@@ -144,12 +144,7 @@ __device__ __forceinline__ void rb_gemm(const float* __restrict__ src, const int
 #define RB_SEL(br_, f) ((br_) == 0 ? a.p[0].f : ((br_) == 1 ? a.p[1].f : a.p[2].f))
 
 template <int C, int NR2>
-// Launch bound 768 for C = 64 (the launch still has 512 threads): it caps the kernel at 168 VGPRs instead of 215 (3 spills,
-// -2 % alone), so two of its waves leave 176 of a SIMD's 512 registers free - room for a wave of another stream's
-// small-block kernels (rowconv: 112) to run on the same CU while this persistent block holds it: the pipelined step
-// gains more than the kernel loses.  <32,20> has that room already (198), <128,*> needs its 224-233 registers (44+ spills
-// under the cap) and its 131 KB of LDS leave no room for a second block anyway.
-__global__ __launch_bounds__(C == 64 ? 768 : 512) void resblock_fused_kernel(const RBArgs a) {
+__global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) {
   using G = RBGeom<C, NR2>;
   constexpr int LDX = G::LDX;
   __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS + 4];      // + meta: {zero rows, next tile, its branch, draw generation}

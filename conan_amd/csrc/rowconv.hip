@@ -50,7 +50,10 @@ constexpr int RC_MAXSEG = 8;       // streams a tile may touch (T >= 2)
 // and split its K groups, partial tiles meet in LDS - the serial MFMA chain and the weight stream per wave shrink 4x and
 // the launch has 4x the blocks.
 template <int NCW, int NRW, int KW = 1>
-__global__ __launch_bounds__(256) void rowconv_kernel(const RowConvArgs a) {
+// (launch bound: 6 waves per SIMD = at most 80 VGPRs for the one-column-tile variants, which need no spill for it - a wave
+// then fits beside two waves of a fused ResBlock pass (2 x 216 of a SIMD's 512 registers), so the decoder stream's
+// launches run on CUs the vocoder's persistent blocks hold instead of waiting for the end of its kernel)
+__global__ __launch_bounds__(256, NCW == 1 ? 6 : 4) void rowconv_kernel(const RowConvArgs a) {
   static_assert(KW == 1 || (NCW == 1 && NRW == 1), "K split: one tile per wave");
   constexpr int RC_D = (KW > 1) ? 4 : (NCW * NRW == 1) ? 8 : 4;
   constexpr int TMB = RC_TM * NRW;                     // output rows per block
