@@ -55,7 +55,7 @@ struct RBGeom {
   static constexpr int XT_ROWS = 16 * NR1;
   static constexpr int MAXSPAN = 50;                  // (k-1)*dil of c1 (k = 11, dil = 5)
   static constexpr int WR_MAX = XT_ROWS + MAXSPAN;    // window rows
-  static constexpr int LDX = C + 8;
+  static constexpr int LDX = C + (C >= 128 ? 4 : 8);   // (C = 128: 4 floats of padding keep the block at 128 KB - with 8 a rowconv block no longer fits beside it)
   static constexpr int LDS_FLOATS = (WR_MAX + XT_ROWS) * LDX;
   static constexpr int NCT = C / 16;                  // 16-column tiles
   static constexpr int RSPLIT = NCT >= 4 ? 1 : 4 / NCT;   // C = 32: two waves share a column strip and split the rows
@@ -63,6 +63,7 @@ struct RBGeom {
   static constexpr int NRW1 = (NR1 + RSPLIT - 1) / RSPLIT;
   static constexpr int NRW2 = (NR2 + RSPLIT - 1) / RSPLIT;
   static constexpr int KQ = C / 16;                   // 16-deep K groups per tap
+  static constexpr int RING = C >= 128 ? KQ / 2 : KQ; // weight-fragment groups in flight (C = 128: half a tap - 32 registers fewer)
   static constexpr int C4 = C / 4;
   static_assert(C % 32 == 0 && (KQ & (KQ - 1)) == 0 && KQ >= 2, "channel count");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -71,10 +72,10 @@ struct RBGeom {
 // Tap-0 weight fragments of a phase, issued in group order (the in-loop waits are counted vmcnt(N): hipcc merges the
 // prologue's issue order with the loop's at the loop header, and a reversed prologue turns every tap's first wait into
 // vmcnt(0)).  Called ahead of the barrier that precedes the phase, so the loads fly while the block synchronises.
-template <int NCW, int KQ>
-__device__ __forceinline__ void rb_prefetch_w(float4 (&bw)[KQ][NCW], const float* __restrict__ wl, const long long ct_stride) {
+template <int NCW, int RING>
+__device__ __forceinline__ void rb_prefetch_w(float4 (&bw)[RING][NCW], const float* __restrict__ wl, const long long ct_stride) {
 #pragma unroll
-  for (int q = 0; q < KQ; ++q) {
+  for (int q = 0; q < RING; ++q) {
 #pragma unroll
     for (int c = 0; c < NCW; ++c) bw[q][c] = gload4(wl + c * ct_stride + q * 256);
     __builtin_amdgcn_sched_barrier(0);
@@ -85,10 +86,11 @@ __device__ __forceinline__ void rb_prefetch_w(float4 (&bw)[KQ][NCW], const float
 // x W(j, q, column tile c).  `src` is the LDS operand image (row stride LDX), `wl` the wave's first weight fragment
 // (+ lane*4), column tiles ct_stride floats apart, groups 256 floats apart; bw holds tap 0 on entry and tap 0 of
 // (wl_next, ct_stride_next) on exit.
-template <int NRW, int NCW, int LDX, int KQ>
+template <int NRW, int NCW, int LDX, int KQ, int RING>
 __device__ __forceinline__ void rb_gemm(const float* __restrict__ src, const int row0, const int tap_stride, const int k,
                                         const float* __restrict__ wl, const long long ct_stride, const float* __restrict__ wl_next,
-                                        const long long ct_stride_next, f32x4 (&acc)[NRW][NCW], float4 (&bw)[KQ][NCW], const int lane) {
+                                        const long long ct_stride_next, f32x4 (&acc)[NRW][NCW], float4 (&bw)[RING][NCW], const int lane) {
+  static_assert(RING == KQ || 2 * RING == KQ, "weight ring: a tap or half a tap");
   const float* abase = src + (row0 + (lane & 15)) * LDX + 4 * (lane >> 4);
   float4 af[NRW];      // ONE fragment set: row tile r of the next group is read right after the last MFMA that uses af[r]
 #pragma unroll
@@ -109,24 +111,30 @@ __device__ __forceinline__ void rb_gemm(const float* __restrict__ src, const int
 #pragma unroll
       for (int r = 0; r < NRW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].x, bw[q][c].x, acc[r][c], 0, 0, 0);
+        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].x, bw[q % RING][c].x, acc[r][c], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < NRW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].y, bw[q][c].y, acc[r][c], 0, 0, 0);
+        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].y, bw[q % RING][c].y, acc[r][c], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < NRW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].z, bw[q][c].z, acc[r][c], 0, 0, 0);
+        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].z, bw[q % RING][c].z, acc[r][c], 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < NRW; ++r) {
 #pragma unroll
-        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].w, bw[q][c].w, acc[r][c], 0, 0, 0);
+        for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].w, bw[q % RING][c].w, acc[r][c], 0, 0, 0);
         af[r] = *reinterpret_cast<const float4*>(anext + r * 16 * LDX);
       }
-      // this group's weight registers are free: fetch the same group of the next tap (KQ groups ahead)
+      // this group's weight registers are free: fetch the group RING ahead (the same group of the next tap, or - half-tap
+      // ring - the second half of this tap / the first half of the next)
+      if (q + RING < KQ) {
 #pragma unroll
-      for (int c = 0; c < NCW; ++c) bw[q][c] = gload4(wnext + c * cnext + q * 256);
+        for (int c = 0; c < NCW; ++c) bw[q % RING][c] = gload4(wl + (long long)j * KQ * 256 + c * ct_stride + (q + RING) * 256);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) bw[q % RING][c] = gload4(wnext + c * cnext + (q + RING - KQ) * 256);
+      }
       // pin the order: three plain passes, then one LDS read behind each row tile's last MFMA, then the weight loads
       __builtin_amdgcn_sched_group_barrier(0x008, 3 * NRW * NCW, 0);
 #pragma unroll
@@ -341,11 +349,11 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
   unsigned long long st_gemm = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_bar = 0, st_b3 = 0, st_b1 = 0, st_b4 = 0, st_b2 = 0;
 #define RB_T() __builtin_amdgcn_s_memtime()
 #endif
-  float4 bw[G::KQ][G::NCW];
+  float4 bw[G::RING][G::NCW];
   int p = tile_word(blockIdx.x, 0);
   {
     const long long cs = (long long)(RB_SEL(p, k) + 1) * G::KQ * 256;
-    rb_prefetch_w<G::NCW, G::KQ>(bw, RB_SEL(p, w1) + (long long)ct0 * cs + lane * 4, cs);
+    rb_prefetch_w<G::NCW, G::RING>(bw, RB_SEL(p, w1) + (long long)ct0 * cs + lane * 4, cs);
   }
   bar();                                                 // B0: first window staged
   while (p >= 0) {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #if RB_ABLATE & 4
       unsigned long long s0 = RB_T();
 #endif
-      rb_gemm<G::NRW1, G::NCW, LDX, G::KQ>(win, rt0 * 16, d, k, w1 + (long long)ct0 * ct_stride + lane * 4, ct_stride,
+      rb_gemm<G::NRW1, G::NCW, LDX, G::KQ, G::RING>(win, rt0 * 16, d, k, w1 + (long long)ct0 * ct_stride + lane * 4, ct_stride,
                                            w2 + (long long)ct0 * ct_stride + lane * 4, ct_stride, acc, bw, lane);
 #if RB_ABLATE & 4
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #endif
       // (behind the last tap the weight registers are refilled with this phase's tap 0 again: harmless, the next tile
       // is only known after B4)
-      rb_gemm<G::NRW2, G::NCW, LDX, G::KQ>(xt, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 4, ct_stride,
+      rb_gemm<G::NRW2, G::NCW, LDX, G::KQ, G::RING>(xt, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 4, ct_stride,
                                            w2 + (long long)ct0 * ct_stride + lane * 4, ct_stride, acc, bw, lane);
 #if RB_ABLATE & 4
       asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
       pn = __builtin_amdgcn_readfirstlane(meta[2]);
       if (pn >= 0) {
         const long long csn = (long long)(RB_SEL(pn, k) + 1) * G::KQ * 256;
-        rb_prefetch_w<G::NCW, G::KQ>(bw, RB_SEL(pn, w1) + (long long)ct0 * csn + lane * 4, csn);
+        rb_prefetch_w<G::NCW, G::RING>(bw, RB_SEL(pn, w1) + (long long)ct0 * csn + lane * 4, csn);
       }
 #pragma unroll
       for (int c = 0; c < G::NCW; ++c) {
