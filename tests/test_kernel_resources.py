@@ -1,0 +1,69 @@
+"""Register / LDS budgets of the built kernels, read from the code objects inside libconan_hip.so.
+
+Why a test: the pipelined chunk step runs the vocoder's persistent one-block-per-CU launches on one stream and the
+decoder's small launches on another; whether a decoder block can start on a CU that a vocoder block holds is decided by
+what is left of the CU's 160 KB of LDS and of the 512 VGPRs per SIMD lane ("Pipelined steps").  These
+numbers are a performance contract between kernels of different files - a change that costs a few registers in one of
+them silently costs 2 % of the step."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conan_amd", "libconan_hip.so")
+
+
+def _kernels(tmp_path):
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(LIB)):
+        pytest.skip("llvm tools or the built library not present")
+    lib = shutil.copy(LIB, tmp_path / "lib.so")          # --offloading extracts the bundles next to its input
+    subprocess.run([objdump, "--offloading", lib], check=True, capture_output=True, cwd=tmp_path)
+    out = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name:
+                continue
+            g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, blk).group(1))
+            out[name.group(1)] = dict(agpr=int(blk.split()[0]), vgpr=g("vgpr_count"), lds=g("group_segment_fixed_size"),
+                                      scratch=g("private_segment_fixed_size"), spill=g("vgpr_spill_count"))
+    assert out, "no gfx950 code object found in the library"
+    return out
+
+
+def _find(ks, *parts):
+    hit = [v for k, v in ks.items() if all(p in k for p in parts)]
+    assert len(hit) == 1, (parts, [k for k in ks if parts[0] in k])
+    return hit[0]
+
+
+def test_co_residency_budgets(tmp_path):
+    ks = _kernels(tmp_path)
+    gran = lambda v: (v + 7) // 8 * 8                    # VGPR allocation granule (unified file: VGPRs + AGPRs)
+    fused = {(64, 10): _find(ks, "resblock_fused_kernelILi64ELi10E"), (32, 20): _find(ks, "resblock_fused_kernelILi32ELi20E"),
+             (128, 5): _find(ks, "resblock_fused_kernelILi128ELi5E")}
+    row = [_find(ks, "rowconv_kernelILi1ELi1ELi1E"), _find(ks, "rowconv_kernelILi1ELi1ELi4E")]
+    for r in row:
+        assert r["spill"] == 0 and r["scratch"] == 0
+        assert gran(r["vgpr"] + r["agpr"]) <= 80
+    for key, f in fused.items():
+        assert f["spill"] == 0 and f["scratch"] == 0, key
+        # two waves of the fused pass per SIMD + one rowconv wave within the 512 registers of a SIMD lane
+        assert 2 * gran(f["vgpr"] + f["agpr"]) + 80 <= 512, (key, f)
+        # its block + a rowconv block (16 + 4*4 window rows x (256 + 8) floats, 32 ints of row table, 240 B static) within 160 KB
+        assert f["lds"] + (32 + 32 * 264) * 4 + 240 <= 160 * 1024, (key, f)
+
+
+def test_hot_kernels_do_not_spill(tmp_path):
+    ks = _kernels(tmp_path)
+    hot = [k for k in ks if any(s in k for s in ("conv_mfma_kernel", "resblock_fused_kernel", "rowconv_kernel", "emformer_fused_kernel"))]
+    assert len(hot) >= 15
+    for k in hot:
+        assert ks[k]["spill"] == 0 and ks[k]["scratch"] == 0, (k, ks[k])
