@@ -36,7 +36,11 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
       best = c;
       // too few 64x64 tiles for two blocks per CU (stage-1 resblocks at 64 streams: 384 tiles): the K-step-64 build runs
       // one persistent block per CU over a balanced tile list instead of leaving a third of the CUs half empty
-      if (c == cnk::CFG_64x64 && blocks < 2 * need) best = cnk::CFG_64x64_KS64;
+      // - for the grouped launches, whose tiles of three costs the list balances.  A single problem with 1.25 equal tiles
+      // per CU (ups.1: 320) needs two rounds either way; there the K-step-32 build with its 320 independently dispatched
+      // blocks is faster alone (94 against 109 us) and, above all, in the pipelined step, where a CU that another
+      // stream's block holds for a while delays a whole static list (step 1.856 -> 1.805 ms)
+      if (c == cnk::CFG_64x64 && blocks < 2 * need && nprob > 1) best = cnk::CFG_64x64_KS64;
       break;
     }
   }
