@@ -124,6 +124,7 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       s->sk_slab_floats = 8ll << 20; s->sk_max_tiles = 4096;
       for (int w = 0; w < 3; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); }
       for (int w = 0; w < 2; ++w) s->rb_sched[w] = (int*)s->alloc(4);
+      for (int w = 0; w < 3; ++w) s->cp_ticket[w] = (int*)s->alloc(4);
       { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0);

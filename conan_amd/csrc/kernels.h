@@ -271,8 +271,13 @@ void launch_pitch_head(const PitchHeadArgs& a, hipStream_t st);
 struct MeanActArgs { TRef x[3]; TRef y; const int* slots; const int* pos; int nsrc, T, n, C; float slope; };
 void launch_mean_act(const MeanActArgs& a, hipStream_t st);
 // conv_post (CausalConv1d(C -> 1, k) + tanh, hifigan_causal.py:331-333) as a VALU dot-product kernel: N = 1 would
-// waste 31/32 of an MFMA tile.  x is the already activated input ring; w is [k][C]; optional pre-tanh tap.
-struct ConvPostArgs { TRef x; const float* w; float bias; float* wav; float* pre; const int* slots; const int* pos; int T, n, C, k; };
+// waste 31/32 of an MFMA tile.  x[0] is the already activated input ring (nsrc = 1); w is [k][C]; optional pre-tanh tap.
+// nsrc > 1: x[] are the RAW outputs of the last stage's branches and the kernel forms leaky_relu(mean) itself (the same
+// operations in the same order as mean_act_kernel), so the stage's own mean_act launch and its tensor disappear.
+// adv_pos != nullptr: the last workgroup to finish advances the per-slot frame counters by adv_delta (the step's
+// launch_advance folded in; adv_ticket is a zeroed int the kernel leaves zeroed).
+struct ConvPostArgs { TRef x[3]; int nsrc; float slope; const float* w; float bias; float* wav; float* pre; const int* slots; const int* pos; int T, n, C, k;
+                      int* adv_pos; int adv_delta; int* adv_ticket; };
 void launch_conv_post(const ConvPostArgs& a, hipStream_t st);
 
 struct ArgmaxArgs { const float* x; int* idx; int rows, C; };

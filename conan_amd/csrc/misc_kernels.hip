@@ -458,23 +458,52 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
     const int r = e / c4n, c4 = e - r * c4n;
     const int t = t0 + r - (a.k - 1);            // may be negative: ring history (zeros before stream start)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < a.T) v = *reinterpret_cast<const float4*>(trowptr(a.x, i, slot, a.pos, t) + c4 * 4);
+    if (t < a.T) {
+      v = *reinterpret_cast<const float4*>(trowptr(a.x[0], i, slot, a.pos, t) + c4 * 4);
+      if (a.nsrc > 1) {        // leaky_relu(mean of the branches): mean_act_kernel's arithmetic, operation for operation
+        const float4 v1 = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
+        v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+        if (a.nsrc > 2) {
+          const float4 v2 = *reinterpret_cast<const float4*>(trowptr(a.x[2], i, slot, a.pos, t) + c4 * 4);
+          v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+        }
+        const float dn = (float)a.nsrc;
+        v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
+        v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
+        v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+      }
+    }
     float* d = cps + r * ld + c4 * 4;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   }
   __syncthreads();
   const int t = t0 + threadIdx.x;
-  if (t >= a.T) return;
-  float acc = 0.f;
-  for (int j = 0; j < a.k; ++j) {
-    const float* xr = cps + (threadIdx.x + j) * ld;
-    const float* wr = sw + j * a.C;
-    for (int c = 0; c < a.C; ++c) acc += xr[c] * wr[c];
+  if (t < a.T) {
+    float acc = 0.f;
+    for (int j = 0; j < a.k; ++j) {
+      const float* xr = cps + (threadIdx.x + j) * ld;
+      const float* wr = sw + j * a.C;
+      for (int c = 0; c < a.C; ++c) acc += xr[c] * wr[c];
+    }
+    acc += a.bias;
+    const long long o = (long long)i * a.T + t;
+    if (a.pre) a.pre[o] = acc;
+    a.wav[o] = tanhf(acc);
   }
-  acc += a.bias;
-  const long long o = (long long)i * a.T + t;
-  if (a.pre) a.pre[o] = acc;
-  a.wav[o] = tanhf(acc);
+  if (a.adv_pos) {
+    // every workgroup read its slot's counter before this point; the one that takes the last ticket advances them all
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      const int ticket = __hip_atomic_fetch_add(a.adv_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = ticket == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+      for (int q = threadIdx.x; q < a.n; q += blockDim.x) a.adv_pos[a.slots ? a.slots[q] : q] += a.adv_delta;
+      if (threadIdx.x == 0) __hip_atomic_store(a.adv_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 void launch_conv_post(const ConvPostArgs& a, hipStream_t st) {
   if (a.n * a.T <= 0) return;

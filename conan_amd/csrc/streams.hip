@@ -224,7 +224,7 @@ void conan_streams::build_vocoder() {
     if (s.fused) for (int b = 0; b < c.voc_num_resblocks; ++b) up_hist = std::max(up_hist, (c.voc_rb_kernels[b] - 1) * (c.voc_rb_dilations[b][0] + 1));
     s.up = mk_ring(ch_, rate, up_hist, &voc_state);
     const int next_pad = (i + 1 < c.voc_num_ups) ? c.voc_up_kernels[i + 1] - 1 : 6;
-    s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
+    if (i + 1 < c.voc_num_ups) s.xs = mk_ring(ch_, rate, next_pad, &voc_state);   // (the last stage's branch mean is formed inside conv_post)
     // LeakyReLU'd twins of `up` and of the resblock outputs that feed another c1: the producer's epilogue writes both
     // (ConvArgs::y2_base), c1 reads the activated copy, the residual add reads the raw one
     if (!s.fused) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
@@ -322,7 +322,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       launch_group(g1, NB, cfg, st);
       launch_group(g2, NB, cfg, st);
     }
-    {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1] / conv_post
+    if (i + 1 < c.voc_num_ups) {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1]; the last stage's by conv_post, which forms it itself
       cnk::MeanActArgs ma; memset(&ma, 0, sizeof(ma));
       for (int b = 0; b < NB; ++b) ma.x[b] = s.xo[b][ND - 1].ref();
       ma.y = s.xs.ref(); ma.slots = d_slots; ma.pos = pos; ma.nsrc = NB; ma.T = T; ma.n = n; ma.C = s.C; ma.slope = LR;
@@ -334,11 +334,14 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     VocStage& s = v_st.back();
     const int T = frames * s.rate;
     cnk::ConvPostArgs a; memset(&a, 0, sizeof(a));
-    a.x = s.xs.ref(); a.w = ctx->vec("voc.conv_post.w"); a.bias = ctx->scalars.at("voc.conv_post.b");
+    for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref();      // raw branch outputs: leaky_relu(mean) is formed in the kernel
+    a.nsrc = NB; a.slope = LR;
+    a.w = ctx->vec("voc.conv_post.w"); a.bias = ctx->scalars.at("voc.conv_post.b");
     a.wav = wav_out; a.pre = pre_tanh; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.C = s.C; a.k = (int)ctx->scalars.at("voc.conv_post.k");
+    // the step's last kernel also advances the per-slot frame counters (one launch less)
+    a.adv_pos = pos_voc; a.adv_delta = frames; a.adv_ticket = cp_ticket[ws_index(st)];
     cnk::launch_conv_post(a, st);
   }
-  cnk::launch_advance(pos_voc, d_slots, n, frames, st);
 }
 
 // ------------------------------------------------------------------------------------------------ emformer
