@@ -98,18 +98,26 @@ struct RBArgs {
   RBProb p[3];                        // the branches of a stage at one dilation index (inputs / outputs share their ring geometry's mode and rate)
   const int* slots; const int* pos;
   const int* tiles;                   // filled by launch_resblock_fused: [ntiles] {branch, slot index, first row, 0}, most expensive first
+                                      // (merge: (slot, row tile)-major, branches 0 .. nprob-1 adjacent)
   int ntiles;
   int* sched;                         // work-queue state owned by the caller: 2 ints, zero before the first launch (re-armed by the kernel);
                                       // one per stream that may have a fused launch in flight
   int nprob, n, T;                    // branches, slots in this batch, output rows per slot
   int tiles_per_slot;
   float slope;
+  // merge = 1 (last dilation of a stage, enough row tiles to fill the chip): a workgroup runs the nprob branches of one
+  // (slot, row tile) one after the other and stores only leaky_relu(mean of the branch outputs) to `ymean` - the sum
+  // (v0 + v1) + v2, the division and the activation are mean_act_kernel's, operation for operation, so the result does
+  // not depend on whether a launch was merged; the branches' own outputs (p[].y) are not written.
+  int merge;
+  TRef ymean;
   unsigned long long* dbg;            // developer builds only (tools/rb_bench -DRB_ABLATE=4): cycle stamps per block
 };
 bool resblock_fused_supported(int C, int kmax, int span_max);
 int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu);   // output rows per tile to launch with
 bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
-const char* resblock_fused_name(int C, int rows);
+bool resblock_fused_can_merge(int C, int rows);   // a merged-branch build exists for this geometry
+const char* resblock_fused_name(int C, int rows, bool merge = false);
 
 
 // Frame-rate conv / linear of the decoder step with an optional LayerNorm in front (rowconv.hip).
@@ -273,10 +281,12 @@ void launch_mean_act(const MeanActArgs& a, hipStream_t st);
 // conv_post (CausalConv1d(C -> 1, k) + tanh, hifigan_causal.py:331-333) as a VALU dot-product kernel: N = 1 would
 // waste 31/32 of an MFMA tile.  x[0] is the already activated input ring (nsrc = 1); w is [k][C]; optional pre-tanh tap.
 // nsrc > 1: x[] are the RAW outputs of the last stage's branches and the kernel forms leaky_relu(mean) itself (the same
-// operations in the same order as mean_act_kernel), so the stage's own mean_act launch and its tensor disappear.
+// operations in the same order as mean_act_kernel), so the stage's own mean_act launch disappears; rows of earlier steps
+// (the k - 1 rows of left context) come from `xmean`, the activated-mean ring, to which the kernel also appends the rows
+// it formed - the ring stays valid whichever way a step produced it (merged fused launch, or here).
 // adv_pos != nullptr: the last workgroup to finish advances the per-slot frame counters by adv_delta (the step's
 // launch_advance folded in; adv_ticket is a zeroed int the kernel leaves zeroed).
-struct ConvPostArgs { TRef x[3]; int nsrc; float slope; const float* w; float bias; float* wav; float* pre; const int* slots; const int* pos; int T, n, C, k;
+struct ConvPostArgs { TRef x[3]; TRef xmean; int nsrc; float slope; const float* w; float bias; float* wav; float* pre; const int* slots; const int* pos; int T, n, C, k;
                       int* adv_pos; int adv_delta; int* adv_ticket; };
 void launch_conv_post(const ConvPostArgs& a, hipStream_t st);
 

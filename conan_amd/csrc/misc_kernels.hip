@@ -458,7 +458,9 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
     const int r = e / c4n, c4 = e - r * c4n;
     const int t = t0 + r - (a.k - 1);            // may be negative: ring history (zeros before stream start)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < a.T) {
+    if (t < a.T && a.nsrc > 1 && t < 0) {
+      v = *reinterpret_cast<const float4*>(trowptr(a.xmean, i, slot, a.pos, t) + c4 * 4);       // earlier steps: the activated mean as stored
+    } else if (t < a.T) {
       v = *reinterpret_cast<const float4*>(trowptr(a.x[0], i, slot, a.pos, t) + c4 * 4);
       if (a.nsrc > 1) {        // leaky_relu(mean of the branches): mean_act_kernel's arithmetic, operation for operation
         const float4 v1 = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
         v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
         v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
         v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
+        if (r >= a.k - 1) *reinterpret_cast<float4*>(trowptr(a.xmean, i, slot, a.pos, t) + c4 * 4) = v;   // this tile's own rows -> the mean ring
       }
     }
     float* d = cps + r * ld + c4 * 4;

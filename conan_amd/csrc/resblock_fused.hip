@@ -151,7 +151,7 @@ __device__ __forceinline__ void rb_gemm(const float* __restrict__ src, const int
 // to scratch memory)
 #define RB_SEL(br_, f) ((br_) == 0 ? a.p[0].f : ((br_) == 1 ? a.p[1].f : a.p[2].f))
 
-template <int C, int NR2>
+template <int C, int NR2, bool MERGE>
 __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) {
   using G = RBGeom<C, NR2>;
   constexpr int LDX = G::LDX;
@@ -171,6 +171,9 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
   const int ntiles = a.ntiles;
   const float slope = a.slope;
   const int T = a.T;
+  constexpr bool merge = MERGE;          // a template parameter: the separate-branch build carries none of the merge state
+  const int np = a.nprob;
+  const int first_tile = merge ? (int)blockIdx.x * np : (int)blockIdx.x;     // merge: a block owns whole (slot, row tile) groups
 
   if (wave >= 4) {
     // ============================================================ helper waves: window loader + output writer
@@ -223,20 +226,30 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
     static_assert((G::RO * G::C4) % 256 == 0 && 256 % G::C4 == 0, "output tile / helper threads");
     constexpr int NOB = (NOUT + 1) / 2;                            // residual rows per batch
     const int oc4 = ht % G::C4;                                    // a thread keeps its channel quad
-    float4 oacc[NOUT];
+    float4 oacc[NOUT], osum[MERGE ? NOUT : 1];                    // osum: running sum of the branch outputs (merge)
     const float* oxb = nullptr; const float* ob2p = nullptr;
     float* oyb = nullptr;
     unsigned oyr0 = 0, oym = 0, oxr0 = 0, oxm = 0;
-    int ot0 = 0;
+    int ot0 = 0, op = 0, oyC = C;
+#pragma unroll
+    for (int u = 0; u < (MERGE ? NOUT : 1); ++u) osum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto out_fetch = [&](const int p, const int i, const int t0, const int slot, const int pos) __attribute__((always_inline)) {
       const int xmode = a.p[0].x.mode, xrate = a.p[0].x.rate, ymode = a.p[0].y.mode, yrate = a.p[0].y.rate;
       oxb = RB_SEL(p, x.base) + (long long)(xmode == 0 ? slot : i) * RB_SEL(p, x.slot_stride);
-      oyb = RB_SEL(p, y.base) + (long long)(ymode == 0 ? slot : i) * RB_SEL(p, y.slot_stride);
       oxr0 = (xmode == 0 ? (unsigned)pos * (unsigned)xrate : 0u) + (unsigned)(RB_SEL(p, x.off) + t0);
-      oyr0 = (ymode == 0 ? (unsigned)pos * (unsigned)yrate : 0u) + (unsigned)(RB_SEL(p, y.off) + t0);
       oxm = xmode == 0 ? (unsigned)RB_SEL(p, x.lmask) : 0xffffffffu;
-      oym = ymode == 0 ? (unsigned)RB_SEL(p, y.lmask) : 0xffffffffu;
-      ot0 = t0;
+      if (!merge) {
+        oyb = RB_SEL(p, y.base) + (long long)(ymode == 0 ? slot : i) * RB_SEL(p, y.slot_stride);
+        oyr0 = (ymode == 0 ? (unsigned)pos * (unsigned)yrate : 0u) + (unsigned)(RB_SEL(p, y.off) + t0);
+        oym = ymode == 0 ? (unsigned)RB_SEL(p, y.lmask) : 0xffffffffu;
+      } else {      // the group's one output: the branch mean
+        const int mmode = a.ymean.mode;
+        oyb = a.ymean.base + (long long)(mmode == 0 ? slot : i) * a.ymean.slot_stride;
+        oyr0 = (mmode == 0 ? (unsigned)pos * (unsigned)a.ymean.rate : 0u) + (unsigned)(a.ymean.off + t0);
+        oym = mmode == 0 ? (unsigned)a.ymean.lmask : 0xffffffffu;
+        oyC = a.ymean.C;
+      }
+      ot0 = t0; op = p;
       ob2p = RB_SEL(p, b2) + oc4 * 4;
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) oacc[u] = *reinterpret_cast<const float4*>(xt + ((ht + 256 * u) / G::C4) * LDX + oc4 * 4);
@@ -254,15 +267,30 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #pragma unroll
         for (int q = 0; q < NOB; ++q) {
           const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
-          if (u < NOUT && ot0 + r < T)
-            gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4,
-                    make_float4((oacc[u].x + ob2.x) + ores[q].x, (oacc[u].y + ob2.y) + ores[q].y, (oacc[u].z + ob2.z) + ores[q].z, (oacc[u].w + ob2.w) + ores[q].w));
+          if (u < NOUT && ot0 + r < T) {
+            const float4 v = make_float4((oacc[u].x + ob2.x) + ores[q].x, (oacc[u].y + ob2.y) + ores[q].y, (oacc[u].z + ob2.z) + ores[q].z, (oacc[u].w + ob2.w) + ores[q].w);
+            if constexpr (!MERGE) gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4, v);
+            else {
+              // mean_act_kernel's arithmetic on the values the branch launches would have stored: (v0 + v1) + v2, / n, LeakyReLU
+              float4 sm = osum[MERGE ? u : 0];
+              if (op == 0) sm = v; else { sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w; }
+              osum[MERGE ? u : 0] = sm;
+              if (op == np - 1) {
+                const float dn = (float)np;
+                if (np > 1) { sm.x /= dn; sm.y /= dn; sm.z /= dn; sm.w /= dn; }
+                sm.x = sm.x > 0.f ? sm.x : sm.x * slope; sm.y = sm.y > 0.f ? sm.y : sm.y * slope;
+                sm.z = sm.z > 0.f ? sm.z : sm.z * slope; sm.w = sm.w > 0.f ? sm.w : sm.w * slope;
+                gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * oyC + oc4 * 4, sm);
+              }
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    int p = tile_word(blockIdx.x, 0), i = tile_word(blockIdx.x, 1), t0 = tile_word(blockIdx.x, 2);
+    int p = tile_word(first_tile, 0), i = tile_word(first_tile, 1), t0 = tile_word(first_tile, 2);
     int slot = slot_of(i), pos = pos_of(slot);
+    int cur = first_tile;                                // index of the tile in flight (merge: its successor is cur + 1 inside a group)
     if (ht == 0) meta[3] = 0;
 #if !(RB_ABLATE & 1)
     load_window(p, i, t0, slot, pos);
@@ -280,7 +308,13 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
       // helper waves poll the generation word (s_barrier is block wide, there is no helper-only rendezvous); the
       // matrix waves read it after B4.
       int nv = 0;
-      if (wave == 4 && lane == 0) nv = (int)gridDim.x + __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wave == 4 && lane == 0) {
+        if (merge && p != np - 1) nv = cur + 1;          // next branch of this group: no draw
+        else {
+          nv = (int)gridDim.x + __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (merge) nv *= np;                           // a drawn group's first tile
+        }
+      }
 #if RB_ABLATE & 4
       const unsigned long long h0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -321,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
       pending = true;
 #endif
       if (pn < 0) break;
-      p = pn; i = in; t0 = t0n; slot = slotn; pos = posn;
+      p = pn; i = in; t0 = t0n; slot = slotn; pos = posn; cur = nidx;
     }
 #if !(RB_ABLATE & 2)
     if (pending) out_store();
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #define RB_T() __builtin_amdgcn_s_memtime()
 #endif
   float4 bw[G::RING][G::NCW];
-  int p = tile_word(blockIdx.x, 0);
+  int p = tile_word(first_tile, 0);
   {
     const long long cs = (long long)(RB_SEL(p, k) + 1) * G::KQ * 256;
     rb_prefetch_w<G::NCW, G::RING>(bw, RB_SEL(p, w1) + (long long)ct0 * cs + lane * 4, cs);
@@ -503,13 +537,14 @@ static const int* rb_tiles(const RBArgs& a, int ro, int* total_out) {
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   (void)hipGetDevice(&dev);
-  Key key = {{a.nprob, a.n, a.tiles_per_slot, a.p[0].k, a.nprob > 1 ? a.p[1].k : 0, a.nprob > 2 ? a.p[2].k : 0, dev, ro, 0, 0}};
+  Key key = {{a.nprob, a.n, a.tiles_per_slot, a.p[0].k, a.nprob > 1 ? a.p[1].k : 0, a.nprob > 2 ? a.p[2].k : 0, dev, ro, a.merge, 0}};
   auto it = cache.find(key);
   if (it != cache.end()) { *total_out = it->second.second; return it->second.first; }
   const int per_prob = a.n * a.tiles_per_slot, total = a.nprob * per_prob;
   std::vector<int> order(total);
   for (int i = 0; i < total; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a.p[x / per_prob].k > a.p[y / per_prob].k; });
+  if (!a.merge) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a.p[x / per_prob].k > a.p[y / per_prob].k; });
+  else for (int e = 0; e < total; ++e) order[e] = (e % a.nprob) * per_prob + e / a.nprob;      // (slot, row tile)-major, branches adjacent
   std::vector<int> flat((size_t)(total + 1) * 4, -1);
   for (int e = 0; e < total; ++e) {
     const int id = order[e], p = id / per_prob, rem = id - p * per_prob, i = rem / a.tiles_per_slot;
@@ -524,7 +559,7 @@ static const int* rb_tiles(const RBArgs& a, int ro, int* total_out) {
   return d;
 }
 
-template <int C, int NR2>
+template <int C, int NR2, bool MERGE = false>
 static bool launch_rb(const RBArgs& ain, int num_cu, hipStream_t st) {
   RBArgs a = ain;
   const int ro = RBGeom<C, NR2>::RO;
@@ -532,15 +567,20 @@ static bool launch_rb(const RBArgs& ain, int num_cu, hipStream_t st) {
   const int total = a.nprob * a.n * a.tiles_per_slot;
   if (total <= 0) return true;
   if (!a.sched) return false;
-  const int grid = std::min(total, num_cu);
+  const int grid = std::min(a.merge ? total / a.nprob : total, num_cu);
   a.tiles = rb_tiles(a, ro, &a.ntiles);
   if (!a.tiles) return false;
-  hipLaunchKernelGGL((resblock_fused_kernel<C, NR2>), dim3(grid), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((resblock_fused_kernel<C, NR2, MERGE>), dim3(grid), dim3(512), 0, st, a);
   return true;
 }
 
 bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st) {
   const int nr2 = rows / 16;
+  if (a.merge) {     // instantiated where a stage can have a group per CU
+    if (C == 32 && nr2 == 20) return launch_rb<32, 20, true>(a, num_cu, st);
+    if (C == 64 && nr2 == 10) return launch_rb<64, 10, true>(a, num_cu, st);
+    return false;
+  }
   if (C == 32 && nr2 == 20) return launch_rb<32, 20>(a, num_cu, st);
   if (C == 32 && nr2 == 4) return launch_rb<32, 4>(a, num_cu, st);
   if (C == 64 && nr2 == 10) return launch_rb<64, 10>(a, num_cu, st);
@@ -551,9 +591,11 @@ bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStre
   return false;
 }
 
-const char* resblock_fused_name(int C, int rows) {
-  static thread_local char buf[64];
-  snprintf(buf, sizeof(buf), "cnk::resblock_fused_kernel<%d, %d>", C, rows / 16);
+bool resblock_fused_can_merge(int C, int rows) { return (C == 32 && rows == 320) || (C == 64 && rows == 160); }
+
+const char* resblock_fused_name(int C, int rows, bool merge) {
+  static thread_local char buf[72];
+  snprintf(buf, sizeof(buf), "cnk::resblock_fused_kernel<%d, %d, %s>", C, rows / 16, merge ? "true" : "false");
   return buf;
 }
 

@@ -169,7 +169,7 @@ struct conan_streams {
   struct ProfKernel { std::string name; double ms, flops; long long n; };
   std::vector<ProfKernel> prof_kernels;          // filled by conan_profile_end: per template instantiation
   void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
-  void launch_rb(const cnk::RBArgs& a, int C, hipStream_t st);
+  bool launch_rb(const cnk::RBArgs& a, int C, hipStream_t st, const TRef* ymean = nullptr);   // true: the launch stored the branch mean (merged)
   bool use_rowconv = true;                  // frame-rate decoder layers through rowconv.hip (CONAN_ROWCONV=0: conv_mfma + LayerNorm launches)
   bool rowconv_ok(const PackedConv& pc, int dil, int T) const { return use_rowconv && pc.wf && cnk::rowconv_supported(pc.Cin, pc.k, dil, T); }
   cnk::RowConvArgs mk_rc(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, int dil = 1) const;

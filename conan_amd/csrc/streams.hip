@@ -126,7 +126,7 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
 }
 
 // one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
-void conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st) {
+bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, const TRef* ymean) {
   cnk::RBArgs a = ain;
   a.sched = rb_sched[ws_index(st) == 1 ? 1 : 0];
   int ksum = 0, kmax = 0;
@@ -137,9 +137,17 @@ void conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st) {
   // dependent front-end launches of the next chunk waits for a vocoder kernel boundary
   const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
   const int rows = cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
-  profiled(cnk::resblock_fused_name(C, rows), fl, st, [&] {
+  // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
+  // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.
+  // With fewer groups than CUs (C = 128 at 64 streams: 128) the branches stay separate tiles.
+  static const bool no_merge = getenv("CONAN_RB_NOMERGE") != nullptr;
+  const long long groups = (long long)a.n * ((a.T + rows - 1) / rows);
+  a.merge = (ymean && !no_merge && a.nprob > 1 && groups >= cus && cnk::resblock_fused_can_merge(C, rows)) ? 1 : 0;
+  if (a.merge) a.ymean = *ymean;
+  profiled(cnk::resblock_fused_name(C, rows, a.merge != 0), fl, st, [&] {
     if (!cnk::launch_resblock_fused(a, C, rows, cus, st)) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
   });
+  return a.merge != 0;
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
@@ -224,7 +232,7 @@ void conan_streams::build_vocoder() {
     if (s.fused) for (int b = 0; b < c.voc_num_resblocks; ++b) up_hist = std::max(up_hist, (c.voc_rb_kernels[b] - 1) * (c.voc_rb_dilations[b][0] + 1));
     s.up = mk_ring(ch_, rate, up_hist, &voc_state);
     const int next_pad = (i + 1 < c.voc_num_ups) ? c.voc_up_kernels[i + 1] - 1 : 6;
-    if (i + 1 < c.voc_num_ups) s.xs = mk_ring(ch_, rate, next_pad, &voc_state);   // (the last stage's branch mean is formed inside conv_post)
+    s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
     // LeakyReLU'd twins of `up` and of the resblock outputs that feed another c1: the producer's epilogue writes both
     // (ConvArgs::y2_base), c1 reads the activated copy, the residual add reads the raw one
     if (!s.fused) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
@@ -265,8 +273,10 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
   const int NB = c.voc_num_resblocks, ND = c.voc_rb_num_dil;
   if (NB > kMaxBranches) throw Error(CONAN_ERR_UNSUPPORTED, "more than 3 resblock branches");
   int ridx = 0;
+  bool last_merged = false;
   for (int i = 0; i < c.voc_num_ups; ++i) {
     VocStage& s = v_st[i];
+    bool merged = false;                    // the stage's branch mean was formed by its last fused launch
     const int Tin = frames * (s.rate / c.voc_up_rates[i]);
     const int T = frames * s.rate;
     {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322): the input (v_pre / branch mean xs) is stored
@@ -288,7 +298,8 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         pr.k = c.voc_rb_kernels[b]; pr.dil = c.voc_rb_dilations[b][d];
       }
       ra.slots = d_slots; ra.pos = pos; ra.nprob = NB; ra.n = n; ra.T = T; ra.slope = LR;
-      launch_rb(ra, s.C, st);
+      if (d + 1 < ND) launch_rb(ra, s.C, st);
+      else { const TRef ym = s.xs.ref(); merged = launch_rb(ra, s.C, st, &ym); }
     }
     for (int d = 0; d < ND && c.voc_resblock == 2; ++d) {  // ResBlock2 (hifigan_causal.py:255-261): x = conv_d(lrelu(x)) + x
       ConvGroup g1;
@@ -322,7 +333,8 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       launch_group(g1, NB, cfg, st);
       launch_group(g2, NB, cfg, st);
     }
-    if (i + 1 < c.voc_num_ups) {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1]; the last stage's by conv_post, which forms it itself
+    last_merged = merged;
+    if (i + 1 < c.voc_num_ups && !merged) {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1]; the last stage's by conv_post, which forms it itself
       cnk::MeanActArgs ma; memset(&ma, 0, sizeof(ma));
       for (int b = 0; b < NB; ++b) ma.x[b] = s.xo[b][ND - 1].ref();
       ma.y = s.xs.ref(); ma.slots = d_slots; ma.pos = pos; ma.nsrc = NB; ma.T = T; ma.n = n; ma.C = s.C; ma.slope = LR;
@@ -334,8 +346,9 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     VocStage& s = v_st.back();
     const int T = frames * s.rate;
     cnk::ConvPostArgs a; memset(&a, 0, sizeof(a));
-    for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref();      // raw branch outputs: leaky_relu(mean) is formed in the kernel
-    a.nsrc = NB; a.slope = LR;
+    if (last_merged) { a.x[0] = s.xs.ref(); a.nsrc = 1; }             // the last fused launch already stored leaky_relu(mean)
+    else { for (int b = 0; b < NB; ++b) a.x[b] = s.xo[b][ND - 1].ref(); a.nsrc = NB; a.xmean = s.xs.ref(); }   // raw branch outputs: the mean is formed (and appended to xs) in the kernel
+    a.slope = LR;
     a.w = ctx->vec("voc.conv_post.w"); a.bias = ctx->scalars.at("voc.conv_post.b");
     a.wav = wav_out; a.pre = pre_tanh; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.C = s.C; a.k = (int)ctx->scalars.at("voc.conv_post.k");
     // the step's last kernel also advances the per-slot frame counters (one launch less)

@@ -47,8 +47,9 @@ def _find(ks, *parts):
 def test_co_residency_budgets(tmp_path):
     ks = _kernels(tmp_path)
     gran = lambda v: (v + 7) // 8 * 8                    # VGPR allocation granule (unified file: VGPRs + AGPRs)
-    fused = {(64, 10): _find(ks, "resblock_fused_kernelILi64ELi10E"), (32, 20): _find(ks, "resblock_fused_kernelILi32ELi20E"),
-             (128, 5): _find(ks, "resblock_fused_kernelILi128ELi5E")}
+    fused = {(64, 10): _find(ks, "resblock_fused_kernelILi64ELi10ELb0E"), (32, 20): _find(ks, "resblock_fused_kernelILi32ELi20ELb0E"),
+             (128, 5): _find(ks, "resblock_fused_kernelILi128ELi5ELb0E"),
+             (64, 10, "merged"): _find(ks, "resblock_fused_kernelILi64ELi10ELb1E"), (32, 20, "merged"): _find(ks, "resblock_fused_kernelILi32ELi20ELb1E")}
     row = [_find(ks, "rowconv_kernelILi1ELi1ELi1E"), _find(ks, "rowconv_kernelILi1ELi1ELi4E")]
     for r in row:
         assert r["spill"] == 0 and r["scratch"] == 0

@@ -76,6 +76,10 @@ int main(int argc, char** argv) {
         a.p[b].k = ks[b]; a.p[b].dil = d;
       }
       a.slots = dslots; a.pos = dpos; a.nprob = 3; a.n = B; a.T = T; a.slope = slope;
+      // RB_MERGE=1: merged-branch build (the three branches of a (slot, row tile) in one workgroup, only leaky_relu(mean) stored)
+      const bool merge = getenv("RB_MERGE") != nullptr && cnk::resblock_fused_can_merge(C, cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu));
+      float* dmean = nullptr;
+      if (merge) { CHECK(hipMalloc(&dmean, (size_t)B * ss * 4)); CHECK(hipMemset(dmean, 0, (size_t)B * ss * 4)); a.merge = 1; a.ymean = a.p[0].y; a.ymean.base = dmean; }
       unsigned long long* ddbg = nullptr;
       CHECK(hipMalloc(&ddbg, 260 * 4 * 8)); CHECK(hipMemset(ddbg, 0, 260 * 4 * 8));
       a.dbg = ddbg;
@@ -84,11 +88,16 @@ int main(int argc, char** argv) {
       if (!cnk::launch_resblock_fused(a, C, rows, num_cu, 0)) { printf("launch failed\n"); return 1; }
       CHECK(hipDeviceSynchronize());
       CHECK(hipMemcpy(hy.data(), dy, hy.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<float> hmean;
+      if (merge) { hmean.resize((size_t)B * ss); CHECK(hipMemcpy(hmean.data(), dmean, hmean.size() * 4, hipMemcpyDeviceToHost)); }
       // ---- sampled check against a scalar restatement
       double worst = 0.0, scale = 0.0;
       std::uniform_int_distribution<int> Ui(0, B - 1), Ut(0, T - 1), Uc(0, C - 1);
       for (int smp = 0; smp < 60; ++smp) {
-        const int b = smp % 3, i = (smp < 12) ? (smp / 3) * 5 % B : Ui(rng), t = (smp < 12) ? smp % 7 : (smp < 24 ? T - 1 - smp % 5 : Ut(rng)), co = Uc(rng);
+        double wsum = 0.0;
+        const int i = (smp < 12) ? (smp / 3) * 5 % B : Ui(rng), t = (smp < 12) ? smp % 7 : (smp < 24 ? T - 1 - smp % 5 : Ut(rng)), co = Uc(rng);
+       for (int bb = 0; bb < (merge ? 3 : 1); ++bb) {
+        const int b = merge ? bb : smp % 3;
         const int slot = hslots[i], pos = hpos[slot], k = ks[b];
         const float* xr = hx.data() + (size_t)b * B * ss + (size_t)slot * ss;
         auto xrow = [&](long long tt) { return xr + (size_t)(((long long)pos * sg.rate + tt) & (L - 1)) * C; };
@@ -111,8 +120,18 @@ int main(int argc, char** argv) {
         for (int j = 0; j < k; ++j)
           for (int ci = 0; ci < C; ++ci) s += (double)c2[b].w[((size_t)co * C + ci) * k + j] * xt[(size_t)j * C + ci];
         const double want = s + c2[b].b[co] + xrow(t)[co];
-        const float got = hy[(size_t)b * B * ss + (size_t)slot * ss + (size_t)(((long long)pos * sg.rate + t) & (L - 1)) * C + co];
-        worst = std::max(worst, std::fabs(want - got)); scale = std::max(scale, std::fabs(want));
+        if (!merge) {
+          const float got = hy[(size_t)b * B * ss + (size_t)slot * ss + (size_t)(((long long)pos * sg.rate + t) & (L - 1)) * C + co];
+          worst = std::max(worst, std::fabs(want - got)); scale = std::max(scale, std::fabs(want));
+        } else {
+          wsum += want;
+          if (bb == 2) {
+            const double wm = lrelu((float)(wsum / 3.0), slope);
+            const float got = hmean[(size_t)slot * ss + (size_t)(((long long)pos * sg.rate + t) & (L - 1)) * C + co];
+            worst = std::max(worst, std::fabs(wm - got)); scale = std::max(scale, std::fabs(wm));
+          }
+        }
+       }
       }
       // rows outside [0, T) of the step must be untouched (zeros)
       long long stray = 0;
