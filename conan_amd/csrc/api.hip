@@ -127,6 +127,7 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       for (int w = 0; w < 3; ++w) s->cp_ticket[w] = (int*)s->alloc(4);
       { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
+      s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);

@@ -140,9 +140,8 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
   // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.
   // With fewer groups than CUs (C = 128 at 64 streams: 128) the branches stay separate tiles.
-  static const bool no_merge = getenv("CONAN_RB_NOMERGE") != nullptr;
   const long long groups = (long long)a.n * ((a.T + rows - 1) / rows);
-  a.merge = (ymean && !no_merge && a.nprob > 1 && groups >= cus && cnk::resblock_fused_can_merge(C, rows)) ? 1 : 0;
+  a.merge = (ymean && rb_merge && a.nprob > 1 && groups >= cus && cnk::resblock_fused_can_merge(C, rows)) ? 1 : 0;
   if (a.merge) a.ymean = *ymean;
   profiled(cnk::resblock_fused_name(C, rows, a.merge != 0), fl, st, [&] {
     if (!cnk::launch_resblock_fused(a, C, rows, cus, st)) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");

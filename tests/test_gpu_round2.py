@@ -154,6 +154,39 @@ def test_emformer_cluster_mode_matches_single_workgroup(monkeypatch):
     ctx.close()
 
 
+def test_merged_branch_launches_equal_separate_branches_bitwise(monkeypatch):
+    """Last dilation of a vocoder stage: the merged-branch build of the fused ResBlock pass (one workgroup runs the three
+    branches of a (slot, row tile) group and stores leaky_relu(mean); 64 streams: stages C = 64 and C = 32) against
+    separate branch tiles + mean_act / conv_post forming the mean - the same 64 streams, the same other kernels, so the
+    audio must be identical bit for bit.  A third stream-set alternates between 64-slot steps (merged) and two 32-slot
+    steps (fewer groups than CUs: not merged; its other kernels differ, so 1e-5): the mean ring stays valid whichever
+    way the previous step produced it."""
+    ctx, _, vhp = _ctx(emformer=False, conan=False)
+    B, steps = 64, 4
+    mel = torch.from_numpy(synth.mel(4 * steps, 77, B)).cuda()                    # [B, 16, 80]
+    merged = ctx.streams(B, max_frames=4, max_ref_frames=16)
+    alt = ctx.streams(B, max_frames=4, max_ref_frames=16)
+    monkeypatch.setenv("CONAN_RB_NOMERGE", "1")
+    separate = ctx.streams(B, max_frames=4, max_ref_frames=16)
+    monkeypatch.delenv("CONAN_RB_NOMERGE")
+    slots = list(range(B))
+    for st in (merged, separate, alt):
+        st.reset(slots)
+    for t in range(steps):
+        chunk = mel[:, 4 * t:4 * t + 4]
+        wa = merged.hifigan_step(slots, chunk)
+        wb = separate.hifigan_step(slots, chunk)
+        assert torch.equal(wa, wb), float((wa - wb).abs().max())
+        if t % 2 == 0:
+            wc = alt.hifigan_step(slots, chunk)
+        else:
+            wc = torch.cat([alt.hifigan_step(slots[:32], chunk[:32]), alt.hifigan_step(slots[32:], chunk[32:])])
+        assert float((wa - wc).abs().max()) < 1e-5
+    for st in (merged, separate, alt):
+        st.close()
+    ctx.close()
+
+
 # ---------------------------------------------------------------------------------------------- loop fixture
 @pytest.mark.parametrize("tag,tiny", [("tiny", True), ("full", False)])
 def test_loop_golden_through_hip_steps(tag, tiny):
