@@ -84,7 +84,7 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
 void conan_ctx::add_rowconv_weights(const std::string& name, const std::vector<float>& W) {
   PackedConv& pc = convs.at(name);
   const int Cin = pc.Cin, Cout = pc.Cout, k = pc.k;
-  if (Cin % 64 || Cin > 512 || pc.shuffle_r != 1) return;
+  if (Cin % 64 || pc.shuffle_r != 1 || (Cin > 512 && !(k == 1 && Cin % 512 == 0 && Cin <= 4096))) return;   // (wide inputs: 1x1 layers only, rowconv.hip chunks their window)
   const int KQ = Cin / 16;
   if (KQ & (KQ - 1)) return;
   const int cpad = ch::round_up(Cout, Cout >= 1024 ? 256 : 64), NCT = cpad / 16;

@@ -62,7 +62,10 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     cnk::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
     if (rowconv_ok(ctx->conv(nm + ".ff1"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T); a.out_act = cnk::ACT_RELU; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st); }
-    { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
+    // ff2 (K = 2048): rowconv with a chunked window - a 31 KB block that shares CUs with the vocoder's, where the split-K conv_mfma
+    // build (126 KB of LDS) needs CUs of its own; a handful of rows (one row tile) keep the split-K build, which spreads K over blocks
+    if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && n * T > 16) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
+    else { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
     cnk::LNArgs ln = mk_ln(c_q.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
     if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
     cnk::launch_layernorm(ln, st);

@@ -135,6 +135,7 @@ struct RowConvArgs {
   int out_act; float out_scale, out_slope;
   int in_lrelu; float in_slope;   // LeakyReLU applied to the input window (HiFi-GAN resblock convs read raw tensors)
   int wr_max;           // filled by launch_rowconv: window rows of a tile
+  int cw;               // filled by launch_rowconv: window channels (0: all of Cin; 1x1 layers wider than 512: chunks of 512)
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);
 void launch_rowconv(const RowConvArgs& a, hipStream_t st);

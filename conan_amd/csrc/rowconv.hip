@@ -289,6 +289,101 @@ __global__ __launch_bounds__(256, NCW == 1 ? 6 : 4) void rowconv_kernel(const Ro
   }
 }
 
+// rowlin: the 1x1 layers whose input is wider than rowconv's window (aligner ff2: 2048 -> 256).  Same tile (16 rows x 64
+// columns per block, one 16-column strip per wave, fragment-major weights through an 8-deep register ring, no barrier in
+// the K loop), but the rows' channels pass through LDS in chunks of 512: gather chunk, barrier, 32 K groups, barrier.  No
+// left context (k = 1), no LayerNorm prologue; the epilogue is rowconv's.  31 KB of LDS: the block shares a CU with a
+// vocoder block, where the split-K conv_mfma build this layer used before (126 KB) needs CUs of its own.
+constexpr int RL_CW = 512, RL_LDX = RL_CW + 8, RL_D = 4;      // (ring of 4: with the gather's registers the kernel stays within 80 VGPRs)
+
+__global__ __launch_bounds__(256, 6) void rowlin_kernel(const RowConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float win[];     // [16][RL_LDX] (dynamic: a static 33 KB would make the compiler give up the 80-VGPR bound)
+  __shared__ int r_i[RC_TM], r_t[RC_TM], r_slot[RC_TM], r_pos[RC_TM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, Mtot = a.n * T, Cin = a.Cin;
+  const int m0 = blockIdx.y * RC_TM, ntile = blockIdx.x;
+  if (tid < RC_TM) {       // one lane per row: stream, time, slot, position (the loads of all rows fly together)
+    const int m = m0 + tid, mm = m < Mtot ? m : Mtot - 1;
+    const int i = mm / T, t = mm - i * T;
+    const int slot = a.slots ? *(rc_gci)(a.slots + i) : i;
+    r_i[tid] = i; r_t[tid] = t; r_slot[tid] = slot; r_pos[tid] = a.pos ? *(rc_gci)(a.pos + slot) : 0;
+  }
+  __syncthreads();
+  const int KQ = Cin >> 4;
+  const int ct0 = ntile * 4 + wave;
+  const int lr = lane & 15, lg = lane >> 4;
+  const float* const abase = win + lr * RL_LDX + 4 * lg;
+  const long long ct_stride = 2ll * KQ * 256;                    // one tap + the zero tap
+  const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+  const bool active = ct0 * 16 < a.Cout_pad;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two interleaved chains (rowconv_kernel)
+  float4 bw[RL_D];
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < RL_D; ++u) { bw[u] = rc_gload4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
+  }
+  // a thread's share of a chunk: 16 rows x 128 float4 = 2048 float4 -> 8 per thread, fetched in two halves; the element's
+  // offset from the tensor base (floats, 32 bits: the activation tensors stay below 4 GiB) is chunk-invariant
+  unsigned soff[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + 256 * u, w = e >> 7, c4 = e & 127;
+    soff[u] = (unsigned)(rc_row(a.x, r_i[w], r_slot[w], r_pos[w], r_t[w]) - a.x.base) + c4 * 4;
+  }
+  const float* const xb = a.x.base;
+  for (int c0 = 0; c0 < Cin; c0 += RL_CW) {
+    if (c0 > 0) __syncthreads();                                  // every wave is done with the previous chunk
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = rc_gload4(xb + soff[4 * h + u] + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int e = tid + 256 * (4 * h + u); *reinterpret_cast<float4*>(win + (e >> 7) * RL_LDX + (e & 127) * 4) = v[u]; }
+    }
+    __syncthreads();
+    if (active) {
+      const int g0 = c0 >> 4;
+      float4 af = *reinterpret_cast<const float4*>(abase);
+      for (int G0 = 0; G0 < RL_CW / 16; G0 += RL_D) {
+#pragma unroll
+        for (int u = 0; u < RL_D; ++u) {
+          const int Gn = G0 + u + 1;
+          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < RL_CW / 16 ? Gn * 16 : 0));
+          f32x4& p = (u & 1) ? acc1 : acc0;
+          f32x4& q = (u & 1) ? acc0 : acc1;
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+          bw[u] = rc_gload4(wl + (long long)(g0 + G0 + u + RL_D) * 256);      // (past the last group: the zero tap, in bounds)
+          af = afn;
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const int col = ct0 * 16 + lr;
+  if (col >= a.Cout) return;
+  const float bias = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = 4 * lg + e, m = m0 + r;
+    if (m >= Mtot) continue;
+    const int i = r_i[r], t = r_t[r], slot = r_slot[r], pos = r_pos[r];
+    float v = ((acc0[e] + acc1[e]) + bias) * a.out_scale;
+    if (a.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (a.out_act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    else if (a.out_act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+    if (a.bvec) v += a.bvec[(long long)slot * a.bvec_stride + col];
+    if (a.has_res) v += rc_row(a.res, i, slot, pos, t)[col];
+    if (a.has_m1) v *= *rc_row(a.m1, i, slot, pos, t);
+    if (a.has_m2) v *= *rc_row(a.m2, i, slot, pos, t);
+    const_cast<float*>(rc_row(a.y, i, slot, pos, t))[col] = v;
+  }
+}
+
 int rowconv_lds_bytes(const RowConvArgs& a, bool ksplit) {
   return (32 + a.wr_max * (a.Cin + 8) + (ksplit ? 3 * 64 * 4 : 0)) * 4;    // window (+ the K-split reduction patch)
 }
@@ -300,7 +395,8 @@ static int rc_window_rows(int tm, int T, int halo) {
 
 bool rowconv_supported(int Cin, int ktaps, int dil, int T) {
   const int KQ = Cin / 16;
-  if (Cin % 64 || Cin > 512 || (KQ & (KQ - 1)) || (ktaps * KQ) % 8) return false;   // K groups: a power of two per tap, a multiple of the ring depth in all
+  if (Cin > 512) return ktaps == 1 && Cin % RL_CW == 0 && T >= 1;    // wide 1x1 layers: rowlin_kernel (no LayerNorm prologue)
+  if (Cin % 64 || (KQ & (KQ - 1)) || (ktaps * KQ) % 8) return false;   // K groups: a power of two per tap, a multiple of the ring depth in all
   if (T < 2) return false;                                              // <= 8 streams per 16-row tile
   const int wr = rc_window_rows(RC_TM, T, (ktaps - 1) * dil);
   return (32 + wr * (Cin + 8)) * 4 <= 60 * 1024;
@@ -321,9 +417,10 @@ static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t
   hipLaunchKernelGGL((rowconv_kernel<NCW, NRW, KW>), dim3(nt, mt), dim3(256), lds, st, a);
 }
 
-// which instantiation a launch uses: 0 <1,1,1>, 1 <4,1,1>, 2 <1,1,4>
+// which kernel a launch uses: 0 <1,1,1>, 1 <4,1,1>, 2 <1,1,4>, 3 rowlin
 static int rc_variant(const RowConvArgs& a) {
   static const bool no_ksplit = getenv("CONAN_RC_NOKSPLIT") != nullptr;   // developer switch
+  if (a.Cin > 512) return 3;
   const int mt = (a.n * a.T + RC_TM - 1) / RC_TM;
   // a single row tile (<= 16 rows in the launch): K split over the waves of a block, one 16-column strip per block
   if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 16) == 0 && !no_ksplit) return 2;
@@ -331,7 +428,7 @@ static int rc_variant(const RowConvArgs& a) {
   return a.Cout_pad >= 1024 ? 1 : 0;
 }
 const char* rowconv_kernel_name(const RowConvArgs& a) {
-  static const char* names[3] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 1, 4>"};
+  static const char* names[4] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 1, 4>", "cnk::rowlin_kernel"};
   return names[rc_variant(a)];
 }
 
@@ -345,6 +442,10 @@ void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
   a.wr_max = rc_window_rows(RC_TM, T, halo);
   const int lds = rowconv_lds_bytes(a, v == 2);
   const int mt = (M + RC_TM - 1) / RC_TM;
+  if (v == 3) {      // (ln / in_lrelu / history are not this kernel's: rowconv_ok() callers pass plain 1x1 layers)
+    hipLaunchKernelGGL(rowlin_kernel, dim3((ncols + 63) / 64, mt), dim3(256), RC_TM * RL_LDX * sizeof(float), st, a);
+    return;
+  }
   switch (v) {
     case 2: rc_launch<1, 1, 4>(a, 1, (ncols + 15) / 16, lds, st); break;
     case 1: rc_launch<4, 1>(a, mt, (ncols + 255) / 256, lds, st); break;

@@ -50,7 +50,7 @@ def test_co_residency_budgets(tmp_path):
     fused = {(64, 10): _find(ks, "resblock_fused_kernelILi64ELi10ELb0E"), (32, 20): _find(ks, "resblock_fused_kernelILi32ELi20ELb0E"),
              (128, 5): _find(ks, "resblock_fused_kernelILi128ELi5ELb0E"),
              (64, 10, "merged"): _find(ks, "resblock_fused_kernelILi64ELi10ELb1E"), (32, 20, "merged"): _find(ks, "resblock_fused_kernelILi32ELi20ELb1E")}
-    row = [_find(ks, "rowconv_kernelILi1ELi1ELi1E"), _find(ks, "rowconv_kernelILi1ELi1ELi4E")]
+    row = [_find(ks, "rowconv_kernelILi1ELi1ELi1E"), _find(ks, "rowconv_kernelILi1ELi1ELi4E"), _find(ks, "rowlin_kernel")]
     for r in row:
         assert r["spill"] == 0 and r["scratch"] == 0
         assert gran(r["vgpr"] + r["agpr"]) <= 80
@@ -64,7 +64,7 @@ def test_co_residency_budgets(tmp_path):
 
 def test_hot_kernels_do_not_spill(tmp_path):
     ks = _kernels(tmp_path)
-    hot = [k for k in ks if any(s in k for s in ("conv_mfma_kernel", "resblock_fused_kernel", "rowconv_kernel", "emformer_fused_kernel"))]
+    hot = [k for k in ks if any(s in k for s in ("conv_mfma_kernel", "resblock_fused_kernel", "rowconv_kernel", "rowlin_kernel", "emformer_fused_kernel"))]
     assert len(hot) >= 15
     for k in hot:
         assert ks[k]["spill"] == 0 and ks[k]["scratch"] == 0, (k, ks[k])
