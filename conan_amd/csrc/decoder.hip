@@ -47,10 +47,17 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   // ProsodyAligner: 2 x CrossAttenLayer, post-LN (prosody_util.py:119-126)
   const int nh = 2, dh = H / nh;
   Lin* src = &c_pin;
+  // Post-LN layers: where the consumer of a LayerNorm is a rowconv launch the norm is that launch's prologue (the
+  // normalised rows also go to `hist`, where the residual adds read them): norm1 -> ff1, and layer 0's norm2 -> layer 1's q.
+  bool n2_pending = false;                       // the previous layer's norm2 is still to be applied (by this layer's q)
   for (int l = 0; l < 2; ++l) {
     const std::string nm = "conan.align." + std::to_string(l);
-    if (rowconv_ok(ctx->conv(nm + ".q"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T); a.out_scale = (float)std::sqrt(1.0 / (double)dh); rowconv(a, st); }
-    else { ConvArgs a = mk(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T, pos); a.out_scale = (float)std::sqrt(1.0 / (double)dh); conv(a, st); }
+    if (rowconv_ok(ctx->conv(nm + ".q"), 1, T)) {
+      cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".q"), n2_pending ? c_a1.ref() : src->ref(), c_q.ref(), n, T);
+      if (n2_pending) { a.ln = 1; a.hist = src->ref(); a.gamma = ctx->vec("conan.align." + std::to_string(l - 1) + ".norm2.g"); a.beta = ctx->vec("conan.align." + std::to_string(l - 1) + ".norm2.b"); }
+      a.out_scale = (float)std::sqrt(1.0 / (double)dh); rowconv(a, st);
+    } else { ConvArgs a = mk(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T, pos); a.out_scale = (float)std::sqrt(1.0 / (double)dh); conv(a, st); }
+    n2_pending = false;
     {
       cnk::XAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = c_q.ref(); a.out = c_att.ref(); a.kv = c_kv + (size_t)l * S_max * 2 * H; a.kv_slot_stride = (long long)2 * S_max * 2 * H;
@@ -59,16 +66,24 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     }
     if (rowconv_ok(ctx->conv(nm + ".out"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T); a.res = src->ref(); a.has_res = 1; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }
-    cnk::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
-    if (rowconv_ok(ctx->conv(nm + ".ff1"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T); a.out_act = cnk::ACT_RELU; rowconv(a, st); }
-    else { ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st); }
-    // ff2 (K = 2048): rowconv with a chunked window - a 31 KB block that shares CUs with the vocoder's, where the split-K conv_mfma
+    if (rowconv_ok(ctx->conv(nm + ".ff1"), 1, T)) {       // norm1 (prologue; normalised rows -> c_a2, ff2's residual) -> ff1 -> ReLU
+      cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff1"), c_a1.ref(), c_ff.ref(), n, T);
+      a.ln = 1; a.hist = c_a2.ref(); a.gamma = ctx->vec(nm + ".norm1.g"); a.beta = ctx->vec(nm + ".norm1.b");
+      a.out_act = cnk::ACT_RELU; rowconv(a, st);
+    } else {
+      cnk::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
+      ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st);
+    }
+    // ff2 (K = 2048) -> c_a1 (free again): rowlin - a 33 KB block that shares CUs with the vocoder's, where the split-K conv_mfma
     // build (126 KB of LDS) needs CUs of its own; a handful of rows (one row tile) keep the split-K build, which spreads K over blocks
-    if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && n * T > 16) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
-    else { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_q.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
-    cnk::LNArgs ln = mk_ln(c_q.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
-    if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
-    cnk::launch_layernorm(ln, st);
+    if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && n * T > 16) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
+    else { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
+    if (l == 0 && rowconv_ok(ctx->conv("conan.align.1.q"), 1, T)) n2_pending = true;      // norm2 -> c_x[0] happens in layer 1's q launch
+    else {
+      cnk::LNArgs ln = mk_ln(c_a1.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
+      if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
+      cnk::launch_layernorm(ln, st);
+    }
     src = &c_x[0];
   }
   // uv_predictor: 5 x [CausalConv k5 + ReLU] (nar_tts_modules.py:113-122)
