@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, NCW == 1 ? 6 : 4) void rowconv_kernel(const Ro
 // the K loop), but the rows' channels pass through LDS in chunks of 512: gather chunk, barrier, 32 K groups, barrier.  No
 // left context (k = 1), no LayerNorm prologue; the epilogue is rowconv's.  31 KB of LDS: the block shares a CU with a
 // vocoder block, where the split-K conv_mfma build this layer used before (126 KB) needs CUs of its own.
-constexpr int RL_CW = 512, RL_LDX = RL_CW + 8, RL_D = 4;      // (ring of 4: with the gather's registers the kernel stays within 80 VGPRs)
+constexpr int RL_CW = 512, RL_LDX = RL_CW + 8, RL_D = 8;
 
 __global__ __launch_bounds__(256, 6) void rowlin_kernel(const RowConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float win[];     // [16][RL_LDX] (dynamic: a static 33 KB would make the compiler give up the 80-VGPR bound)
@@ -323,24 +323,18 @@ __global__ __launch_bounds__(256, 6) void rowlin_kernel(const RowConvArgs a) {
 #pragma unroll
     for (int u = 0; u < RL_D; ++u) { bw[u] = rc_gload4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
   }
-  // a thread's share of a chunk: 16 rows x 128 float4 = 2048 float4 -> 8 per thread, fetched in two halves; the element's
-  // offset from the tensor base (floats, 32 bits: the activation tensors stay below 4 GiB) is chunk-invariant
-  unsigned soff[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int e = tid + 256 * u, w = e >> 7, c4 = e & 127;
-    soff[u] = (unsigned)(rc_row(a.x, r_i[w], r_slot[w], r_pos[w], r_t[w]) - a.x.base) + c4 * 4;
-  }
-  const float* const xb = a.x.base;
+  // a thread's share of a chunk: 16 rows x 128 float4 = 2048 float4 -> 8 per thread, fetched four at a time (the kernel is
+  // bounded to 80 VGPRs and the 8-deep weight ring lives across the chunks); row u of a thread is (tid >> 7) + 2 u
+  const int gw = tid >> 7, gc4 = tid & 127;
   for (int c0 = 0; c0 < Cin; c0 += RL_CW) {
     if (c0 > 0) __syncthreads();                                  // every wave is done with the previous chunk
-#pragma unroll
+#pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = rc_gload4(xb + soff[4 * h + u] + c0);
+      for (int u = 0; u < 4; ++u) { const int w = gw + 2 * (4 * h + u); v[u] = rc_gload4(rc_row(a.x, r_i[w], r_slot[w], r_pos[w], r_t[w]) + gc4 * 4 + c0); }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int e = tid + 256 * (4 * h + u); *reinterpret_cast<float4*>(win + (e >> 7) * RL_LDX + (e & 127) * 4) = v[u]; }
+      for (int u = 0; u < 4; ++u) { const int w = gw + 2 * (4 * h + u); *reinterpret_cast<float4*>(win + w * RL_LDX + gc4 * 4) = v[u]; }
     }
     __syncthreads();
     if (active) {
