@@ -15,11 +15,13 @@
 // Wave roles (512 threads): waves 0-3, one per SIMD, issue nothing but LDS fragment reads, weight-fragment loads and
 // MFMAs; waves 4-7 load the next tile's window while c2 runs (the window is dead then) and write the previous tile's
 // output while c1 runs.  A wave owns whole 16-column strips of the output, so its B operands (weights, fragment-major:
-// 1 KiB per 16x16 operand, streamed from L2 straight into registers, prefetched one tap ahead) are private and the K
+// 1 KiB per 16x16 operand, streamed from L2 straight into registers, prefetched one tap - C = 128: half a tap - ahead) are private and the K
 // loops contain NO barrier: per 16-deep K group one ds_read_b128 per row tile + one 16-byte global load per column
 // tile feed 4 x (row tiles x column tiles) MFMAs.  Four block barriers per tile in all.
 // LDS rows are padded to C + 8 floats: the 16 lanes of every ds_read_b128 lane group hit 16 distinct 16-byte slots.
-// Workgroups are persistent over a host-made longest-first balanced tile list (branch costs are k = 11 : 7 : 3).
+// Workgroups are persistent over a host-made longest-first tile list with an agent-scope draw counter (branch costs are
+// k = 11 : 7 : 3).  MERGE build (last dilation of a stage): a workgroup owns (slot, row tile) groups, runs the branches of a
+// group one after the other and stores only leaky_relu(mean of the three outputs) - see RBArgs::merge.
 #include <algorithm>
 #include <cstring>
 #include <map>
