@@ -68,6 +68,7 @@ _PROTOS = {
     "conan_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_streams_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "conan_streams_output_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_profile_mark": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_profile_begin": (C.c_int, [C.c_void_p]),
     "conan_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -338,8 +338,8 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     // of t+1 beside the vocoder of t): the decoder's ~50 latency-bound launches no longer queue behind the Emformer's
     // one long launch, and their tail no longer leaves the vocoder stream idle.
     // inputs are ready in the caller's stream order
-    HIP_CHECK(hipEventRecord(s->ev_in, (hipStream_t)stream));
-    HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_in, 0));
+    HIP_CHECK(hipEventRecord(s->ev_in[p], (hipStream_t)stream));
+    HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_in[p], 0));
     // a changed slot list rewrites the table the in-flight decoder / vocoder still read: drain them first
     bool same = (int)s->h_slots.size() == n;
     for (int i = 0; same && i < n; ++i) same = s->h_slots[i] == slots[i];
@@ -370,9 +370,21 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     if (mel_out_dev) HIP_CHECK(hipMemcpyAsync(mel_out_dev, mel, (size_t)n * emit * s->ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, s->st_front));
     HIP_CHECK(hipEventRecord(s->ev_front[p], s->st_front));
     HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_front[p], 0));
+    if (s->fence_set) {      // the caller's output fence: only the stage that writes the audio buffer waits for it
+      HIP_CHECK(hipEventRecord(s->ev_fence[p], s->fence_stream));
+      HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_fence[p], 0));
+      s->fence_set = false;
+    }
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, s->st_voc);
     HIP_CHECK(hipEventRecord(s->ev_voc[p], s->st_voc));
     s->async_steps = t + 1;
+  });
+}
+
+int conan_streams_output_fence(conan_streams* s, void* fence_stream) {
+  return guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    s->fence_stream = (hipStream_t)fence_stream; s->fence_set = true;
   });
 }
 

@@ -27,7 +27,6 @@
 #include <map>
 #include <mutex>
 #include <queue>
-#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -426,27 +425,22 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
 #else
       bar();                                             // B3: the helpers are done with the previous tile's accumulators
 #endif
-      // (0 <= slope < 1: LeakyReLU(v) = max(v, slope v); zrows != 0 only for the first tile of a stream's first steps)
-      auto c1_out = [&](auto zr_tag) __attribute__((always_inline)) {
-        constexpr bool ZR = decltype(zr_tag)::value;
 #pragma unroll
-        for (int c = 0; c < G::NCW; ++c) {
-          const int col = (ct0 + c) * 16 + lr;
+      for (int c = 0; c < G::NCW; ++c) {
+        const int col = (ct0 + c) * 16 + lr;
 #pragma unroll
-          for (int r = 0; r < G::NRW1; ++r) {
-            if (rt0 + r < G::NR1) {
+        for (int r = 0; r < G::NRW1; ++r) {
+          if (rt0 + r < G::NR1) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int m = (rt0 + r) * 16 + 4 * lg + e;
-                float v = acc[r][c][e] + b1v[c];
-                v = fmaxf(v, v * slope);
-                xt[m * LDX + col] = (ZR && m < zrows) ? 0.f : v;
-              }
+            for (int e = 0; e < 4; ++e) {
+              const int m = (rt0 + r) * 16 + 4 * lg + e;
+              float v = acc[r][c][e] + b1v[c];
+              v = v > 0.f ? v : v * slope;
+              xt[m * LDX + col] = m < zrows ? 0.f : v;
             }
           }
         }
-      };
-      if (zrows == 0) c1_out(std::false_type{}); else c1_out(std::true_type{});
+      }
     }
 #if RB_ABLATE & 4
     { unsigned long long q0 = RB_T(); bar(); unsigned long long q1 = RB_T(); st_b1 += q1 - q0; st_bar += q1 - q0; }

@@ -135,7 +135,10 @@ struct conan_streams {
   // --- pipelined stepping (conan_step_async): front-end (Emformer + decoder) and vocoder on two internal streams
   hipStream_t st_emf = nullptr, st_front = nullptr, st_voc = nullptr;
   static constexpr int NP = 4;                 // depth of the hand-off rings: a stage may run up to NP steps ahead of its consumer
-  hipEvent_t ev_in = nullptr, ev_emf[NP] = {}, ev_front[NP] = {}, ev_voc[NP] = {};
+  hipEvent_t ev_in[NP] = {}, ev_emf[NP] = {}, ev_front[NP] = {}, ev_voc[NP] = {};   // (one input event per ring position: a single
+                                               // event re-recorded while its previous record is still pending stalls the pipeline)
+  hipEvent_t ev_fence[NP] = {};                // output fences (conan_streams_output_fence)
+  hipStream_t fence_stream = nullptr; bool fence_set = false;
   int* codes_hand[NP] = {};                    // code hand-off buffers Emformer -> decoder [max_slots][segment]
   // workspace index of a stream: 0 caller / pipelined decoder, 1 pipelined vocoder, 2 pipelined Emformer
   int ws_index(hipStream_t st) const { return (st_voc && st == st_voc) ? 1 : ((st_emf && st == st_emf) ? 2 : 0); }
@@ -148,7 +151,7 @@ struct conan_streams {
     if (st_emf) (void)hipStreamDestroy(st_emf);
     if (st_front) (void)hipStreamDestroy(st_front);
     if (st_voc) (void)hipStreamDestroy(st_voc);
-    if (ev_in) (void)hipEventDestroy(ev_in);
+    for (int i = 0; i < NP; ++i) { if (ev_in[i]) (void)hipEventDestroy(ev_in[i]); if (ev_fence[i]) (void)hipEventDestroy(ev_fence[i]); }
     for (int i = 0; i < NP; ++i) { if (ev_emf[i]) (void)hipEventDestroy(ev_emf[i]); if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

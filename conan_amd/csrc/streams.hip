@@ -186,8 +186,9 @@ void conan_streams::async_init() {
       HIP_CHECK(hipStreamCreateWithPriority(&st_voc, hipStreamNonBlocking, mode > 0 ? lo : hi));
     }
   }
-  HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   for (int i = 0; i < NP; ++i) {
+    HIP_CHECK(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_fence[i], hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_emf[i], hipEventDisableTiming));
     codes_hand[i] = (int*)alloc((size_t)max_slots * max_frames);
     HIP_CHECK(hipEventCreateWithFlags(&ev_front[i], hipEventDisableTiming));

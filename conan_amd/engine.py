@@ -98,6 +98,11 @@ class AudioGatherRing:
             ... enqueue the step that writes buf ...
             ring.submit(j, join)           # side stream: join(); gather(buf); record
         ring.drain()
+
+    Pipelined steps should not take the wait on the current stream: it holds back the step's Emformer and decoder stages,
+    which never touch the buffer, and drains the three-stage pipeline (measured on one MI355X: 1.81 -> 2.6 ms per step).
+    `buf, fence = ring.acquire(j, fence=True)` returns the side stream instead (None while no gather can be pending) for
+    `Streams.step_async(..., out_fence=fence)`: only the stage that writes the audio waits for the gather.
     """
 
     def __init__(self, make_buffer, world, rank, nb=4, always=False, on_gathered=None):
@@ -115,9 +120,12 @@ class AudioGatherRing:
             self.done = [_HostStream() for _ in range(nb)]
         self.submitted = 0
 
-    def acquire(self, j):
+    def acquire(self, j, fence=False):
         k = j % self.nb
-        if self.active and j >= self.nb:
+        pending = self.active and j >= self.nb
+        if fence:       # the side stream is in order: everything enqueued on it so far includes the gather that read bufs[k]
+            return self.bufs[k], (self.comm if (pending and self.cuda) else None)
+        if pending:
             (torch.cuda.current_stream() if self.cuda else _HostStream()).wait_event(self.done[k])
         return self.bufs[k]
 
