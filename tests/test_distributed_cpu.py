@@ -69,7 +69,8 @@ def _ring_worker(rank, world, port, steps, q):
     ring = AudioGatherRing(lambda: torch.zeros(3, 16), world, rank, nb=4, on_gathered=on_gathered)
     joined = []
     for j in range(steps):
-        buf = ring.acquire(j)
+        buf, fence = ring.acquire(j, fence=True)      # the benchmark's form: the step takes the side stream as its output fence
+        assert fence is None                          # (host-only group: everything is synchronous, nothing to wait for)
         buf.fill_(1000.0 * rank + j)                  # the "vocoder" of step j
         ring.submit(j, join=lambda j=j: joined.append(j))
     ring.drain()
