@@ -177,10 +177,9 @@ def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=
     if hifigan_hp is not None and hifigan:
         v = hifigan_hp
         up = v.get("upsample", "shuffle")
-        if up not in ("shuffle", "zero"):
-            raise ConanError(ERR_UNSUPPORTED, "upsample='%s': CausalUpsampleBlock1's output frame t depends on input frames t+1, t+2 "
-                                              "(hifigan_causal.py:60-145), it cannot be streamed; use 'shuffle' or 'zero'" % up)
-        c.voc_upsample = 0 if up == "shuffle" else 1
+        if up not in ("shuffle", "zero", "nn"):
+            raise ConanError(ERR_UNSUPPORTED, "upsample='%s': 'shuffle', 'zero' or 'nn' (hifigan_causal.py:287-293)" % up)
+        c.voc_upsample = {"shuffle": 0, "zero": 1, "nn": 2}[up]
         c.voc_resblock = 1 if str(v.get("resblock", "1")) == "1" else 2
         if len({len(ds) for ds in v["resblock_dilation_sizes"]}) != 1:
             raise ConanError(ERR_UNSUPPORTED, "resblock branches with different numbers of dilations")

@@ -72,6 +72,9 @@ HIFIGAN_TINY = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample_initial_chan
 HIFIGAN_ZERO_RB2 = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample="zero", resblock="2",
                         resblock_dilation_sizes=[[1, 3], [1, 3], [1, 3]])
 HIFIGAN_ZERO_RB2_TINY = dict(copy.deepcopy(HIFIGAN_ZERO_RB2), upsample_initial_channel=64)
+# `upsample: nn` (CausalUpsampleBlock1, transposed convolution): whole-utterance / whole-window forward only
+HIFIGAN_NN = dict(copy.deepcopy(HIFIGAN_16K320_SHUFFLE), upsample="nn")
+HIFIGAN_NN_TINY = dict(copy.deepcopy(HIFIGAN_NN), upsample_initial_channel=64)
 
 
 def conan_hparams(tiny=False):

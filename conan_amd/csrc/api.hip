@@ -27,7 +27,9 @@ static void validate_cfg(const conan_cfg& c) {
     if (c.voc_num_ups < 1 || c.voc_num_ups > CONAN_MAX_UPS) throw Error(CONAN_ERR_INVALID, "voc_num_ups");
     if (c.voc_num_resblocks < 1 || c.voc_num_resblocks > 3) throw Error(CONAN_ERR_UNSUPPORTED, "1..3 resblock branches supported");
     if (c.voc_rb_num_dil < 1 || c.voc_rb_num_dil > CONAN_MAX_DILATIONS) throw Error(CONAN_ERR_INVALID, "voc_rb_num_dil");
-    if (c.voc_upsample < 0 || c.voc_upsample > 1) throw Error(CONAN_ERR_UNSUPPORTED, "voc_upsample: 0 (shuffle) or 1 (zero)");
+    if (c.voc_upsample < 0 || c.voc_upsample > 2) throw Error(CONAN_ERR_UNSUPPORTED, "voc_upsample: 0 (shuffle), 1 (zero) or 2 (nn)");
+    for (int i = 0; i < c.voc_num_ups && c.voc_upsample == 2; ++i)     // hifigan_causal.py:70-71
+      if (c.voc_up_kernels[i] % 2 || c.voc_up_rates[i] < 2) throw Error(CONAN_ERR_INVALID, "upsample 'nn': kernel sizes must be even, rates >= 2");
     if (c.voc_resblock < 0 || c.voc_resblock > 2) throw Error(CONAN_ERR_UNSUPPORTED, "voc_resblock: 1 or 2");
     int ch_ = c.voc_initial_channel;
     for (int i = 0; i < c.voc_num_ups; ++i) { ch_ /= 2; if (ch_ < 4 || ch_ % 4) throw Error(CONAN_ERR_UNSUPPORTED, "vocoder channel ladder must stay a multiple of 4"); }
@@ -128,7 +130,7 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
       s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
-      s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0);
+      s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
       std::vector<int> id(max_slots);
@@ -158,7 +160,10 @@ int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which
       for (auto& b : v) cnk::launch_zero_slots(b.first, b.second, b.second, s->d_slots, n, st);
       cnk::launch_fill_int(pos, s->d_slots, n, 0, st);
     };
-    if (models & CONAN_MODEL_HIFIGAN) zero(s->voc_state, s->pos_voc);
+    if (models & CONAN_MODEL_HIFIGAN) {
+      zero(s->voc_state, s->pos_voc);
+      for (int i = 0; i < n; ++i) s->voc_fresh[slots[i]] = 1;
+    }
     if (models & CONAN_MODEL_EMFORMER) zero(s->emf_state, s->pos_emf);
     if (models & CONAN_MODEL_CONAN) zero(s->dec_state, s->pos_dec);
   });

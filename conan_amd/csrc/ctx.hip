@@ -182,6 +182,45 @@ void conan_ctx::finalize_hifigan() {
     const std::string up = P + "ups." + std::to_string(i) + ".conv.conv";
     if (c.voc_upsample == 0) {
       pack_weightnorm("voc.ups." + std::to_string(i), up, c.voc_up_rates[i]);
+    } else if (c.voc_upsample == 2) {
+      // CausalUpsampleBlock1 (hifigan_causal.py:60-145): left pad P = k/2 - 1, ConvTranspose1d, drop P*s + k - 1 samples:
+      //   y[q*s + r][co] = b[co] + sum_m sum_ci x[q + m][ci] * w[ci][co][r + k - 1 - m*s],   0 <= r + k - 1 - m*s < k,
+      // i.e. m = 0 .. M = (k + s - 2) / s input frames AHEAD of q and none behind it (x beyond the last frame = 0).
+      // Packed as an M + 1 tap conv to Cout*s channels in pixel-shuffle form; the launch reads rows t .. t + M
+      // (pad_left = 0, streams.hip) instead of t - M .. t.  weight_norm of a ConvTranspose1d normalises over dim 0 of the
+      // [Cin, Cout, k] weight, the INPUT channel.
+      const std::string dc = P + "ups." + std::to_string(i) + ".deconv";
+      const bool folded = has(dc + ".weight");
+      const HostTensor& v = get(dc + (folded ? ".weight" : ".weight_v"));
+      const HostTensor& bias = get(dc + ".bias");
+      const int Cin = (int)v.shape[0], Cout = (int)v.shape[1], k = (int)v.shape[2];
+      const int sr = c.voc_up_rates[i];
+      if (k != c.voc_up_kernels[i] || k % 2 || sr < 2 || bias.numel() != Cout) throw Error(CONAN_ERR_SHAPE, "bad transposed upsampler: " + dc);
+      std::vector<float> W(v.data);
+      if (!folded) {
+        const HostTensor& g = get(dc + ".weight_g");
+        if (g.numel() != Cin) throw Error(CONAN_ERR_SHAPE, "bad weight_g: " + dc);
+        const size_t per = (size_t)Cout * k;
+        for (int ci = 0; ci < Cin; ++ci) {
+          double ss = 0.0;
+          for (size_t e = 0; e < per; ++e) { double x = v.data[ci * per + e]; ss += x * x; }
+          const float nrm = (float)std::sqrt(ss), gg = g.data[ci];
+          for (size_t e = 0; e < per; ++e) W[ci * per + e] = v.data[ci * per + e] * (gg / nrm);
+        }
+      }
+      const int D = (k + sr - 2) / sr + 1;
+      std::vector<float> Wp((size_t)Cout * sr * Cin * D, 0.f), bp((size_t)Cout * sr);
+      for (int co = 0; co < Cout; ++co)
+        for (int r = 0; r < sr; ++r) {
+          bp[(size_t)co * sr + r] = bias.data[co];
+          for (int m = 0; m < D; ++m) {
+            const int idx = r + k - 1 - m * sr;
+            if (idx < 0 || idx >= k) continue;
+            for (int ci = 0; ci < Cin; ++ci)     // tap m reads x[t + m]
+              Wp[(((size_t)co * sr + r) * Cin + ci) * D + m] = W[((size_t)ci * Cout + co) * k + idx];
+          }
+        }
+      pack_conv("voc.ups." + std::to_string(i), Wp, bp.data(), Cout * sr, Cin, D, sr);
     } else {
       // CausalUpsampleBlock2 (zero insertion + causal conv k, hifigan_causal.py:151-165) as a polyphase conv over the
       // *input* rate in pixel-shuffle form: output sample t*s+j = sum_d w[(k-1) - j - s*d] . x[t-d], d = 0 .. D-1 with

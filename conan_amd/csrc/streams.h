@@ -104,6 +104,7 @@ struct conan_streams {
   int* c_slen = nullptr;        // [slot]
   int* c_vqids = nullptr;       // [slot][S_max] VQ indices of the prosody tokens (-1 past the token count)
   std::vector<char> has_ref;    // per slot: conan_set_reference has run for it
+  std::vector<char> voc_fresh;  // per slot: vocoder state reset and not stepped since (voc_upsample 2 steps need it)
   // --- style pass workspace (batch indexed, max_slots_sp at a time)
   int sp_batch = 0;
   Lin s_mel, s_np, s_wnm, s_x[2], s_ln, s_h, s_blkm, s_wx, s_wout, s_win, s_acts, s_rs, s_ph, s_pm, s_px[2], s_pln, s_phh,

@@ -252,6 +252,15 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
   const conan_cfg& c = ctx->cfg;
   const int* pos = pos_voc;
   const float LR = 0.1f;   // LRELU_SLOPE, hifigan_causal.py:20
+  // upsample 'nn' (CausalUpsampleBlock1) reads input frames AHEAD of the output frame and zeros beyond the last one:
+  // a step is a whole forward (utterance or window) from freshly reset state, whose untouched ring rows are those zeros
+  const bool lookahead = c.voc_upsample == 2;
+  for (int i = 0; i < n; ++i) {
+    if (lookahead && !voc_fresh[h_slots[i]])
+      throw Error(CONAN_ERR_STATE, "upsample 'nn' (CausalUpsampleBlock1) looks ahead of the frame it writes: slot " + std::to_string(h_slots[i]) +
+                                       " needs conan_streams_reset(CONAN_MODEL_HIFIGAN) before every vocoder step (whole-utterance or windowed forward only)");
+    voc_fresh[h_slots[i]] = 0;
+  }
   {  // mel chunk -> ring (conv_pre needs 6 frames of left context)
     cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.x = ch::lin_ref(const_cast<float*>(mel_dev), frames, c.num_mels); ca.y = v_mel.ref();
@@ -281,7 +290,8 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
     const int T = frames * s.rate;
     {  // x = leaky_relu(x); x = ups[i](x)   (hifigan_causal.py:321-322): the input (v_pre / branch mean xs) is stored
        // activated; the output goes out raw (residual operand) and activated (c1 operand)
-      ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos);
+      ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos, 1,
+                      lookahead ? 0 : -1);
       if (!s.fused) { a.y2_base = s.upa.base; a.y2_slope = LR; }
       conv(a, st);
       if (taps) tap(taps->ups[i], s.up, T);

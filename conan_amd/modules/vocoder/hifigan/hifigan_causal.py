@@ -3,7 +3,9 @@
 
 forward(x[B, 80, T]) -> [B, 1, T*prod(upsample_rates)].  Because every layer is causal, the whole-utterance
 forward equals a reset followed by stateful steps; it is run as steps of <= 16 frames so the
-per-stream rings stay small."""
+per-stream rings stay small.  `upsample: nn` (CausalUpsampleBlock1, :60-145) is the exception: the transposed
+convolution looks two input frames ahead at every stage, so its forward is one step over the whole input (rings sized
+for T frames) and the library refuses a second step without a reset."""
 import torch
 from torch import nn
 
@@ -18,10 +20,12 @@ class HifiGanGenerator(_tree.ParamTree):
     def __init__(self, hparams):
         super().__init__()
         self.h = hparams
-        if hparams.get("upsample", "shuffle") not in ("shuffle", "zero"):
-            raise NotImplementedError("upsample='nn' (CausalUpsampleBlock1) looks two frames ahead and cannot be streamed; "
-                                      "'shuffle' (egs/hifi_16k320_shuffle.yaml) and 'zero' are on the HIP path, with resblock '1' or '2'")
-        _tree.build_tree(self, specs.hifigan_spec(hparams))
+        if hparams.get("upsample", "shuffle") not in ("shuffle", "zero", "nn"):
+            raise NotImplementedError("upsample=%r: 'shuffle', 'zero' or 'nn' (hifigan_causal.py:287-293)" % (hparams.get("upsample"),))
+        self.one_shot = hparams.get("upsample", "shuffle") == "nn"
+        spec = specs.hifigan_spec(hparams)
+        _tree.build_tree(self, spec, buffers=[k for k in spec if k.endswith("._cache")])
+        self._frames = self.STEP_FRAMES
         self._ctx = None
         self._streams = None
 
@@ -57,13 +61,14 @@ class HifiGanGenerator(_tree.ParamTree):
         self._drop()
         return out
 
-    def _get_streams(self, B):
+    def _get_streams(self, B, frames):
         if self._ctx is None:
             self.refresh()
-        if self._streams is None or self._streams.max_slots < B:
+        if self._streams is None or self._streams.max_slots < B or self._frames < frames:
             if self._streams is not None:
                 self._streams.close()
-            self._streams = self._ctx.streams(B, max_frames=self.STEP_FRAMES, max_ref_frames=4)
+            self._frames = max(self._frames, frames)
+            self._streams = self._ctx.streams(B, max_frames=self._frames, max_ref_frames=4)
         return self._streams
 
     @torch.no_grad()
@@ -71,13 +76,14 @@ class HifiGanGenerator(_tree.ParamTree):
         if not x.is_cuda:
             raise RuntimeError("conan_amd.HifiGanGenerator runs on a HIP device only (no CPU fallback)")
         B, C, T = x.shape
-        st = self._get_streams(B)
+        step = T if self.one_shot else self.STEP_FRAMES
+        st = self._get_streams(B, step)
         slots = list(range(B))
         st.reset(slots, which=4)
         mel = x.transpose(1, 2).contiguous().float()
         outs = []
-        for p in range(0, T, self.STEP_FRAMES):
-            outs.append(st.hifigan_step(slots, mel[:, p:p + self.STEP_FRAMES]))
+        for p in range(0, T, step):
+            outs.append(st.hifigan_step(slots, mel[:, p:p + step]))
         return torch.cat(outs, 1).unsqueeze(1)
 
     def remove_weight_norm(self):

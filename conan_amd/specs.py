@@ -107,8 +107,9 @@ def conan_spec(hp):
 
 
 def hifigan_spec(hp):
-    """HifiGanGenerator (hifigan_causal.py:273-312): upsample 'shuffle' (CausalUpsampleBlock3) or 'zero'
-    (CausalUpsampleBlock2), resblock '1' (convs1/convs2) or '2' (convs)."""
+    """HifiGanGenerator (hifigan_causal.py:273-312): upsample 'shuffle' (CausalUpsampleBlock3), 'zero'
+    (CausalUpsampleBlock2) or 'nn' (CausalUpsampleBlock1: weight-normed ConvTranspose1d `deconv`, weight [Cin, Cout, k]
+    with the norm over dim 0 = Cin, plus the `_cache` buffer of :115), resblock '1' (convs1/convs2) or '2' (convs)."""
     s = OrderedDict()
 
     def wn(prefix, co, ci, k):
@@ -124,12 +125,18 @@ def hifigan_spec(hp):
     ups, rbs = [], []
     for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
         out = ch // 2
-        ups.append((f"ups.{i}.conv.conv", out * u if mode == "shuffle" else out, ch, k))
+        if mode == "nn":
+            ups.append((f"ups.{i}.deconv", ch, out, k))        # ConvTranspose1d: dim 0 is the input channel
+        else:
+            ups.append((f"ups.{i}.conv.conv", out * u if mode == "shuffle" else out, ch, k))
         for j, (rk, rd) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
             rbs.append((len(rbs), out, rk, rd))
         ch = out
-    for (p, co, ci, k) in ups:
+    for i, (p, co, ci, k) in enumerate(ups):
         wn(p, co, ci, k)
+        if mode == "nn":
+            s[f"{p}.bias"] = (ci,)                              # one bias per OUTPUT channel (dim 1 of the weight)
+            s[f"ups.{i}._cache"] = (1, co, k // 2 - 1)
     for (idx, c, rk, rd) in rbs:
         for name in (("convs",) if rb2 else ("convs1", "convs2")):
             for d in range(len(rd)):

@@ -40,7 +40,7 @@ def fill(key, shape, seed=0):
     """Deterministic value of state_dict entry `key` (float32 ndarray of `shape`)."""
     shape = tuple(int(s) for s in shape)
     r = _rng(seed, key)
-    if key.endswith("_float_tensor"):
+    if key.endswith("_float_tensor") or key.endswith("._cache"):
         return np.zeros(shape, np.float32)
     if key.endswith("data_initialized"):
         return np.ones(shape, np.float32)

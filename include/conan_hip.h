@@ -75,7 +75,9 @@ typedef struct conan_cfg {
   /* which sub-models this context holds (bit 0 Emformer, bit 1 Conan, bit 2 HiFi-GAN) */
   int32_t models;
   /* vocoder config.yaml choices (hifigan_causal.py:287-303); 0 = the shipped egs/hifi_16k320_shuffle.yaml values */
-  int32_t voc_upsample;           /* 0: 'shuffle' (CausalUpsampleBlock3), 1: 'zero' (CausalUpsampleBlock2); 'nn' is not streamable */
+  int32_t voc_upsample;           /* 0: 'shuffle' (CausalUpsampleBlock3), 1: 'zero' (CausalUpsampleBlock2), 2: 'nn' (CausalUpsampleBlock1,
+                                     hifigan_causal.py:60-145: looks ahead, so every vocoder step must follow a reset of its slots
+                                     and carry the whole utterance or window; CONAN_ERR_STATE otherwise) */
   int32_t voc_resblock;           /* 0 or 1: ResBlock1, 2: ResBlock2 */
   /* torchaudio.models.Emformer(max_memory_size=, tanh_on_mem=): the memory bank.  modules/Emformer/emformer.py:14-22
    * never passes them (0 / false), so shipped checkpoints run without a bank; > 0 enables the summary vector,

@@ -1,7 +1,7 @@
 """Oracle: causal pixel-shuffle HiFi-GAN generator.
 
 Restates modules/vocoder/hifigan/hifigan_causal.py:
-  CausalConv1d :30-58, CausalUpsampleBlock2 :151-165, CausalPixelShuffle1d :171-189, CausalUpsampleBlock3 :191-212,
+  CausalConv1d :30-58, CausalUpsampleBlock1 :60-145, CausalUpsampleBlock2 :151-165, CausalPixelShuffle1d :171-189, CausalUpsampleBlock3 :191-212,
   ResBlock1 :217-244, ResBlock2 :246-267, HifiGanGenerator.forward :314-333,
 and the numpy wrapper tasks/tts/vocoder_infer/hifigan.py:23-31 (spec2wav).
 Test infrastructure only (see oracle/__init__.py).
@@ -63,13 +63,30 @@ def zero_insert(x, stride):
     return up
 
 
+def transposed_upsample(sd, prefix, x, stride, k):
+    """CausalUpsampleBlock1.forward, hifigan_causal.py:118-141: left-pad k/2 - 1 zero frames, ConvTranspose1d (padding 0,
+    output_padding stride - 1; weight_norm over dim 0 = the INPUT channel of a ConvTranspose1d weight [Cin, Cout, k]),
+    drop the first (k/2 - 1) * stride + k - 1 samples.  T*stride samples remain.  Despite its name the block looks
+    ahead: sample t depends on input frames ceil(t/stride) .. floor((t + k - 1)/stride), none of them in the past."""
+    if prefix + ".weight" in sd:
+        w = sd[prefix + ".weight"]
+    else:
+        w = torch._weight_norm(sd[prefix + ".weight_v"], sd[prefix + ".weight_g"], 0)
+    pad = k // 2 - 1
+    y = F.conv_transpose1d(F.pad(x, (pad, 0)), w, sd[prefix + ".bias"], stride=stride, padding=0, output_padding=stride - 1)
+    y = y[:, :, pad * stride + k - 1:]
+    assert y.shape[2] == x.shape[2] * stride
+    return y
+
+
 @torch.no_grad()
 def generator_forward(sd, hp, mel, st=None, taps=None):
     """HifiGanGenerator.forward (hifigan_causal.py:314-333). mel[B,80,T] -> wav[B,1,T*prod(rates)].
     `st` (dict) switches to stateful streaming (new frames only); `taps` (dict) collects
     per-stage pre-activation tensors for the parity tests."""
     mode = hp.get("upsample", "shuffle")
-    assert mode in ("shuffle", "zero")     # 'nn' (CausalUpsampleBlock1) is not restated
+    assert mode in ("shuffle", "zero", "nn")
+    assert mode != "nn" or st is None      # 'nn' looks ahead: whole-utterance (or whole-window) forward only
     rb = resblock1 if str(hp.get("resblock", "1")) == "1" else resblock2
     x = _cconv(sd, "conv_pre.conv", mel, 1, st)
     if taps is not None:
@@ -81,6 +98,8 @@ def generator_forward(sd, hp, mel, st=None, taps=None):
         if mode == "shuffle":
             x = _cconv(sd, f"ups.{i}.conv.conv", x, 1, st)
             x = pixel_shuffle_1d(x, u)
+        elif mode == "nn":
+            x = transposed_upsample(sd, f"ups.{i}.deconv", x, u, k)
         else:
             x = _cconv(sd, f"ups.{i}.conv.conv", zero_insert(x, u), 1, st)
         if taps is not None:

@@ -159,11 +159,42 @@ def test_zero_insert_upsampler_and_resblock2(tag, vhp):
     st.close(); ctx.close()
 
 
-def test_transposed_conv_upsampler_is_rejected():
+@pytest.mark.parametrize("tag,vhp", [("nn_tiny", configs.HIFIGAN_NN_TINY), ("nn_full", configs.HIFIGAN_NN)])
+def test_transposed_conv_upsampler_whole_forward(tag, vhp):
+    """`upsample: nn` (CausalUpsampleBlock1, hifigan_causal.py:60-145).  The block looks two input
+    frames ahead at every stage, so it runs as ONE step over the whole input from reset state (polyphase taps over rows
+    t .. t+2, zeros beyond the end) - against the reference golden, per-stage taps included; a second step without a reset
+    is refused; the Python seam's forward and a 2-slot batch give the same samples."""
     from conan_amd import _lib
-    vhp = dict(configs.hifigan_hparams(True), upsample="nn")
-    with pytest.raises(_lib.ConanError):
-        _lib.make_cfg(None, vhp, emformer=False, conan=False, hifigan=True)
+    from conan_amd.runtime import Context
+    from conan_amd.modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
+    ctx = Context(None, vhp, 0, False, False, True)
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    g = load_golden(f"hifigan_{tag}.npz")
+    st = ctx.streams(2, max_frames=40, max_ref_frames=16)
+    mel40 = torch.from_numpy(g["mel_40"]).transpose(1, 2).contiguous().cuda()      # [1, 40, 80]
+    mel12 = torch.from_numpy(g["mel_12"]).transpose(1, 2).contiguous().cuda()
+    wav = st.hifigan_step([1], mel40)                                                 # a new stream-set starts reset
+    np.testing.assert_allclose(wav[0].cpu().numpy(), g["wav_40"], atol=1e-4, rtol=0)
+    with pytest.raises(_lib.ConanError, match="looks ahead"):
+        st.hifigan_step([1], mel40[:, :4])
+    st.reset([1, 0])
+    both = st.hifigan_step([1, 0], torch.cat([mel40, mel40.flip(1)], 0))
+    np.testing.assert_allclose(both[0].cpu().numpy(), g["wav_40"], atol=1e-4, rtol=0)
+    st.reset([0])
+    wav12, _, _, ups = st.hifigan_step_taps([0], mel12)
+    for i in range(len(vhp["upsample_rates"])):
+        ref = g[f"ups.{i}_12"].T                                                      # [T_i, C_i]
+        np.testing.assert_allclose(ups[i][0].cpu().numpy(), ref, atol=1e-4 * max(1.0, np.abs(ref).max()), rtol=0)
+    np.testing.assert_allclose(wav12[0].cpu().numpy(), g["wav_12"], atol=1e-4, rtol=0)
+    st.close(); ctx.close()
+    gen = HifiGanGenerator(dict(vhp))
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hifigan_state_dict(vhp, 0).items()}, strict=True)
+    y = gen(torch.from_numpy(g["mel_40"]).cuda())
+    np.testing.assert_allclose(y[0, 0].cpu().numpy(), g["wav_40"], atol=1e-4, rtol=0)
+    y = gen(torch.from_numpy(g["mel_12"]).cuda())                                    # resets between forwards
+    np.testing.assert_allclose(y[0, 0].cpu().numpy(), g["wav_12"], atol=1e-4, rtol=0)
 
 
 def test_emformer_mode_both_uses_proj1():

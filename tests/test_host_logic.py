@@ -30,8 +30,9 @@ def test_cfg_struct_matches_header_and_hparams():
     assert cfg.models == 7 and cfg.hidden_size == 256 and cfg.emf_segment == 4 and cfg.emf_right_context == 2
     assert list(cfg.voc_up_rates)[:4] == [8, 5, 4, 2] and list(cfg.voc_up_kernels)[:4] == [16, 10, 8, 4]
     assert [list(r)[:3] for r in cfg.voc_rb_dilations][:3] == [[1, 3, 5]] * 3
+    assert _lib.make_cfg(None, configs.HIFIGAN_NN, emformer=False, conan=False).voc_upsample == 2
     with pytest.raises(_lib.ConanError):
-        _lib.make_cfg(None, dict(configs.hifigan_hparams(), upsample="nn"))
+        _lib.make_cfg(None, dict(configs.hifigan_hparams(), upsample="linear"))
     with pytest.raises(_lib.ConanError):
         _lib.make_cfg(dict(configs.conan_hparams(), f0_gen="flow"), None)
 
@@ -78,7 +79,14 @@ def test_state_dict_contracts():
     with pytest.raises(ValueError):
         c.forward(torch.zeros(1, 4, dtype=torch.long), ref=None, infer=True)      # Conan.py:152-155
     with pytest.raises(NotImplementedError):
-        HifiGanGenerator(dict(vhp, upsample="nn"))
+        HifiGanGenerator(dict(vhp, upsample="linear"))
+    # `upsample: nn` carries the reference's ConvTranspose1d tree: weight [Cin, Cout, k], weight_g per INPUT channel, `_cache` buffer
+    gn = HifiGanGenerator(dict(vhp, upsample="nn"))
+    nsd = gn.state_dict()
+    C0 = vhp["upsample_initial_channel"]
+    assert tuple(nsd["ups.0.deconv.weight_v"].shape) == (C0, C0 // 2, 16) and tuple(nsd["ups.0.deconv.weight_g"].shape) == (C0, 1, 1)
+    assert tuple(nsd["ups.0.deconv.bias"].shape) == (C0 // 2,) and tuple(nsd["ups.0._cache"].shape) == (1, C0, 7)
+    assert "ups.0._cache" in dict(gn.named_buffers()) and gn.one_shot
 
 
 def test_hparams_yaml_chain(tmp_path, monkeypatch):

@@ -131,3 +131,28 @@ def test_hifigan_zero_upsampler_resblock2_matches_reference(tag, vhp, golden):
     for i in range(0, 40, 4):
         outs.append(ohifi.generator_forward(vsd, vhp, mel[:, :, i:i + 4], st))
     np.testing.assert_allclose(torch.cat(outs, 2)[0, 0].numpy(), g["wav_40"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("tag,vhp", [("nn_tiny", configs.HIFIGAN_NN_TINY), ("nn_full", configs.HIFIGAN_NN)])
+def test_hifigan_transposed_conv_upsampler_matches_reference(tag, vhp, golden):
+    """`upsample: nn` (CausalUpsampleBlock1, hifigan_causal.py:60-145) against the reference generator built from that
+    config; and the property that makes it a whole-utterance-only block: it looks AHEAD (a later frame changes earlier
+    samples), so prefix outputs differ from the full forward near the prefix end."""
+    vsd = to_torch_sd(synth.hifigan_state_dict(vhp, 0))
+    g = golden(f"hifigan_{tag}.npz")
+    for T in (12, 40):
+        taps = {}
+        wav = ohifi.generator_forward(vsd, vhp, torch.from_numpy(g[f"mel_{T}"]), None, taps)
+        np.testing.assert_allclose(wav[0, 0].numpy(), g[f"wav_{T}"], atol=TOL, rtol=0)
+        if T == 12:
+            for i in range(4):
+                np.testing.assert_allclose(taps[f"ups.{i}"][0].numpy(), g[f"ups.{i}_12"], atol=2e-5, rtol=1e-5)
+            np.testing.assert_allclose(taps["pre_tanh"][0].numpy(), g["pre_tanh_12"], atol=2e-5, rtol=1e-5)
+    mel = torch.from_numpy(g["mel_40"])
+    pre = ohifi.generator_forward(vsd, vhp, mel[:, :, :20])[0, 0].numpy()
+    full = g["wav_40"][:20 * 320]
+    # total look-ahead: 2 frames at every stage's input rate = 2*320 + 2*40 + 2*8 + 2*2 = 740 samples
+    np.testing.assert_allclose(pre[:20 * 320 - 740], full[:20 * 320 - 740], atol=TOL, rtol=0)
+    assert np.abs(pre - full).max() > 1e-3
+    with pytest.raises(AssertionError):
+        ohifi.generator_forward(vsd, vhp, mel[:, :, :4], {})      # no stateful streaming for this block

@@ -77,9 +77,11 @@ def vocoder_goldens(g, tag, frames=(12, 150)):
 
 @torch.no_grad()
 def vocoder_variant_goldens():
-    """`upsample: zero` + `resblock: "2"` (hifigan_causal.py:287-303): the reference generator built from that config."""
+    """`upsample: zero` + `resblock: "2"`, and `upsample: nn` (hifigan_causal.py:287-303): the reference generator
+    built from those configs."""
     from modules.vocoder.hifigan.hifigan_causal import HifiGanGenerator
-    for tag, ghp in (("zero_rb2_tiny", configs.HIFIGAN_ZERO_RB2_TINY), ("zero_rb2_full", configs.HIFIGAN_ZERO_RB2)):
+    for tag, ghp in (("zero_rb2_tiny", configs.HIFIGAN_ZERO_RB2_TINY), ("zero_rb2_full", configs.HIFIGAN_ZERO_RB2),
+                     ("nn_tiny", configs.HIFIGAN_NN_TINY), ("nn_full", configs.HIFIGAN_NN)):
         g = HifiGanGenerator(dict(ghp)).eval()
         g.load_state_dict(t(synth.hifigan_state_dict(ghp, 0)), strict=True)
         vocoder_goldens(g, tag, frames=(12, 40))
@@ -152,7 +154,7 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     vocoder_variant_goldens()
-    print("wrote goldens: vocoder variants (zero-insert upsampler + ResBlock2)")
+    print("wrote goldens: vocoder variants (zero-insert upsampler + ResBlock2; transposed-conv upsampler)")
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
         return
     for tiny in (False, True):
