@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conan_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_UPS, MAX_RESBLOCKS, MAX_DILATIONS, MAX_DEC_BLOCKS = 8, 4, 4, 16
 MODEL_EMFORMER, MODEL_CONAN, MODEL_HIFIGAN = 1, 2, 4
 
@@ -121,7 +121,8 @@ class MelCfg(C.Structure):
     """conan_mel_cfg (include/conan_hip.h)."""
     _fields_ = [("fft_size", C.c_int32), ("hop_size", C.c_int32), ("win_length", C.c_int32), ("num_mels", C.c_int32),
                 ("sample_rate", C.c_int32), ("fmin", C.c_float), ("fmax", C.c_float), ("eps", C.c_float),
-                ("vmin", C.c_float), ("vmax", C.c_float)]
+                ("vmin", C.c_float), ("vmax", C.c_float), ("framing", C.c_int32), ("natural_log", C.c_int32),
+                ("mag_eps", C.c_float)]
 
 
 class DecoderTaps(C.Structure):

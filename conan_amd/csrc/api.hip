@@ -408,7 +408,7 @@ int conan_wav2mel(conan_ctx* ctx, const conan_mel_cfg* cfg, const float* wav_dev
     if (!ctx->finalized) throw Error(CONAN_ERR_STATE, "conan_ctx_finalize must run before conan_wav2mel");
     HIP_CHECK(hipSetDevice(ctx->device));
     ctx->wav2mel(*cfg, wav_dev, n, samples, mel_out_dev, (hipStream_t)stream);
-    if (frames_out) *frames_out = 1 + samples / cfg->hop_size;
+    if (frames_out) *frames_out = conan_mel_frames(*cfg, samples);
   });
 }
 

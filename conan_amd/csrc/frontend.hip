@@ -9,23 +9,34 @@
 
 namespace cnk {
 
-struct FrameArgs { const float* wav; const float* win; float* out; int n, samples, frames, hop, n_fft; };
+struct FrameArgs { const float* wav; const float* win; float* out; int n, samples, frames, hop, n_fft, framing; };
 
 __global__ __launch_bounds__(256) void stft_frames_kernel(const FrameArgs a) {
   const long long row = blockIdx.x;                       // i * frames + f
   const int i = (int)(row / a.frames), f = (int)(row - (long long)i * a.frames);
   const float* x = a.wav + (long long)i * a.samples;
-  const int s0 = f * a.hop - a.n_fft / 2;                 // center=True, pad_mode='constant'
-  for (int k = threadIdx.x; k < a.n_fft; k += blockDim.x) {
-    const int s = s0 + k;
-    a.out[row * a.n_fft + k] = (s >= 0 && s < a.samples) ? x[s] * a.win[k] : 0.f;
+  if (a.framing == 0) {
+    const int s0 = f * a.hop - a.n_fft / 2;               // center=True, pad_mode='constant'
+    for (int k = threadIdx.x; k < a.n_fft; k += blockDim.x) {
+      const int s = s0 + k;
+      a.out[row * a.n_fft + k] = (s >= 0 && s < a.samples) ? x[s] * a.win[k] : 0.f;
+    }
+  } else {
+    // F.pad(y, ((n_fft - hop) / 2,) * 2, mode='reflect') then torch.stft(center=False) (inference/Conan_previous.py:112-116)
+    const int s0 = f * a.hop - (a.n_fft - a.hop) / 2;
+    for (int k = threadIdx.x; k < a.n_fft; k += blockDim.x) {
+      int s = s0 + k;
+      if (s < 0) s = -s;
+      if (s >= a.samples) s = 2 * (a.samples - 1) - s;
+      a.out[row * a.n_fft + k] = x[s] * a.win[k];
+    }
   }
 }
 
 // |rfft| of the windowed frames: the DFT sums run in f64 (a 1024-term f32 sum loses the bins 5 decades below the frame
 // peak, which the log then magnifies; MI355X's f64 vector rate makes the exact sum free at this size: 1 MMAC per frame).
 // Block = 256 bins of one frame; the frame and the twiddle table tw[t] = (cos, sin)(2 pi t / N) sit in LDS as f64.
-struct DftArgs { const float* fr; const double2* tw; float* mag; int n_fft, nb, cmag; };
+struct DftArgs { const float* fr; const double2* tw; float* mag; int n_fft, nb, cmag; float mag_eps; };
 
 __global__ __launch_bounds__(256) void dft_mag_kernel(const DftArgs a) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
@@ -46,13 +57,13 @@ __global__ __launch_bounds__(256) void dft_mag_kernel(const DftArgs a) {
       re = fma(x[t], w.x, re); im = fma(x[t], w.y, im);
       idx = (idx + b) & mask;
     }
-    v = (float)sqrt(re * re + im * im);
+    v = (float)sqrt(re * re + im * im + (double)a.mag_eps);
   }
   a.mag[row * a.cmag + b] = v;
 }
 
 // mel = log10(max(eps, filterbank . |X|)) clipped; one thread per (frame, mel bin), f64 sum over the bins of its triangle
-struct MelArgs { const float* mag; const float* fb; const int* lo; const int* hi; float* y; long long rows; int nmel, cmag; float eps, vmin, vmax; };
+struct MelArgs { const float* mag; const float* fb; const int* lo; const int* hi; float* y; long long rows; int nmel, cmag; float eps, vmin, vmax; int natural_log; };
 
 __global__ __launch_bounds__(256) void mel_log_kernel(const MelArgs a) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,7 +74,8 @@ __global__ __launch_bounds__(256) void mel_log_kernel(const MelArgs a) {
   const float* w = a.fb + (long long)m * a.cmag;
   double s = 0.0;
   for (int b = a.lo[m]; b < a.hi[m]; ++b) s = fma((double)w[b], (double)mg[b], s);
-  const float v = log10f(fmaxf(a.eps, (float)s));
+  const float c = fmaxf(a.eps, (float)s);
+  const float v = a.natural_log ? logf(c) : log10f(c);
   a.y[e] = fminf(fmaxf(v, a.vmin), a.vmax);
 }
 
@@ -83,12 +95,21 @@ double mel_to_hz(double m) {
 
 }  // namespace
 
+int conan_mel_frames(const conan_mel_cfg& m, int samples) {
+  if (m.framing == 0) return 1 + samples / m.hop_size;
+  const int padded = samples + 2 * ((m.fft_size - m.hop_size) / 2);
+  return padded < m.fft_size ? 0 : (padded - m.fft_size) / m.hop_size + 1;
+}
+
 void conan_ctx::wav2mel(const conan_mel_cfg& m, const float* wav, int n, int samples, float* mel_out, hipStream_t st) {
   using ch::Error;
   if (m.fft_size < 64 || (m.fft_size & (m.fft_size - 1)) || m.fft_size > 2048 || m.hop_size < 1 || m.win_length < 1 || m.win_length > m.fft_size ||
       m.num_mels < 1 || m.num_mels > 512 || m.sample_rate < 1 || !(m.eps > 0.f))
     throw Error(CONAN_ERR_INVALID, "mel front-end configuration");
   if (n < 1 || samples < 1) throw Error(CONAN_ERR_INVALID, "wav2mel batch / samples");
+  if (m.framing < 0 || m.framing > 1 || !(m.mag_eps >= 0.f)) throw Error(CONAN_ERR_INVALID, "mel front-end framing / mag_eps");
+  // reflect padding needs pad < samples (torch raises otherwise); frames = (samples + 2 pad - n_fft) / hop + 1
+  if (m.framing == 1 && ((m.fft_size - m.hop_size) / 2 >= samples || m.hop_size > m.fft_size)) throw Error(CONAN_ERR_INVALID, "wav2mel: reflect padding longer than the signal");
   const int N = m.fft_size, NB = N / 2 + 1, CM = (NB + 3) & ~3;
   const double fmin = m.fmin < 0 ? 0.0 : m.fmin, fmax = m.fmax < 0 ? m.sample_rate / 2.0 : m.fmax;
   char key[160];
@@ -131,7 +152,8 @@ void conan_ctx::wav2mel(const conan_mel_cfg& m, const float* wav, int n, int sam
     vecs[k + ".fb"] = upload(B);
     vecs[k + ".range"] = upload(range);
   }
-  const int frames = 1 + samples / m.hop_size;
+  const int frames = conan_mel_frames(m, samples);
+  if (frames < 1) throw Error(CONAN_ERR_INVALID, "wav2mel: signal shorter than one frame");
   const long long rows = (long long)n * frames;
   if (rows > (1ll << 19)) throw Error(CONAN_ERR_INVALID, "wav2mel: more than 2^19 frames in one call");
   // workspace: frames [rows][N] | magnitude [rows][CM]
@@ -145,11 +167,11 @@ void conan_ctx::wav2mel(const conan_mel_cfg& m, const float* wav, int n, int sam
     fe_ws = dev_alloc(need, false); fe_ws_floats = need;
   }
   float* fr = fe_ws; float* mag = fr + (size_t)rows * N;
-  { cnk::FrameArgs a{wav, vec(k + ".win"), fr, n, samples, frames, m.hop_size, N}; hipLaunchKernelGGL(cnk::stft_frames_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
-  { cnk::DftArgs a{fr, reinterpret_cast<const double2*>(vec(k + ".tw")), mag, N, NB, CM};
+  { cnk::FrameArgs a{wav, vec(k + ".win"), fr, n, samples, frames, m.hop_size, N, m.framing}; hipLaunchKernelGGL(cnk::stft_frames_kernel, dim3((unsigned)rows), dim3(256), 0, st, a); }
+  { cnk::DftArgs a{fr, reinterpret_cast<const double2*>(vec(k + ".tw")), mag, N, NB, CM, m.mag_eps};
     hipLaunchKernelGGL(cnk::dft_mag_kernel, dim3((unsigned)rows, (unsigned)((CM + 255) / 256)), dim3(256), (size_t)N * 24, st, a); }
   { const float* rg = vec(k + ".range");
-    cnk::MelArgs a{mag, vec(k + ".fb"), reinterpret_cast<const int*>(rg), reinterpret_cast<const int*>(rg) + m.num_mels, mel_out, rows, m.num_mels, CM, m.eps, m.vmin, m.vmax};
+    cnk::MelArgs a{mag, vec(k + ".fb"), reinterpret_cast<const int*>(rg), reinterpret_cast<const int*>(rg) + m.num_mels, mel_out, rows, m.num_mels, CM, m.eps, m.vmin, m.vmax, m.natural_log};
     const long long total = rows * m.num_mels;
     hipLaunchKernelGGL(cnk::mel_log_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a); }
 }

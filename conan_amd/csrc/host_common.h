@@ -71,6 +71,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace ch
 
+int conan_mel_frames(const conan_mel_cfg& m, int samples);   // frontend.hip: frames conan_wav2mel writes per waveform
+
 struct conan_ctx {
   int device = 0;
   conan_cfg cfg;

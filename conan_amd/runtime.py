@@ -70,17 +70,25 @@ class Context:
         return self.lib.conan_ctx_weight_bytes(self.h)
 
     def wav2mel(self, wav, fft_size=1024, hop_size=320, win_length=1024, num_mels=80, fmin=80, fmax=7600, sample_rate=16000,
-                eps=1e-6, mel_vmin=-6.0, mel_vmax=1.5):
-        """Mel front-end on the GPU (conan_wav2mel): wav cuda float32 [n, samples] -> mel [n, 1 + samples // hop, num_mels]
-        = clip(librosa_wav2spec(wav)['mel'], mel_vmin, mel_vmax) of inference/Conan.py:57-70 (loud_norm off)."""
+                eps=1e-6, mel_vmin=-6.0, mel_vmax=1.5, framing=0, natural_log=False, mag_eps=0.0):
+        """Mel front-end on the GPU (conan_wav2mel): wav cuda float32 [n, samples] -> mel [n, frames, num_mels].
+        Defaults: clip(librosa_wav2spec(wav)['mel'], mel_vmin, mel_vmax) of inference/Conan.py:57-70 (loud_norm off),
+        frames = 1 + samples // hop.  framing=1, natural_log=True, mag_eps=1e-9: the torch.stft front-end of
+        inference/Conan_previous.py:100-121 (reflect padding, center=False), frames = samples // hop."""
         wav = wav.to(torch.device("cuda", self.device), torch.float32).contiguous()
         if wav.dim() == 1:
             wav = wav[None]
         n, samples = wav.shape
-        mc = _lib.MelCfg(fft_size, hop_size, win_length, num_mels, sample_rate, float(fmin), float(fmax), eps, mel_vmin, mel_vmax)
-        frames = 1 + samples // hop_size
+        mc = _lib.MelCfg(fft_size, hop_size, win_length, num_mels, sample_rate, float(fmin), float(fmax), eps, mel_vmin, mel_vmax,
+                         int(framing), int(bool(natural_log)), float(mag_eps))
+        if framing == 0:
+            frames = 1 + samples // hop_size
+        else:
+            frames = max(0, (samples + 2 * ((fft_size - hop_size) // 2) - fft_size) // hop_size + 1)
         mel = torch.empty(n, frames, num_mels, device=wav.device)
-        _lib.check(self.lib.conan_wav2mel(self.h, C.byref(mc), _ptr(wav), n, samples, _ptr(mel), None, _stream()))
+        got = C.c_int32(0)
+        _lib.check(self.lib.conan_wav2mel(self.h, C.byref(mc), _ptr(wav), n, samples, _ptr(mel), C.byref(got), _stream()))
+        assert got.value == frames
         return mel
 
     def streams(self, max_slots, max_frames=4, max_ref_frames=256):

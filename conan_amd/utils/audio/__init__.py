@@ -54,3 +54,19 @@ def librosa_wav2spec(wav_path, fft_size=1024, hop_size=256, win_length=1024, win
     l_pad, r_pad = librosa_pad_lr(wav, fft_size, hop_size, 1)
     wav = np.pad(wav, (l_pad, r_pad), mode="constant", constant_values=0.0)[:mel.shape[0] * hop_size]
     return {"wav": wav, "mel": mel, "wav_orig": wav_orig}
+
+
+def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False, ctx=None):
+    """The earlier loop's front-end (`mel_spectrogram` nested in inference/Conan_previous.py:100-121) on the HIP path:
+    reflect padding of (n_fft - hop_size) / 2 per side, torch.stft(center=False) with a periodic Hann window,
+    sqrt(re^2 + im^2 + 1e-9), librosa (Slaney) mel basis with fmax=None -> Nyquist, ln(clamp(., min=1e-5)).
+    y: [B, samples] tensor in [-1, 1] -> [B, num_mels, samples // hop_size] (the reference's layout)."""
+    if center:
+        raise NotImplementedError("the reference calls it with center=False only (inference/Conan_previous.py:133)")
+    if ctx is None:
+        raise ValueError("mel_spectrogram needs ctx= (a finalized conan_amd.runtime.Context): the transform runs on the GPU")
+    y = torch.as_tensor(y, dtype=torch.float32)
+    mel = ctx.wav2mel(y, fft_size=n_fft, hop_size=hop_size, win_length=win_size, num_mels=num_mels, fmin=fmin,
+                      fmax=-1 if fmax is None else fmax, sample_rate=sampling_rate, eps=1e-5, mel_vmin=-1e30, mel_vmax=1e30,
+                      framing=1, natural_log=True, mag_eps=1e-9)
+    return mel.transpose(1, 2)

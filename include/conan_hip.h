@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 3
+#define CONAN_HIP_ABI_VERSION 4
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -216,10 +216,17 @@ int conan_streams_output_fence(conan_streams* s, void* fence_stream);
  * StreamingVoiceConversion._wav_to_mel (utils/audio/__init__.py:37-84, inference/Conan.py:57-70), loud_norm off:
  * centred zero-padded STFT (periodic Hann) -> magnitude -> Slaney mel filterbank -> log10(max(eps, .)) -> clip.
  * wav_dev[n][samples] fp32 in [-1, 1]; mel_out_dev[n][frames][num_mels] with frames = 1 + samples / hop_size
- * (*frames_out, may be NULL).  fmin / fmax < 0 mean 0 / Nyquist.  Not re-entrant per context (shared workspace). */
+ * (*frames_out, may be NULL).  fmin / fmax < 0 mean 0 / Nyquist.  Not re-entrant per context (shared workspace).
+ * framing 1 / natural_log 1 / mag_eps 1e-9 select the earlier loop's front-end (inference/Conan_previous.py:100-121:
+ * reflect padding of (fft_size - hop_size) / 2 samples per side, torch.stft(center=False), sqrt(re^2 + im^2 + 1e-9),
+ * ln(max(eps, .)), frames = samples / hop_size; pass vmin / vmax = -/+ 1e30 for "no clip"). */
 typedef struct conan_mel_cfg {
   int32_t fft_size, hop_size, win_length, num_mels, sample_rate;
   float fmin, fmax, eps, vmin, vmax;
+  int32_t framing;      /* 0: centred frames, zero padding of fft_size / 2 (librosa.stft, pad_mode='constant');
+                           1: reflect padding of (fft_size - hop_size) / 2, frames start at the padded signal's first sample */
+  int32_t natural_log;  /* 0: log10, 1: ln */
+  float mag_eps;        /* added under the magnitude's square root (0 for librosa's |X|) */
 } conan_mel_cfg;
 int conan_wav2mel(conan_ctx* ctx, const conan_mel_cfg* cfg, const float* wav_dev, int n, int samples,
                   float* mel_out_dev, int32_t* frames_out, void* stream);

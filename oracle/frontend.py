@@ -84,3 +84,24 @@ def wav2mel(wav, **kw):
     mel = basis @ mag
     mel = np.log10(np.maximum(p["eps"], mel))
     return np.clip(mel.T, p["mel_vmin"], p["mel_vmax"]).astype(np.float32)
+
+
+def torch_mel_spectrogram(y, n_fft=1024, num_mels=80, sampling_rate=16000, hop_size=320, win_size=1024, fmin=80, fmax=None):
+    """`mel_spectrogram` of the earlier loop (inference/Conan_previous.py:100-121), center=False, restated in numpy:
+    reflect-pad (n_fft - hop) / 2 per side, frames from the padded signal's first sample, periodic Hann (torch.hann_window),
+    sqrt(re^2 + im^2 + 1e-9), librosa mel basis (fmax None -> sr / 2), ln(clamp(., min=1e-5)).  y [samples] -> [num_mels, frames].
+    PIN: the reference's function is torch.stft + F.pad, both in this image; tests/test_oracle_frontend.py compares."""
+    y = np.asarray(y, dtype=np.float32)
+    pad = int((n_fft - hop_size) / 2)
+    yp = np.pad(y, (pad, pad), mode="reflect")
+    win = scipy.signal.get_window("hann", win_size, fftbins=True)
+    if win_size < n_fft:
+        lp = (n_fft - win_size) // 2
+        win = np.pad(win, (lp, n_fft - win_size - lp))
+    n_frames = 1 + (len(yp) - n_fft) // hop_size
+    idx = np.arange(n_fft)[:, None] + hop_size * np.arange(n_frames)[None, :]
+    frames = yp[idx] * win[:, None].astype(np.float32)       # torch.stft multiplies input and window in float32
+    spec = np.fft.rfft(frames.astype(np.float64), axis=0)
+    mag = np.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9).astype(np.float32)
+    basis = mel_filterbank(sampling_rate, n_fft, num_mels, fmin, sampling_rate / 2 if fmax is None else fmax)
+    return np.log(np.maximum(basis @ mag, 1e-5)).astype(np.float32)

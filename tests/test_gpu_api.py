@@ -186,6 +186,17 @@ def test_wav2mel_frontend_matches_oracle():
     # silence -> floor; a second call with another length reuses the tables
     z = ctx.wav2mel(torch.zeros(1, 4000, device="cuda")).cpu().numpy()
     assert z.shape == (1, 13, 80) and np.all(z == -6.0)
+    # the earlier loop's front-end (inference/Conan_previous.py:100-121: reflect padding, torch.stft(center=False),
+    # sqrt(. + 1e-9), natural log with floor 1e-5) through the same kernels; ln magnifies by ln(10): 3e-5
+    from conan_amd.utils.audio import mel_spectrogram
+    got = mel_spectrogram(torch.from_numpy(wavs), 1024, 80, sr, 320, 1024, 80, None, center=False, ctx=ctx).cpu().numpy()
+    for i in range(n):
+        ref = ofe.torch_mel_spectrogram(wavs[i])
+        assert got[i].shape == ref.shape == (80, wavs.shape[1] // 320)
+        assert np.abs(got[i] - ref).max() < 3e-5, np.abs(got[i] - ref).max()
+    gt = mel_spectrogram(torch.from_numpy(tone[None]), 1024, 80, sr, 320, 1024, 80, None, ctx=ctx).cpu().numpy()[0]
+    rt2 = ofe.torch_mel_spectrogram(tone)
+    assert np.abs(rt2.min() - np.log(1e-5)) < 1e-6 and np.abs(gt - rt2).max() < 3e-5, np.abs(gt - rt2).max()
     ctx.close()
 
 

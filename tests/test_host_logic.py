@@ -24,6 +24,7 @@ def test_library_exports_every_declared_symbol():
 def test_cfg_struct_matches_header_and_hparams():
     cfg = _lib.make_cfg(configs.conan_hparams(), configs.hifigan_hparams())
     assert C.sizeof(cfg) == 4 * 81          # 81 int32 fields, include/conan_hip.h
+    assert C.sizeof(_lib.MelCfg) == 4 * 13  # conan_mel_cfg
     assert cfg.voc_upsample == 0 and cfg.voc_resblock == 1
     z = _lib.make_cfg(None, configs.HIFIGAN_ZERO_RB2, emformer=False, conan=False)
     assert z.voc_upsample == 1 and z.voc_resblock == 2 and z.voc_rb_num_dil == 2

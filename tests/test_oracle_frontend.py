@@ -89,3 +89,20 @@ def test_stft_pinned_against_torch_stft():
                    pad_mode="constant", return_complex=True).abs().numpy()
     mag = fe.stft_mag(wav, 1024, 320, 1024)
     assert S.shape == mag.shape and np.abs(S - mag).max() < 1e-6 * mag.max()
+
+
+def test_torch_stft_frontend_of_the_earlier_loop_pinned_against_torch():
+    """inference/Conan_previous.py:100-121 is torch.nn.functional.pad(reflect) + torch.stft(center=False) + a librosa mel
+    basis + log(clamp): the same torch calls, on the mel basis pinned above, are the independent implementation here."""
+    import torch
+    for wav in (_signal(), _signal(5, 0.4, 0)):
+        y = torch.from_numpy(wav)[None]
+        yp = torch.nn.functional.pad(y.unsqueeze(1), (int((1024 - 320) / 2), int((1024 - 320) / 2)), mode="reflect").squeeze(1)
+        spec = torch.view_as_real(torch.stft(yp, 1024, hop_length=320, win_length=1024, window=torch.hann_window(1024), center=False,
+                                             pad_mode="reflect", normalized=False, onesided=True, return_complex=True))
+        spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
+        basis = torch.from_numpy(fe.mel_filterbank(16000, 1024, 80, 80, 8000.0))
+        ref = torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))[0].numpy()
+        got = fe.torch_mel_spectrogram(wav)
+        assert got.shape == ref.shape == (80, len(wav) // 320)
+        assert np.abs(got - ref).max() < 2e-4, np.abs(got - ref).max()      # float32 FFT noise under a natural log
