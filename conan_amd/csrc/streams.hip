@@ -176,10 +176,19 @@ void conan_streams::async_init() {
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     const char* e = getenv("CONAN_FRONT_PRIO");
     const int mode = e ? atoi(e) : 0;
+    // CONAN_FRONT_CUSTRIDE / CONAN_EMF_CUSTRIDE = s: that stage's stream may only use CUs i with i % s == 0 (experiment knob)
+    auto masked = [&](hipStream_t* st, const char* env) {
+      const char* v = getenv(env);
+      const int stride = v ? atoi(v) : 0;
+      if (stride < 2) { HIP_CHECK(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return; }
+      std::vector<uint32_t> mask((ctx->num_cu + 31) / 32, 0u);
+      for (int i = 0; i < ctx->num_cu; i += stride) mask[i / 32] |= 1u << (i % 32);
+      HIP_CHECK(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+    };
     if (mode == 0) {
-      HIP_CHECK(hipStreamCreateWithFlags(&st_front, hipStreamNonBlocking));
+      masked(&st_front, "CONAN_FRONT_CUSTRIDE");
       HIP_CHECK(hipStreamCreateWithFlags(&st_voc, hipStreamNonBlocking));
-      HIP_CHECK(hipStreamCreateWithFlags(&st_emf, hipStreamNonBlocking));
+      masked(&st_emf, "CONAN_EMF_CUSTRIDE");
     } else {
       HIP_CHECK(hipStreamCreateWithPriority(&st_emf, hipStreamNonBlocking, mode > 0 ? hi : lo));
       HIP_CHECK(hipStreamCreateWithPriority(&st_front, hipStreamNonBlocking, mode > 0 ? hi : lo));
