@@ -362,7 +362,7 @@ def main():
             fe = {"workload": f"conan_wav2mel, {B} x 3 s @16 kHz -> [{B},151,80]", "ms": fe_ms, "frames_per_s": B * 151 / (fe_ms * 1e-3)}
         except Exception as e:  # noqa: BLE001  (a front-end failure must not hide the headline measurement)
             fe = {"error": str(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # a reported baseline of the N = 1 line only
             cpu = cpu_baseline()
 
     if world > 1:
