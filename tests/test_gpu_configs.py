@@ -195,6 +195,13 @@ def test_transposed_conv_upsampler_whole_forward(tag, vhp):
     np.testing.assert_allclose(y[0, 0].cpu().numpy(), g["wav_40"], atol=1e-4, rtol=0)
     y = gen(torch.from_numpy(g["mel_12"]).cuda())                                    # resets between forwards
     np.testing.assert_allclose(y[0, 0].cpu().numpy(), g["wav_12"], atol=1e-4, rtol=0)
+    if tag == "nn_tiny":       # a 3 s utterance (rings regrown to 150 frames = 48 000 rows in the last stage) against the oracle
+        from oracle import hifigan as ohifi
+        from oracle.common import to_torch_sd
+        mel = torch.from_numpy(synth.mel(150, 77, 2)).transpose(1, 2).contiguous()   # [2, 80, 150]
+        ref = ohifi.generator_forward(to_torch_sd(synth.hifigan_state_dict(vhp, 0)), vhp, mel)[:, 0].numpy()
+        y = gen(mel.cuda())
+        np.testing.assert_allclose(y[:, 0].cpu().numpy(), ref, atol=1e-4, rtol=0)
 
 
 def test_emformer_mode_both_uses_proj1():
