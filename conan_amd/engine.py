@@ -207,6 +207,8 @@ class StreamingVoiceConversionEngine:
         The whole source is available here, so by default the chunks are issued as pipelined steps
         (conan_step_async): the Emformer + decoder of chunk t+1 overlap the vocoder of chunk t.  The
         results are bit-identical to the blocking loop (pipelined=False)."""
+        if self.ctx.cfg.voc_upsample == 2:
+            return self._infer_prefix_vocoder(src_mel, ref_mel, ref_len)
         self.start(ref_mel, ref_len)
         B = src_mel.shape[0]
         hop, nm = self.ctx.hop, self.ctx.cfg.num_mels
@@ -224,4 +226,28 @@ class StreamingVoiceConversionEngine:
             codes.append(c[:, :emit])
         if pipelined:
             self.st.join()
+        return torch.cat(wavs, 1), torch.cat(mels, 1), torch.cat(codes, 1)
+
+    @torch.no_grad()
+    def _infer_prefix_vocoder(self, src_mel, ref_mel, ref_len=None):
+        """Vocoders that look ahead (`upsample: nn`, CausalUpsampleBlock1) cannot carry state from chunk to chunk; the
+        reference loop does not need them to: it runs the vocoder on ALL mel frames so far and keeps the samples of the
+        current chunk (inference/Conan.py:147-155).  Same here: Emformer and decoder step statefully, the vocoder is reset
+        and run over the prefix (O(T^2) like the reference; rings sized for the whole utterance)."""
+        B, T, _ = src_mel.shape
+        if self.st.max_frames < T:
+            mr = self.st.max_ref_frames
+            self.st.close()
+            self.st = self.ctx.streams(self.n, max_frames=T, max_ref_frames=mr)
+        self.start(ref_mel, ref_len)
+        hop = self.ctx.hop
+        wavs, mels, codes = [], [], []
+        for pos, emit, chunk in self.chunks(src_mel):
+            _, _, c = self.st.emformer_step(self.slots, chunk, want_out=False, want_logits=False)
+            m = self.st.decoder_step(self.slots, c[:, :emit].contiguous())
+            mels.append(m)
+            codes.append(c[:, :emit])
+            self.st.reset(self.slots, which=4)
+            w = self.st.hifigan_step(self.slots, torch.cat(mels, 1))
+            wavs.append(w[:, pos * hop:(pos + emit) * hop])
         return torch.cat(wavs, 1), torch.cat(mels, 1), torch.cat(codes, 1)

@@ -89,6 +89,28 @@ def test_streaming_voice_conversion_infer_once():
         StreamingVoiceConversion(dict(chp, vocoder="Nope"), vhp, sds)
 
 
+def test_streaming_voice_conversion_with_lookahead_vocoder():
+    """A vocoder config whose upsampler looks ahead (`upsample: nn`) through StreamingVoiceConversion: like the reference
+    loop (inference/Conan.py:147-155) the vocoder runs on all mel frames so far and the current chunk's samples are kept,
+    so each chunk's tail lacks its look-ahead exactly as in the reference - against the reference-semantics oracle loop."""
+    from conan_amd.inference.Conan import StreamingVoiceConversion
+    from oracle import emformer as oemf
+    from oracle import loop as oloop
+    from oracle.common import to_torch_sd
+    chp, vhp = configs.conan_hparams(True), dict(configs.HIFIGAN_NN_TINY)
+    sds = {"emformer": synth.emformer_state_dict(chp, 0), "conan": synth.conan_state_dict(chp, 0), "hifigan": synth.hifigan_state_dict(vhp, 0)}
+    eng = StreamingVoiceConversion(chp, vhp, sds)
+    src, ref = synth.mel(23, 1234)[0], synth.mel(40, 4321)[0]
+    wav, mel = eng.infer_once({"src_mel": src, "ref_mel": ref})
+    t = {k: to_torch_sd(v) for k, v in sds.items()}
+    w_ref, m_ref, _ = oloop.infer_once_ref(t["emformer"], oemf.EmformerCfg(chp), t["conan"], chp, t["hifigan"], vhp, src, ref)
+    assert wav.shape == (23 * 320,) and mel.shape == (23, 80)
+    np.testing.assert_allclose(mel, m_ref, atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(wav, w_ref, atol=1e-4, rtol=0)
+    wav2, _ = eng.infer_once({"src_mel": src[:9], "ref_mel": ref})        # a second, shorter utterance on the same engine
+    np.testing.assert_allclose(wav2[:4 * 320], wav[:4 * 320], atol=1e-6, rtol=0)
+
+
 def test_error_conventions_through_the_c_abi():
     from conan_amd import _lib
     from conan_amd.runtime import Context
