@@ -300,6 +300,8 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
     if (!s || !slots || !mel_chunk_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     const int all = CONAN_MODEL_EMFORMER | CONAN_MODEL_CONAN | CONAN_MODEL_HIFIGAN;
     if ((s->ctx->cfg.models & all) != all) throw Error(CONAN_ERR_STATE, "conan_step needs all three models in the context");
+    if (s->ctx->cfg.voc_upsample == 2) throw Error(CONAN_ERR_UNSUPPORTED, "fused chunk steps carry vocoder state from chunk to chunk; upsample 'nn' (CausalUpsampleBlock1) looks ahead: "
+                                                                        "step the Emformer and decoder per chunk and run conan_hifigan_step over the mel prefix after a reset (inference/Conan.py:147-155)");
     const int seg = s->ctx->cfg.emf_segment;
     if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
     hipStream_t st = (hipStream_t)stream;
@@ -330,6 +332,8 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     if (!s || !slots || !mel_chunk_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     const int all = CONAN_MODEL_EMFORMER | CONAN_MODEL_CONAN | CONAN_MODEL_HIFIGAN;
     if ((s->ctx->cfg.models & all) != all) throw Error(CONAN_ERR_STATE, "conan_step_async needs all three models in the context");
+    if (s->ctx->cfg.voc_upsample == 2) throw Error(CONAN_ERR_UNSUPPORTED, "fused chunk steps carry vocoder state from chunk to chunk; upsample 'nn' (CausalUpsampleBlock1) looks ahead: "
+                                                                        "step the Emformer and decoder per chunk and run conan_hifigan_step over the mel prefix after a reset (inference/Conan.py:147-155)");
     const int seg = s->ctx->cfg.emf_segment;
     if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
     if (s->prof_on) throw Error(CONAN_ERR_STATE, "profiling is not available for pipelined steps");

@@ -109,6 +109,14 @@ def test_streaming_voice_conversion_with_lookahead_vocoder():
     np.testing.assert_allclose(wav, w_ref, atol=1e-4, rtol=0)
     wav2, _ = eng.infer_once({"src_mel": src[:9], "ref_mel": ref})        # a second, shorter utterance on the same engine
     np.testing.assert_allclose(wav2[:4 * 320], wav[:4 * 320], atol=1e-6, rtol=0)
+    # the fused chunk steps carry vocoder state from chunk to chunk: refused for this vocoder before anything is enqueued
+    from conan_amd import _lib
+    st = eng.engine.st
+    chunk = torch.from_numpy(src[None, :6]).cuda()
+    for call in (lambda: st.step([0], chunk), lambda: st.step_async([0], chunk, torch.empty(1, 4 * 320, device="cuda"))):
+        with pytest.raises(_lib.ConanError) as ei:
+            call()
+        assert ei.value.code == _lib.ERR_UNSUPPORTED
 
 
 def test_error_conventions_through_the_c_abi():
