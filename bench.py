@@ -29,6 +29,8 @@ if REPO not in sys.path:
 # measured 2.59 instead of 1.85 ms per step.  Has to be set before the HIP runtime initialises (conan_amd/__init__.py does
 # the same for callers that import the package first).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
