@@ -366,7 +366,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
     }
   }
 
-  // ---- inter-block split-K hand-off (MI355X: per-XCD L2s are not coherent -> agent-scope release / acquire)
+  // ---- inter-block split-K hand-off.  MI355X: per-XCD L2s are not coherent; the partial tiles travel as agent-scope
+  // write-through stores / sc1 loads (relaxed atomics), ordered by s_waitcnt + the ticket - no release / acquire fence,
+  // i.e. no write-back and invalidate of the whole L2 per tile (same scheme as the fused Emformer's cluster exchange).
   if (SK && nslices > 1) {
     constexpr int PER_WAVE = RM * RN * 16 * 64;
     constexpr int PER_TILE = WM * WN * PER_WAVE;
@@ -376,19 +378,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) mine[((rm * RN + rn) * 16 + e) * 64 + lane] = acc[rm][rn][e];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores
+        for (int e = 0; e < 16; ++e)
+          __hip_atomic_store(mine + ((rm * RN + rn) * 16 + e) * 64 + lane, acc[rm][rn][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its (write-through) stores
     block_barrier();                                       // X1
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == nslices - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
-      }
+      if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
       *sflag = last;
     }
     block_barrier();                                       // X2
@@ -407,7 +404,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #pragma unroll
         for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[rm][rn][e] += src[((rm * RN + rn) * 16 + e) * 64 + lane];
+          for (int e = 0; e < 16; ++e)
+            acc[rm][rn][e] += __hip_atomic_load(src + ((rm * RN + rn) * 16 + e) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
