@@ -79,8 +79,9 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     if (S > nks / 2) S = nks / 2;
     if (S > 16) S = 16;
     while (S > 1 && tiles * S * TM * TN > sk_slab_floats) --S;
-    // the hand-off (partial-tile stores, agent-scope release/acquire, ticket) costs about as much as ~6 K-steps of 32
-    // channels: split only when it removes clearly more than that from the critical path
+    // the hand-off (write-through partial-tile stores, ticket, sc1 loads) is not free - with fences it cost about 6 K-steps
+    // of 32 channels -: split only when it removes clearly more than that from the critical path (thresholds of 2 .. 12
+    // measure the same at one and four streams)
     static const int min_saved = getenv("CONAN_SK_MIN") ? atoi(getenv("CONAN_SK_MIN")) : 12;
     if (S >= 2 && tiles <= sk_max_tiles && (nks - nks / S) * (KS / 32) >= min_saved) g.ksplit = S;
   }
