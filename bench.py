@@ -169,14 +169,29 @@ def cpu_baseline():
     return out
 
 
+def lib_sha256():
+    """sha256 of the libconan_hip.so this process loaded (ties committed profiler summaries to a binary)."""
+    import hashlib
+    from conan_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def pmc_summary(tag):
     """The committed summary of the separate rocprofv3 --pmc passes for this workload (PMC counters cannot be collected
-    from inside the benchmark): profiles/r2_<tag>_pmc.json, made by tools/collect_profiles.sh + tools/summarize_pmc.py."""
-    path = os.path.join(REPO, "profiles", f"r2_{tag}_pmc.json")
-    try:
-        return json.load(open(path)), f"profiles/r2_{tag}_pmc.json"
-    except (OSError, ValueError):
-        return None, None
+    from inside the benchmark): profiles/r<round>_<tag>_pmc.json, made by tools/collect_profiles.sh + tools/summarize_pmc.py
+    (newest round first).  The summary records the sha256 of the library it was collected with; `stale` says whether that
+    differs from the library loaded now (a summary without a hash counts as stale)."""
+    for rnd in ("r3", "r2"):
+        path = os.path.join(REPO, "profiles", f"{rnd}_{tag}_pmc.json")
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        return d, f"profiles/{rnd}_{tag}_pmc.json", d.get("lib_sha256") != lib_sha256()
+    return None, None, None
 
 
 def main():
@@ -259,11 +274,61 @@ def main():
     if args.marks:
         eng.st.profile_mark()
         torch.cuda.synchronize()
+    # Every rank's own clock, its device, and a check of the exchange: the audio rank 0 gathered for the LAST timed step must
+    # be, bit for bit, what each rank produced for it (one all_gather of integer checksums, outside the timed region).
+    dt_local = dt
+    ranks = None
+    last = ring.bufs[(j - 1) % ring.nb]
+    csum = last.view(torch.int32).to(torch.int64).sum().reshape(1)            # order-independent, exact
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt_local, float(torch.cuda.current_device())], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        sums = [torch.zeros_like(csum) for _ in range(world)]
+        dist.all_gather(sums, csum)
+        dt = max(float(r[0].item()) for r in allr)                              # MAX over ranks = the job's time
+        if rank == 0:
+            got = [int(g.view(torch.int32).to(torch.int64).sum().item()) for g in ring.gbufs]
+            want = [int(x.item()) for x in sums]
+            ranks = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
+                     "devices": [int(r[1].item()) for r in allr], "device_name": torch.cuda.get_device_name(),
+                     "ms_per_step_per_rank": [float(r[0].item()) / args.steps * 1e3 for r in allr],
+                     "ms_per_step_min": min(float(r[0].item()) for r in allr) / args.steps * 1e3,
+                     "ms_per_step_max": max(float(r[0].item()) for r in allr) / args.steps * 1e3,
+                     "gather_check": {"step": j - 1, "ok": got == want, "checksums_rank0_gathered": got, "checksums_ranks_own": want}}
+            if got != want:
+                raise SystemExit("bench.py: the audio gathered on rank 0 differs from what the ranks produced: %r vs %r" % (got, want))
+    else:
+        ranks = {"rccl_world": 1, "backend": None, "devices": [torch.cuda.current_device()], "device_name": torch.cuda.get_device_name(),
+                 "ms_per_step_per_rank": [dt / args.steps * 1e3], "ms_per_step_min": dt / args.steps * 1e3, "ms_per_step_max": dt / args.steps * 1e3,
+                 "gather_check": ({"step": j - 1, "ok": True, "note": "single rank: the gather path (CONAN_BENCH_COMM=1) hands rank 0 its own buffer",
+                                   "checksums_ranks_own": [int(csum.item())]} if ring.active else None)}
     ms_step = dt / args.steps * 1e3
+
+    # Distribution of the step time (outside the timed region): one HIP event per step, recorded on a side stream behind a
+    # join of the library's internal streams (a join on the caller's stream would hold back the next step's front-end and
+    # drain the pipeline), intervals between consecutive events.
+    step_stats = None
+    if not args.marks:
+        side = torch.cuda.Stream()
+        evs = []
+        for _ in range(min(args.steps, 40) + 1):
+            step(j); j += 1
+            with torch.cuda.stream(side):
+                if not window:
+                    eng.st.join()
+                else:
+                    side.wait_stream(torch.cuda.current_stream())
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(side)
+                evs.append(e)
+        barrier()
+        side.synchronize()
+        iv = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+        if iv:
+            step_stats = {"n": len(iv), "mean_ms": statistics.fmean(iv), "sigma_ms": statistics.pstdev(iv), "p50_ms": statistics.median(iv),
+                          "p95_ms": iv[min(len(iv) - 1, int(round(0.95 * (len(iv) - 1))))], "min_ms": iv[0], "max_ms": iv[-1],
+                          "how": "intervals between per-step completion events on a side stream, a separate run of steps after the timed region"}
     frames_per_step = (window + seg) if window else seg           # decoder / vocoder frames computed per stream per step
 
     def one_blocking_step(e, ch, c_, m_, w_, h_):
@@ -274,7 +339,7 @@ def main():
             e.st.step(e.slots, ch, emit=seg, codes=c_, mel_out=m_, wav_out=w_)
 
     roof = b1 = cpu = fe = None
-    p50 = None
+    p50 = lat_stats = None
     if not args.marks:
         # per-chunk latency: one step for all B streams, host submit -> audio complete on device
         lats = []
@@ -285,6 +350,8 @@ def main():
             torch.cuda.synchronize()
             lats.append((time.perf_counter() - a) * 1e3)
         p50 = statistics.median(lats)
+        lat_stats = {"n": len(lats), "p50_ms": p50, "p95_ms": sorted(lats)[min(len(lats) - 1, int(round(0.95 * (len(lats) - 1))))],
+                     "sigma_ms": statistics.pstdev(lats), "min_ms": min(lats), "max_ms": max(lats)}
 
     if rank == 0 and not args.marks:
         # roofline of the dominant kernel: HIP events around every launch of the matrix kernels on their stream
@@ -306,7 +373,7 @@ def main():
         name, (k_ms, k_fl, k_n, insts) = max(fams.items(), key=lambda kv: kv[1][0])
         ach = k_fl / (k_ms * 1e-3) / 1e12
         fam = conv_flops / (conv_ms * 1e-3) / 1e12
-        pmc, pmc_src = pmc_summary(args.workload)
+        pmc, pmc_src, pmc_stale = pmc_summary(args.workload)
         traffic = step_bytes = mfma_busy = None
         if pmc:
             hit = [v for k, v in pmc.get("kernels", {}).items() if name in k]
@@ -320,6 +387,7 @@ def main():
         bytes_alg = WEIGHT_BYTES_PER_STEP + B * STATE_BYTES_PER_STREAM * (frames_per_step / seg)
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+                "traffic_stale": pmc_stale if traffic is not None else None, "lib_sha256": lib_sha256(),
                 "mfma_busy_frac_pmc": mfma_busy,
                 "kernel": name, "instantiations": insts, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
                 "largest_instantiation": {"kernel": kernels[0][0], "ms_per_step": kernels[0][1] / nprof, "tflops": kernels[0][2] / (kernels[0][1] * 1e-3) / 1e12},
@@ -381,7 +449,7 @@ def main():
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
                        "architecture": "egs/conan_emformer.yaml + egs/hifi_16k320_shuffle.yaml shapes, random-init weights",
                        "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1"},
-            "p50_latency_ms": p50,
+            "p50_latency_ms": p50, "latency_stats": lat_stats, "step_time_stats": step_stats, "ranks": ranks,
             "schedule": ("throughput and latency: one blocking windowed step" if window else
                          "throughput: pipelined steps (front-end of chunk t+1 overlaps the vocoder of chunk t on two HIP streams); latency: one blocking fused step"),
             "realtime_streams_supported": (total_chunks / dt) / (1000.0 / wl["chunk_ms"]),

@@ -130,6 +130,7 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
       s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
+      { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
@@ -190,6 +191,32 @@ int conan_emformer_step(conan_streams* s, const int32_t* slots, int n, const flo
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->emformer_step(n, chunk_dev, out_dev, logits_dev, codes_dev, (hipStream_t)stream);
+  });
+}
+
+int conan_emformer_head_dim(conan_streams* s, const char* head) {
+  int k = 0;
+  const int rc = guarded([&] {
+    if (!s || !head) throw Error(CONAN_ERR_INVALID, "null argument");
+    auto it = s->ctx->convs.find(std::string("emf.head.") + head);
+    k = it == s->ctx->convs.end() ? 0 : it->second.Cout;
+  });
+  return rc < 0 ? rc : k;
+}
+
+int conan_emformer_project(conan_streams* s, const char* head, const float* x_dev, int rows, float* y_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !head || !x_dev || !y_dev) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (!(s->ctx->cfg.models & CONAN_MODEL_EMFORMER)) throw Error(CONAN_ERR_STATE, "context holds no Emformer model");
+    if (rows <= 0) return;
+    const std::string name = std::string("emf.head.") + head;
+    if (!s->ctx->convs.count(name)) throw Error(CONAN_ERR_MISSING, std::string("the Emformer checkpoint holds no output head '") + head + "'");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    s->join(st);
+    const ch::PackedConv& pc = s->ctx->conv(name);
+    // a Linear is a k = 1 conv over one "slot" of `rows` rows (conv_mfma; no ring, no slot table)
+    s->conv(s->mk(pc, ch::lin_ref(const_cast<float*>(x_dev), rows, pc.Cin), ch::lin_ref(y_dev, rows, pc.Cout), 1, rows, nullptr), st);
   });
 }
 

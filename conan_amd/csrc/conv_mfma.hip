@@ -71,7 +71,7 @@ struct ConvLds {
 // loads while the matrix waves are still in the previous tile's epilogue.
 template <int TM, int TN, int WM, int WN, int WK, int KS>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const int n0, float* lds, int& gbuf, const int tile,
-                                          const int kslice, const int nslices, float* slab, int* counter) {
+                                          const int kslice, const int nslices, float* slab, int* counter, const int fenced) {
   static_assert(WM * WN * WK == 4, "4 compute waves per block");
   static_assert(KS == 32 || KS == 64 || KS == 128, "K-step");
   constexpr int RM = TM / WM / 32;
@@ -381,6 +381,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
         for (int e = 0; e < 16; ++e)
           __hip_atomic_store(mine + ((rm * RN + rn) * 16 + e) * 64 + lane, acc[rm][rn][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its (write-through) stores
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     block_barrier();                                       // X1
     if (tid == 0) {
       const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -390,6 +391,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
     }
     block_barrier();                                       // X2
     if (*sflag == 0) return;
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // reducer: sum the partial tiles in slice order (own slice from memory too: identical bits, fixed order)
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS>::TOTAL * 4 > 80 * 102
     const int tn = g.tiles_n[p];
     const int mt = local / tn, nt = local - mt * tn;
     conv_tile<TM, TN, WM, WN, WK, KS>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, S,
-                                            g.slab + (long long)tile * S * (TM * TN), g.counters + tile);
+                                            g.slab + (long long)tile * S * (TM * TN), g.counters + tile, g.fenced);
     ++i;
     cur = assign ? (i < g.assign_per ? assign[i] : -1) : cur + (int)gridDim.x;
   }

@@ -88,7 +88,9 @@ void conan_ctx::add_rowconv_weights(const std::string& name, const std::vector<f
   const int KQ = Cin / 16;
   if (KQ & (KQ - 1)) return;
   const int cpad = ch::round_up(Cout, Cout >= 1024 ? 256 : 64), NCT = cpad / 16;
-  std::vector<float> out((size_t)NCT * (k + 1) * KQ * 256, 0.f);
+  // (the kernels' weight rings run up to 8 groups ahead of the group they consume: a column tile's zero tap covers that
+  // where KQ >= 8; the 8 zero groups behind the LAST column tile keep narrower layers - Cin = 64: KQ = 4 - in bounds too)
+  std::vector<float> out((size_t)NCT * (k + 1) * KQ * 256 + 8 * 256, 0.f);
   for (int ct = 0; ct < NCT; ++ct)
     for (int j = 0; j < k; ++j)
       for (int q = 0; q < KQ; ++q)
@@ -298,6 +300,13 @@ void conan_ctx::finalize_emformer() {
     if (get(pj + ".weight").shape.size() != 2 || get(pj + ".weight").shape[0] != c.emf_output_dim)
       throw Error(CONAN_ERR_SHAPE, "Emformer projection rows != emf_output_dim: " + pj);
     pack_from_keys("emf.proj", pj + ".weight", pj + ".bias");
+  }
+  // every output head the checkpoint carries, by name, for conan_emformer_project (EmformerDistillModel.inference projects
+  // the concatenated features, modules/Emformer/emformer.py:95-97)
+  for (const char* h : {"proj", "proj1", "proj2"}) {
+    const std::string k = std::string("emformer.") + h;
+    if (has(k + ".weight") && get(k + ".weight").shape.size() == 2 && get(k + ".weight").shape[1] == c.emf_input_dim)
+      pack_from_keys(std::string("emf.head.") + h, k + ".weight", k + ".bias");
   }
   // Second copy of the Linear weights for the fused step (emformer_fused.hip), fragment-major: fragment (ntile, kq)
   // is the 64-lane x float4 MFMA B operand {W[ntile*16 + (lane&15)][kq*16 + (lane>>4)*4 + e]} stored as 1 KiB, and

@@ -504,12 +504,14 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's partial-sum stores are complete ...
+      if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       ef_barrier();
       if (tid == 0) __hip_atomic_store(fl + member, xtarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag goes out
       if (tid < cs) {
         while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xtarget) __builtin_amdgcn_s_sleep(2);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       ef_barrier();
       float pv[EMF_MAX_CLUSTER][XE];
 #pragma unroll

@@ -74,6 +74,9 @@ struct ConvGroup {      // up to 3 independent problems in one launch
   const int* assign;
   int assign_per;
   int ksplit;
+  // 1: the split-K hand-off is additionally bracketed by agent-scope release / acquire fences (CONAN_FENCED=1, a
+  // developer cross-check of the fence-free default: write-through stores, ticket, sc1 loads)
+  int fenced;
 };
 
 // Tile configurations of conv_mfma (block = 256 threads = 4 waves).
@@ -238,6 +241,7 @@ struct EmfFusedArgs {
   float* xch;             // [cluster][2][EMF_MAX_CLUSTER][16][D] partial sums (layer parity double buffer)
   unsigned* xflag;        // [cluster][EMF_MAX_LAYERS][EMF_MAX_CLUSTER] "partial of this launch is written" (= epoch + 1)
   unsigned* xepoch;       // [cluster] launches this cluster has taken part in
+  int fenced;             // 1: release / acquire fences around the exchange as well (CONAN_FENCED=1 cross-check)
 };
 constexpr int EMF_MAX_CLUSTER = 8;
 // floats of xch / words of xflag+xepoch for up to `max_groups` stream groups
@@ -281,7 +285,8 @@ struct MeanActArgs { TRef x[3]; TRef y; const int* slots; const int* pos; int ns
 void launch_mean_act(const MeanActArgs& a, hipStream_t st);
 // conv_post (CausalConv1d(C -> 1, k) + tanh, hifigan_causal.py:331-333) as a VALU dot-product kernel: N = 1 would
 // waste 31/32 of an MFMA tile.  x[0] is the already activated input ring (nsrc = 1); w is [k][C]; optional pre-tanh tap.
-// nsrc > 1: x[] are the RAW outputs of the last stage's branches and the kernel forms leaky_relu(mean) itself (the same
+// xmean.base != nullptr: x[0 .. nsrc) are the RAW outputs of the last stage's branches (nsrc may be 1: a single-branch
+// vocoder still needs its LeakyReLU in front of conv_post) and the kernel forms leaky_relu(mean) itself (the same
 // operations in the same order as mean_act_kernel), so the stage's own mean_act launch disappears; rows of earlier steps
 // (the k - 1 rows of left context) come from `xmean`, the activated-mean ring, to which the kernel also appends the rows
 // it formed - the ring stays valid whichever way a step produced it (merged fused launch, or here).

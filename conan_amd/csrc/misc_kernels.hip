@@ -454,17 +454,22 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
   float* sw = cps + rows * ld;
   for (int e = threadIdx.x; e < a.k * a.C; e += blockDim.x) sw[e] = a.w[e];
   const int c4n = a.C >> 2;
+  // x[] are raw branch outputs (also for a single-branch vocoder: the LeakyReLU in front of conv_post is then applied
+  // here) exactly when the caller passes the activated-mean ring
+  const bool form = a.xmean.base != nullptr;
   for (int e = threadIdx.x; e < rows * c4n; e += blockDim.x) {
     const int r = e / c4n, c4 = e - r * c4n;
     const int t = t0 + r - (a.k - 1);            // may be negative: ring history (zeros before stream start)
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t < a.T && a.nsrc > 1 && t < 0) {
+    if (t < a.T && form && t < 0) {
       v = *reinterpret_cast<const float4*>(trowptr(a.xmean, i, slot, a.pos, t) + c4 * 4);       // earlier steps: the activated mean as stored
     } else if (t < a.T) {
       v = *reinterpret_cast<const float4*>(trowptr(a.x[0], i, slot, a.pos, t) + c4 * 4);
-      if (a.nsrc > 1) {        // leaky_relu(mean of the branches): mean_act_kernel's arithmetic, operation for operation
-        const float4 v1 = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
-        v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+      if (form) {        // leaky_relu(mean of the branches): mean_act_kernel's arithmetic, operation for operation
+        if (a.nsrc > 1) {
+          const float4 v1 = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
+          v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+        }
         if (a.nsrc > 2) {
           const float4 v2 = *reinterpret_cast<const float4*>(trowptr(a.x[2], i, slot, a.pos, t) + c4 * 4);
           v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;

@@ -63,7 +63,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
   const int wsi = ws_index(st);
-  g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1;
+  g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1; g.fenced = fenced ? 1 : 0;
   if (cnk::conv_cfg_tm(cfg) == 32) {
     // (grouped launches: one split factor for all problems, sized by the longest K loop)
     const int TM = cnk::conv_cfg_tm(cfg), TN = cnk::conv_cfg_tn(cfg);
@@ -451,15 +451,21 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
   const int D = c.emf_input_dim, R = c.emf_right_context, U = c.emf_segment, Q = R + U;
   if (emf_fused) {   // whole step in one launch (emformer_fused.hip)
     cnk::EmfFusedArgs a = emf_fused_args;
-    a.chunk = chunk; a.out = out; a.logits = logits; a.codes = codes; a.n = n;
+    a.chunk = chunk; a.out = out; a.logits = logits; a.codes = codes; a.n = n; a.fenced = fenced ? 1 : 0;
     // Workgroups per stream group: the step is a chain of latency-bound phases on one 16-row tile, so a few streams are
     // spread over up to 8 CUs each (feed-forward hidden units split 8 ways, one exchange per layer); with many streams
     // the groups themselves fill the CUs and the split only has to keep the launch short beside the vocoder.
-    if (emf_cluster > 0) a.cs = emf_cluster;
-    else {
+    {
       const int groups = (n + cnk::emformer_fused_streams_per_block(a) - 1) / cnk::emformer_fused_streams_per_block(a);
-      a.cs = cnk::EMF_MAX_CLUSTER;
-      while (a.cs > 1 && groups * a.cs > 128) a.cs >>= 1;     // (B = 64: 128 workgroups, 147 us alone; 256 cost the vocoder 6 %)
+      // The members of a cluster spin on each other's flags: every workgroup of the launch must be able to be resident at
+      // once (one 129 KB workgroup per CU).  The developer override is clamped to that like the automatic choice, and a
+      // CU-masked Emformer stream (CONAN_EMF_CUSTRIDE) gets no clusters at all.
+      static const bool masked = getenv("CONAN_EMF_CUSTRIDE") != nullptr && atoi(getenv("CONAN_EMF_CUSTRIDE")) >= 2;
+      const int cap = emf_cluster > 0 ? ctx->num_cu : 128;   // (B = 64: 128 workgroups, 147 us alone; 256 cost the vocoder 6 %)
+      a.cs = emf_cluster > 0 ? std::min(emf_cluster, (int)cnk::EMF_MAX_CLUSTER) : cnk::EMF_MAX_CLUSTER;
+      while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two
+      while (a.cs > 1 && groups * a.cs > cap) a.cs >>= 1;
+      if (masked && st == st_emf) a.cs = 1;
     }
     // algorithmic FLOPs of the step: per stream and layer Q = R + U query rows against the four D x D projections, the
     // D x F x 2 feed-forward, and attention over R + LC + U keys; plus the output projection

@@ -17,23 +17,23 @@ class EmformerState:
         self.streams, self.slots = streams, slots
 
 
-def _linear(m, x):
-    return torch.nn.functional.linear(x, m.weight.to(x.device), m.bias.to(x.device))
-
-
 class _Proj:
-    """`.proj` of EmformerDistillModel (emformer.py:25).  The projection runs inside conan_emformer_step: applied to
-    the very tensor infer() just returned (inference/Conan.py:115-120) it hands back those logits; any other input
-    (a slice, a concatenation of chunks) is projected with the module's own weight on the device."""
+    """An output head of EmformerDistillModel (emformer.py:25 `proj`, :29-30 `proj1` / `proj2`).  The streaming step
+    (conan_emformer_step) already projects with `proj` / `proj1`: applied to the very tensor infer() just returned
+    (inference/Conan.py:115-120) the head hands back those logits.  Any other input (a slice, the concatenated chunks of
+    `inference()`, or the second head) goes through conan_emformer_project - a k = 1 conv on the same MFMA kernel, with the
+    weights packed at finalize; there is no torch / rocBLAS arithmetic behind these modules."""
 
-    def __init__(self, owner, module):
-        self.owner, self.module = owner, module
+    def __init__(self, owner, name, fused):
+        self.owner, self.name, self.fused = owner, name, fused
 
     def __call__(self, x):
         last = self.owner._last
-        if last is not None and x is last[0]:
+        if self.fused and last is not None and x is last[0]:
             return last[1]
-        return _linear(self.module, x)
+        if not x.is_cuda:
+            raise RuntimeError("conan_amd.Emformer runs on a HIP device only (no CPU fallback)")
+        return self.owner._get_streams(1).emformer_project(self.name, x)
 
 
 class _Emformer:
@@ -73,16 +73,12 @@ class EmformerDistillModel(_tree.ParamTree):
         # `.emformer` must stay the container of the parameter tree (state_dict keys 'emformer.emformer_layers...'),
         # so the streaming entry point is attached to that sub-module; `.proj` keeps its parameters likewise.
         self._modules["emformer"].infer = _Emformer(self).infer
-        if self.mode == "both":
-            # dual heads (emformer.py:28-30): the streaming step projects with proj1; proj / proj2 stay plain Linears
-            # (torch on the device, off the hot path: only the distillation forward reads them)
-            self._modules["proj1"].forward = _Proj(self, self._modules["proj1"])
-            for name in ("proj", "proj2"):
-                if name in self._modules:
-                    m = self._modules[name]
-                    m.forward = (lambda x, m=m: _linear(m, x))
-        elif "proj" in self._modules:
-            self._modules["proj"].forward = _Proj(self, self._modules["proj"])
+        # the head the streaming step projects with (proj1 in 'both' mode, inference/Conan.py:117-118) returns the step's own
+        # logits; every head can also project arbitrary features (conan_emformer_project)
+        step_head = "proj1" if self.mode == "both" else "proj"
+        for name in ("proj", "proj1", "proj2"):
+            if name in self._modules and isinstance(self._modules[name], nn.Module) and hasattr(self._modules[name], "weight"):
+                self._modules[name].forward = _Proj(self, name, fused=name == step_head)
         self._last = None
         self._ctx = None
         self._streams = None
@@ -122,7 +118,7 @@ class EmformerDistillModel(_tree.ParamTree):
         (proj1(features), proj2(features)) when mode == 'both' (emformer.py:95-97)."""
         B, T, F = mel_input.shape
         seg, rc = self.segment_length, self.right_context_len
-        pos, state, outs = 0, None, []
+        pos, state, outs, logits = 0, None, [], []
         while pos < T:
             emit = min(seg, T - pos)
             look = min(rc, T - (pos + emit))
@@ -133,12 +129,15 @@ class EmformerDistillModel(_tree.ParamTree):
                 chunk = torch.cat([chunk, chunk[:, -1:, :].expand(B, need, F)], dim=1)
             lengths = torch.full((B,), chunk.size(1), dtype=torch.long, device=mel_input.device)
             out, _, state = self.emformer.infer(chunk, lengths, state)
-            outs.append(out[:, :emit, :].clone())
+            outs.append(out[:, :emit, :])
+            logits.append(self._last[1][:, :emit, :])      # the step projected these rows already (proj / proj1)
             pos += emit
-        streamed = torch.cat(outs, dim=1)
+        first = torch.cat(logits, dim=1)
         if self.mode == "both":
-            return self.proj1(streamed), self.proj2(streamed)
-        return self.proj(streamed)
+            return first, self.proj2(torch.cat(outs, dim=1))
+        if "proj" not in self._modules or not hasattr(self._modules["proj"], "weight"):    # nn.Identity: input_dim == output_dim
+            return torch.cat(outs, dim=1)
+        return first
 
     def forward(self, mel_input, lengths):
         raise NotImplementedError("non-streaming Emformer.forward (training) is outside the hot path")

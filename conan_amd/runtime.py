@@ -166,6 +166,19 @@ class Streams:
         self._release()
         return out, logits, codes
 
+    def emformer_project(self, head, x):
+        """x [..., D] (cuda float32) through the checkpoint's output head `head` ('proj' / 'proj1' / 'proj2'):
+        conan_emformer_project, a k = 1 conv on the MFMA path."""
+        D = self.ctx.cfg.emf_input_dim
+        x2 = x.to(self.dev, torch.float32).reshape(-1, D).contiguous()
+        K = int(self.lib.conan_emformer_head_dim(self.h, head.encode()))
+        if K <= 0:
+            raise _lib.ConanError(_lib.ERR_MISSING, f"no Emformer output head '{head}'")
+        y = torch.empty(x2.shape[0], K, device=self.dev)
+        _lib.check(self.lib.conan_emformer_project(self.h, head.encode(), _ptr(x2), x2.shape[0], _ptr(y), _stream()))
+        self._release()
+        return y.reshape(*x.shape[:-1], K)
+
     def decoder_step(self, slots, codes, taps=False):
         a, p = _i32(slots)
         n = len(a)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 4
+#define CONAN_HIP_ABI_VERSION 5
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -133,6 +133,14 @@ int conan_set_reference(conan_streams* s, const int32_t* slots, int n, const flo
  * logits_dev[n][seg][K] (may be NULL); codes_dev[n][seg] int32 (may be NULL). */
 int conan_emformer_step(conan_streams* s, const int32_t* slots, int n, const float* chunk_dev,
                         float* out_dev, float* logits_dev, int32_t* codes_dev, void* stream);
+/* The output heads of EmformerDistillModel applied to features that did NOT just come out of a step
+ * (modules/Emformer/emformer.py:25 `proj`, :29-30 `proj1` / `proj2`; used by `inference()` :95-97 on the concatenated
+ * per-chunk features): y_dev[rows][K_head] = x_dev[rows][D] @ W_head^T + b_head.  head = "proj", "proj1" or "proj2" as named
+ * in the checkpoint.  CONAN_ERR_MISSING when the checkpoint holds no such head. */
+int conan_emformer_project(conan_streams* s, const char* head, const float* x_dev, int rows, float* y_dev, void* stream);
+/* Output width K_head of that head (nn.Linear(input_dim, K_head).out_features), 0 when the checkpoint has none. */
+int conan_emformer_head_dim(conan_streams* s, const char* head);
+
 
 /* `frames` new content codes per slot -> `frames` mel rows: Conan.forward(infer=True) restricted to
  * the new frames (modules/Conan/Conan.py:140-198 given the cached style pass).

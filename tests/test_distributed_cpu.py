@@ -85,11 +85,56 @@ def _ring_worker(rank, world, port, steps, q):
     q.put((rank, bool(ok)))
 
 
-def test_bench_gather_choreography_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_gather_choreography(world):
+    """world 8 = the 8-GPU node's rank count (BASELINE.json configs[3]): the choreography the driver's N = 8 run executes."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, 11, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+def _check_worker(rank, world, port, q):
+    """bench.py's rank bookkeeping on a host group: per-rank clocks and devices by all_gather, and the check that what
+    rank 0 gathered for the last step is what every rank produced (integer checksums of the fp32 bit patterns)."""
+    from conan_amd.engine import AudioGatherRing
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ring = AudioGatherRing(lambda: torch.zeros(4, 32), world, rank, nb=4)
+    g = torch.Generator().manual_seed(100 + rank)
+    steps = 6
+    for j in range(steps):
+        buf, _ = ring.acquire(j, fence=True)
+        buf.copy_(torch.randn(4, 32, generator=g))
+        ring.submit(j)
+    ring.drain()
+    last = ring.bufs[(steps - 1) % ring.nb]
+    csum = last.view(torch.int32).to(torch.int64).sum().reshape(1)
+    sums = [torch.zeros_like(csum) for _ in range(world)]
+    dist.all_gather(sums, csum)
+    mine = torch.tensor([0.001 * (rank + 1), float(rank)], dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    ok = [int(r[1].item()) for r in allr] == list(range(world)) and max(float(r[0]) for r in allr) == pytest.approx(0.001 * world)
+    if rank == 0:
+        got = [int(b.view(torch.int32).to(torch.int64).sum().item()) for b in ring.gbufs]
+        ok = ok and got == [int(x.item()) for x in sums] and len(set(got)) == world
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_bench_gather_check_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_check_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

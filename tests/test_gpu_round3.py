@@ -1,0 +1,98 @@
+"""Round-3 GPU tests: single-branch vocoders, host plans that take their widths from the checkpoint, the fused first
+vocoder stage, fused decoder sub-layers, the memory bank inside the one-launch Emformer step, fenced hand-offs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conan_amd import configs, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _voc_ctx(vhp):
+    from conan_amd.runtime import Context
+    ctx = Context(None, vhp, 0, False, False, True)
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    return ctx
+
+
+@pytest.mark.parametrize("tiny,slots", [(True, 1), (False, 1), (False, 9)])
+def test_single_branch_vocoder_keeps_the_last_leaky_relu(tiny, slots):
+    """resblock_kernel_sizes = [3]: HifiGanGenerator.forward still applies F.leaky_relu before conv_post
+    (hifigan_causal.py:324-333) although the branch mean is over one branch.  Streamed in 4-frame steps against the
+    oracle's one-shot forward; 9 slots take the fused ResBlock plan at every width, one slot the two-launch plan."""
+    from oracle import hifigan as ohifi
+    from oracle.common import to_torch_sd
+    vhp = dict(configs.hifigan_hparams(tiny), resblock_kernel_sizes=[3], resblock_dilation_sizes=[[1, 3, 5]])
+    ctx = _voc_ctx(vhp)
+    T = 12
+    mel = torch.from_numpy(synth.mel(T, 31, slots)).transpose(1, 2).contiguous()      # [slots, 80, T]
+    taps = {}
+    ref = ohifi.generator_forward(to_torch_sd(synth.hifigan_state_dict(vhp, 0)), vhp, mel, None, taps)[:, 0].numpy()
+    st = ctx.streams(slots, max_frames=4, max_ref_frames=16)
+    ids = list(range(slots))
+    st.reset(ids)
+    x = mel.transpose(1, 2).contiguous().cuda()
+    outs, pres = [], []
+    for i in range(0, T, 4):
+        w, p = st.hifigan_step(ids, x[:, i:i + 4], want_pre_tanh=True)
+        outs.append(w); pres.append(p)
+    wav, pre = torch.cat(outs, 1).cpu().numpy(), torch.cat(pres, 1).cpu().numpy()
+    ref_pre = taps["pre_tanh"][:, 0].numpy()
+    np.testing.assert_allclose(pre, ref_pre, atol=1e-4 * max(1.0, np.abs(ref_pre).max()), rtol=0)
+    np.testing.assert_allclose(wav, ref, atol=1e-4, rtol=0)
+    st.close(); ctx.close()
+
+
+def test_fence_free_handoffs_match_the_fenced_build_under_concurrency():
+    """Split-K partial tiles (conv_mfma) and the Emformer cluster exchange travel as write-through stores + a flag / ticket +
+    sc1 loads, without release / acquire fences.  Cross-check: a second stream-set created with CONAN_FENCED=1 brackets the
+    same hand-offs with agent-scope fences; at 1-4 streams all three pipelined stages split K / run clusters concurrently on
+    their internal streams.  Every output of 120 pipelined steps must be bit-identical between the two (the split factors
+    and cluster sizes are the same, so any difference is a stale read)."""
+    from conan_amd.runtime import Context
+    chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
+    ctx = Context(chp, vhp, 0)
+    ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0))
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
+    ctx.finalize()
+    S, N = 4, 120
+    old = os.environ.get("CONAN_FENCED")
+    try:
+        os.environ["CONAN_FENCED"] = "0"
+        plain = ctx.streams(S, 4, 64)
+        os.environ["CONAN_FENCED"] = "1"
+        fenced = ctx.streams(S, 4, 64)
+    finally:
+        if old is None:
+            os.environ.pop("CONAN_FENCED", None)
+        else:
+            os.environ["CONAN_FENCED"] = old
+    ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
+    src = torch.from_numpy(synth.mel(4 * N + 8, 9, S)).cuda()
+    hop = ctx.hop
+    rng = np.random.default_rng(3)
+    outs = {}
+    for name, st in (("plain", plain), ("fenced", fenced)):
+        st.reset(list(range(S))); st.set_reference(list(range(S)), ref)
+    pos = [0] * S
+    res = {"plain": [], "fenced": []}
+    for it in range(N):
+        n = int(rng.integers(1, S + 1))
+        slots = sorted(rng.choice(S, n, replace=False).tolist())
+        chunk = torch.stack([src[s, pos[s]:pos[s] + 6] for s in slots]).contiguous()
+        for name, st in (("plain", plain), ("fenced", fenced)):
+            c = torch.empty(n, 4, dtype=torch.int32, device="cuda"); m = torch.empty(n, 4, 80, device="cuda"); w = torch.empty(n, 4 * hop, device="cuda")
+            st.step_async(slots, chunk, w, emit=4, codes=c, mel_out=m)
+            res[name].append((c, m, w))
+        for s in slots:
+            pos[s] += 4
+    plain.join(); fenced.join(); torch.cuda.synchronize()
+    bad = [k for k, (a, b) in enumerate(zip(res["plain"], res["fenced"])) if not all(torch.equal(x, y) for x, y in zip(a, b))]
+    assert not bad, f"steps whose fence-free result differs from the fenced one: {bad[:10]}"
+    assert all(torch.isfinite(w).all() for _, _, w in res["plain"])
+    plain.close(); fenced.close(); ctx.close()

@@ -2,12 +2,13 @@
 #   bash tools/collect_profiles.sh [workload]      (default b64)
 # rocprofv3 kernel stats of the default bench schedule, then separate PMC passes (one counter group per pass, with
 # --kernel-trace only) of `bench.py --marks`, summarised by tools/summarize_pmc.py over the marked (timed) steps.
-# Outputs under gpurun_out/r2_prof_<workload>/; the summaries to keep are copied into profiles/ (r2_<workload>_*).
+# Outputs under gpurun_out/${R}_prof_<workload>/; the summaries to keep are copied into profiles/ (${R}_<workload>_*).
 W=${1:-b64}
+R=${ROUND:-r3}
 STEPS=${STEPS:-4}
 cd /tmp && export TMPDIR=/tmp
 cd /root/repo
-O=gpurun_out/r2_prof_$W; rm -rf $O; mkdir -p $O
+O=gpurun_out/${R}_prof_$W; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-b1 > $O/stats.log 2>&1
 # the same kernels in blocking steps only (the schedule bench.py's roofline events are taken in): under the tracer the pipelined
 # run above is host-bound and its stages collide in ways the untraced run does not show ("What the stages cost each other")
@@ -19,9 +20,9 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_H
 done
 python3 tools/summarize_pmc.py --cmd "$CMD" --steps $STEPS --out $O/pmc.json $O/pmc_*/run_counter_collection.csv > $O/pmc.txt
 mkdir -p profiles
-cp $O/stats/run_kernel_stats.csv profiles/r2_${W}_kernel_stats.csv 2>/dev/null
-cp $O/stats_blocking/run_kernel_stats.csv profiles/r2_${W}_kernel_stats_blocking.csv 2>/dev/null
-cp $O/pmc.json profiles/r2_${W}_pmc.json; cp $O/pmc.txt profiles/r2_${W}_pmc.txt
-mkdir -p gpurun_out/profiles_r2; cp profiles/r2_${W}_kernel_stats.csv profiles/r2_${W}_kernel_stats_blocking.csv profiles/r2_${W}_pmc.json profiles/r2_${W}_pmc.txt gpurun_out/profiles_r2/
+cp $O/stats/run_kernel_stats.csv profiles/${R}_${W}_kernel_stats.csv 2>/dev/null
+cp $O/stats_blocking/run_kernel_stats.csv profiles/${R}_${W}_kernel_stats_blocking.csv 2>/dev/null
+cp $O/pmc.json profiles/${R}_${W}_pmc.json; cp $O/pmc.txt profiles/${R}_${W}_pmc.txt
+mkdir -p gpurun_out/profiles_${R}; cp profiles/${R}_${W}_kernel_stats.csv profiles/${R}_${W}_kernel_stats_blocking.csv profiles/${R}_${W}_pmc.json profiles/${R}_${W}_pmc.txt gpurun_out/profiles_${R}/
 rm -f $O/*/run_kernel_trace.csv
 head -8 $O/stats/run_kernel_stats.csv | cut -c1-160; head -20 $O/pmc.txt

@@ -62,7 +62,13 @@ def main():
             e["l2_hit_rate"] = h / (h + m) if h + m > 0 else None
         e.setdefault("fetch", 0.0); e.setdefault("write", 0.0)
         kernels[k] = e
-    out = {"command": a.cmd, "steps": a.steps, "filtered_to_marked_steps": marked,
+    import hashlib, os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conan_amd", "libconan_hip.so")
+    try:
+        sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()      # the library the passes ran with (bench.py compares it with the one it loads)
+    except OSError:
+        sha = None
+    out = {"command": a.cmd, "steps": a.steps, "filtered_to_marked_steps": marked, "lib_sha256": sha,
            "unit": "bytes per dispatch (FETCH_SIZE x2 on gfx950, WRITE_SIZE exact), averaged over the dispatches of the timed steps",
            "bytes_per_step": (tot_fetch + tot_write) / a.steps, "fetch_bytes_per_step": tot_fetch / a.steps, "write_bytes_per_step": tot_write / a.steps,
            "kernels": kernels}
