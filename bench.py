@@ -305,30 +305,22 @@ def main():
                                    "checksums_ranks_own": [int(csum.item())]} if ring.active else None)}
     ms_step = dt / args.steps * 1e3
 
-    # Distribution of the step time (outside the timed region): one HIP event per step, recorded on a side stream behind a
-    # join of the library's internal streams (a join on the caller's stream would hold back the next step's front-end and
-    # drain the pipeline), intervals between consecutive events.
+    # Distribution of the step time (outside the timed region, same schedule): the library stamps the completion of every
+    # pipelined step with a timing event on its own vocoder stream (conan_step_clock) - no extra stream, no extra wait;
+    # windowed workloads run blocking steps, whose host-timed latencies are the distribution (latency_stats).
     step_stats = None
-    if not args.marks:
-        side = torch.cuda.Stream()
-        evs = []
-        for _ in range(min(args.steps, 40) + 1):
+    if not args.marks and not window:
+        ns = min(max(args.steps, 2), 60)
+        eng.st.step_clock(ns + 1)
+        for _ in range(ns + 1):
             step(j); j += 1
-            with torch.cuda.stream(side):
-                if not window:
-                    eng.st.join()
-                else:
-                    side.wait_stream(torch.cuda.current_stream())
-                e = torch.cuda.Event(enable_timing=True)
-                e.record(side)
-                evs.append(e)
         barrier()
-        side.synchronize()
-        iv = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1))
+        iv = sorted(eng.st.step_clock_read())
+        eng.st.step_clock(0)
         if iv:
             step_stats = {"n": len(iv), "mean_ms": statistics.fmean(iv), "sigma_ms": statistics.pstdev(iv), "p50_ms": statistics.median(iv),
                           "p95_ms": iv[min(len(iv) - 1, int(round(0.95 * (len(iv) - 1))))], "min_ms": iv[0], "max_ms": iv[-1],
-                          "how": "intervals between per-step completion events on a side stream, a separate run of steps after the timed region"}
+                          "how": "intervals between consecutive step completions (timing events on the library's vocoder stream), a separate run of pipelined steps after the timed region"}
     frames_per_step = (window + seg) if window else seg           # decoder / vocoder frames computed per stream per step
 
     def one_blocking_step(e, ch, c_, m_, w_, h_):

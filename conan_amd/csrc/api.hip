@@ -413,8 +413,33 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     }
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, s->st_voc);
     HIP_CHECK(hipEventRecord(s->ev_voc[p], s->st_voc));
+    if (s->clock_on && s->clock_n < (int)s->clock_ev.size()) HIP_CHECK(hipEventRecord(s->clock_ev[s->clock_n++], s->st_voc));   // step completion stamp
     s->async_steps = t + 1;
   });
+}
+
+int conan_step_clock(conan_streams* s, int capacity) {
+  return guarded([&] {
+    if (!s || capacity < 0 || capacity > 4096) throw Error(CONAN_ERR_INVALID, "conan_step_clock: capacity in [0, 4096]");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    while ((int)s->clock_ev.size() < capacity) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); s->clock_ev.push_back(e); }
+    s->clock_on = capacity > 0; s->clock_n = 0;
+  });
+}
+
+int conan_step_clock_read(conan_streams* s, double* ms_out, int cap) {
+  int cnt = 0;
+  const int rc = guarded([&] {
+    if (!s || (!ms_out && cap > 0)) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (s->clock_n < 2) return;
+    HIP_CHECK(hipEventSynchronize(s->clock_ev[s->clock_n - 1]));
+    for (int i = 0; i + 1 < s->clock_n && cnt < cap; ++i) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, s->clock_ev[i], s->clock_ev[i + 1]));
+      ms_out[cnt++] = ms;
+    }
+  });
+  return rc < 0 ? rc : cnt;
 }
 
 int conan_streams_output_fence(conan_streams* s, void* fence_stream) {

@@ -142,7 +142,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   const int ncb32 = a.Cin_pad >> 5;                 // 32-channel blocks per tap
   const int ncb = (ncb32 + SB - 1) / SB;            // K-steps per tap
   const int nks_all = ktaps * ncb;
-  constexpr bool SK = (TM == 32);                  // inter-block split-K is compiled into the small-M shapes only
+  // inter-block split-K is compiled into the small-M shapes (every tile of a launch) and into the 64-column K-step-32
+  // streaming shapes (the tail tiles of a launch); conv_cfg_splitk() tells the host which
+  constexpr bool SK = (TM == 32) || (TN == 64 && KS == 32 && WK == 1);
   // inter-block split-K: this block owns K-steps [ks_lo, ks_lo + nks) of the tile; the partial tiles are combined by the
   // last-arriving block (ticket counter), in slice order, so the sum is reproducible
   const int ks_lo = SK ? (int)((long long)nks_all * kslice / nslices) : 0;
@@ -607,7 +609,8 @@ __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS>::TOTAL * 4 > 80 * 102
   __shared__ __attribute__((aligned(16))) float lds[ConvLds<TM, TN, WK, KS>::TOTAL];
   int gbuf = 0;
   const int S = g.ksplit;
-  const int total = g.tile_start[3] * S;
+  const int sfrom = g.split_from;                  // items [0, sfrom): whole tiles; then S slices per tile
+  const int total = sfrom + (g.tile_start[3] - sfrom) * S;
 #ifdef CK_STAMPS
   if (g.p[0].dbg && threadIdx.x == 0 && blockIdx.x < 512) g.p[0].dbg[32 + blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -617,13 +620,15 @@ __global__ __launch_bounds__(512, (ConvLds<TM, TN, WK, KS>::TOTAL * 4 > 80 * 102
   int i = 0;
   int cur = assign ? assign[0] : (int)blockIdx.x;
   while (cur >= 0 && cur < total) {
-    const int tile = cur / S, kslice = cur - tile * S;        // slices of a tile are adjacent: they finish together
+    const int rs = cur - sfrom;
+    const int tile = rs < 0 ? cur : sfrom + rs / S, kslice = rs < 0 ? 0 : rs % S;        // slices of a tile are adjacent: they finish together
+    const int ns = rs < 0 ? 1 : S;
     const int p = (tile >= g.tile_start[1] ? 1 : 0) + (tile >= g.tile_start[2] ? 1 : 0);
     const int local = tile - g.tile_start[p];
     const int tn = g.tiles_n[p];
     const int mt = local / tn, nt = local - mt * tn;
-    conv_tile<TM, TN, WM, WN, WK, KS>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, S,
-                                            g.slab + (long long)tile * S * (TM * TN), g.counters + tile, g.fenced);
+    conv_tile<TM, TN, WM, WN, WK, KS>(g.p[g.order[p]], mt * TM, nt * TN, lds, gbuf, tile, kslice, ns,
+                                            g.slab + (long long)(tile - sfrom) * S * (TM * TN), g.counters + tile, g.fenced);
     ++i;
     cur = assign ? (i < g.assign_per ? assign[i] : -1) : cur + (int)gridDim.x;
   }
@@ -638,6 +643,7 @@ int conv_cfg_tm(int cfg) { return kTM[cfg]; }
 int conv_cfg_tn(int cfg) { return kTN[cfg]; }
 static const int kKS[NUM_CFG] = {32, 32, 32, 64, 128, 32, 64, 64};
 int conv_cfg_ks(int cfg) { return kKS[cfg]; }
+bool conv_cfg_splitk(int cfg) { return kTM[cfg] == 32 || cfg == CFG_64x64 || cfg == CFG_128x64; }
 const char* conv_cfg_name(int cfg) {
   static const char* names[NUM_CFG] = {
       "cnk::conv_mfma_kernel<128, 64, 2, 2, 1, 32>", "cnk::conv_mfma_kernel<64, 64, 2, 2, 1, 32>", "cnk::conv_mfma_kernel<128, 32, 4, 1, 1, 32>",
@@ -655,7 +661,7 @@ const char* conv_cfg_name(int cfg) {
 //  * balanced: within an XCD, longest-processing-time-first over its blocks (the three branches of a grouped resblock
 //    launch have k = 11 / 7 / 3); cost of an item = its K-steps + a constant for prologue/epilogue.
 static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int* per_out) {
-  struct Key { int v[12]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
+  struct Key { int v[14]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
   static std::map<Key, std::pair<const int*, int>> cache;
   static std::mutex cache_mu;                       // host threads driving different devices / stream-sets share it
   std::lock_guard<std::mutex> lock(cache_mu);
@@ -664,16 +670,18 @@ static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int*
   for (int q = 0; q < 3; ++q) { const ConvArgs& a = g.p[g.order[q]]; nks[q] = a.ktaps * ((a.Cin_pad + KS - 1) / KS); }
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);                     // the cached lists live in that device's memory
-  Key k = {{grid, g.tile_start[1], g.tile_start[2], g.tile_start[3], nks[0], nks[1], nks[2], KS, g.tiles_n[0], g.tiles_n[1], g.tiles_n[2], dev_id}};
+  Key k = {{grid, g.tile_start[1], g.tile_start[2], g.tile_start[3], nks[0], nks[1], nks[2], KS, g.tiles_n[0], g.tiles_n[1], g.tiles_n[2], dev_id, g.ksplit, g.split_from}};
   auto it = cache.find(k);
   if (it != cache.end()) { *per_out = it->second.second; return it->second.first; }
-  const int total = g.tile_start[3];
+  const int ntiles = g.tile_start[3], S = std::max(1, g.ksplit), sfrom = g.ksplit > 1 ? g.split_from : ntiles;
+  const int total = sfrom + (ntiles - sfrom) * S;      // work items: whole tiles, then the K slices of the tail tiles
   std::vector<std::vector<int>> lists(grid);
   typedef std::pair<long long, int> Bin;
   std::priority_queue<Bin, std::vector<Bin>, std::greater<Bin>> heap[NX];
   const bool by_xcd = grid >= NX * 2 && grid % NX == 0;
   for (int b = 0; b < grid; ++b) heap[by_xcd ? b % NX : 0].push({0, b});
-  for (int item = 0; item < total; ++item) {
+  for (int it = 0; it < total; ++it) {
+    const int item = it < sfrom ? it : sfrom + (it - sfrom) / S;      // the tile of this work item
     const int q = (item >= g.tile_start[1] ? 1 : 0) + (item >= g.tile_start[2] ? 1 : 0);
     const int local = item - g.tile_start[q], tn = g.tiles_n[q];
     const int n_mt = (g.tile_start[q + 1] - g.tile_start[q]) / tn, mt = local / tn, nt = local - mt * tn;
@@ -684,8 +692,8 @@ static const int* balanced_assignment(const ConvGroup& g, int grid, int KS, int*
     const int x = !by_xcd ? 0 : by_cols ? std::min(NX - 1, (int)((long long)nt * NX / tn))
                                         : std::min(NX - 1, (int)((long long)mt * NX / std::max(n_mt, 1)));
     Bin top = heap[x].top(); heap[x].pop();
-    lists[top.second].push_back(item);
-    heap[x].push({top.first + nks[q] + 3, top.second});
+    lists[top.second].push_back(it);
+    heap[x].push({top.first + (it < sfrom ? nks[q] : (nks[q] + S - 1) / S) + 3, top.second});
   }
   // The two blocks that share a CU would otherwise walk equal-length tiles in lockstep and reach their epilogues -
   // where the matrix pipe idles - together: every other block of an XCD runs its list shortest-first.
@@ -708,10 +716,12 @@ static void launch_one(const ConvGroup& gin, int num_cu, hipStream_t st) {
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   ConvGroup g = gin;
   g.assign = nullptr; g.assign_per = 0;
-  int grid = g.tile_start[3] * g.ksplit;
+  if (g.ksplit <= 1) { g.ksplit = 1; g.split_from = g.tile_start[3]; }
+  if (g.split_from > g.tile_start[3]) g.split_from = g.tile_start[3];
+  int grid = g.split_from + (g.tile_start[3] - g.split_from) * g.ksplit;
   if (grid > num_cu * per_cu) {     // persistent blocks
     grid = num_cu * per_cu;
-    if (g.ksplit == 1) g.assign = balanced_assignment(g, grid, KS, &g.assign_per);
+    g.assign = balanced_assignment(g, grid, KS, &g.assign_per);
   }
   hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, WK, KS>), dim3(grid), dim3(512), 0, st, g);
 }
@@ -732,7 +742,7 @@ static void launch_conv_cfg(const ConvGroup& g, int cfg, int num_cu, hipStream_t
 
 void launch_conv(const ConvGroup& gin, int nprob, int cfg, hipStream_t st, int num_cu) {
   ConvGroup g = gin;
-  if (g.ksplit < 1 || !g.slab || !g.counters || kTM[cfg] != 32) g.ksplit = 1;
+  if (g.ksplit < 1 || !g.slab || !g.counters || !conv_cfg_splitk(cfg)) g.ksplit = 1;
   const int TM = kTM[cfg], TN = kTN[cfg];
   // longest-K problem first
   int idx[3] = {0, 1, 2};

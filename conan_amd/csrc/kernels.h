@@ -74,6 +74,10 @@ struct ConvGroup {      // up to 3 independent problems in one launch
   const int* assign;
   int assign_per;
   int ksplit;
+  // tiles [0, split_from) are whole work items; only the tiles from split_from on are divided into `ksplit` K slices (the
+  // tail of a launch whose tile count is not a multiple of the CU count: 320 tiles on 256 CUs = 256 tiles + 64 x 4
+  // quarter tiles - every CU gets 1.25 tiles of work instead of some getting two).  0: every tile is split.
+  int split_from;
   // 1: the split-K hand-off is additionally bracketed by agent-scope release / acquire fences (CONAN_FENCED=1, a
   // developer cross-check of the fence-free default: write-through stores, ticket, sc1 loads)
   int fenced;
@@ -83,6 +87,7 @@ struct ConvGroup {      // up to 3 independent problems in one launch
 enum ConvCfg { CFG_128x64 = 0, CFG_64x64 = 1, CFG_128x32 = 2, CFG_32x64_K2 = 3, CFG_32x32_K4 = 4, CFG_64x32_K2 = 5,
                CFG_64x64_KS64 = 6, CFG_128x32_KS64 = 7, NUM_CFG };
 int conv_cfg_ks(int cfg);          // K-step of the configuration
+bool conv_cfg_splitk(int cfg);     // the build carries the inter-block split-K hand-off
 const char* conv_cfg_name(int cfg);  // the kernel's name as rocprofv3 prints it
 int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);

@@ -146,6 +146,8 @@ struct conan_streams {
   int ws_index(hipStream_t st) const { return (st_voc && st == st_voc) ? 1 : ((st_emf && st == st_emf) ? 2 : 0); }
   float* mel_hand[NP] = {};                    // mel hand-off buffers decoder -> vocoder [max_slots][max_frames][num_mels]
   long long async_steps = 0;                   // steps enqueued since creation
+  std::vector<hipEvent_t> clock_ev;            // conan_step_clock: one timing event per pipelined step, on the vocoder stream
+  bool clock_on = false; int clock_n = 0;
   void async_init();
   void join(hipStream_t st);                   // make `st` wait for everything enqueued by conan_step_async
 
@@ -157,6 +159,7 @@ struct conan_streams {
     for (int i = 0; i < NP; ++i) { if (ev_emf[i]) (void)hipEventDestroy(ev_emf[i]); if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : clock_ev) (void)hipEventDestroy(e);
   }
 
   void build_vocoder();

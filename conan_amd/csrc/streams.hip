@@ -63,7 +63,26 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
   const int wsi = ws_index(st);
-  g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1; g.fenced = fenced ? 1 : 0;
+  g.slab = sk_slab[wsi]; g.counters = sk_counters[wsi]; g.ksplit = 1; g.split_from = 0; g.fenced = fenced ? 1 : 0;
+  const int cus_all = std::max(8, ctx->num_cu - (wsi == 1 ? reserve_cus : 0));
+  if (cnk::conv_cfg_tm(cfg) != 32 && nprob == 1 && cnk::conv_cfg_splitk(cfg)) {
+    // Streaming shapes whose tile count is not a multiple of the CU count (ups[1]: 320 tiles of 64 x 64 on 256 CUs): the
+    // last `rem` tiles are cut into S K-slices each, rem * S <= CUs, so that every CU gets the same 1 + 1/S (2 + 1/S ...)
+    // tiles of MFMA work instead of some CUs getting one tile more than the others - the tail of a stream-K schedule,
+    // with the fence-free partial-tile hand-off of the small-M shapes.
+    static const bool off = getenv("CONAN_NO_TAILSPLIT") != nullptr;
+    const ConvArgs& a = g.p[0];
+    const int TM = cnk::conv_cfg_tm(cfg), TN = cnk::conv_cfg_tn(cfg), KS = cnk::conv_cfg_ks(cfg);
+    const long long tiles = (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
+    const int nks = a.ktaps * ((a.Cin_pad + KS - 1) / KS);
+    const long long rem = tiles % cus_all;
+    if (!off && tiles > cus_all && rem > 0 && tiles <= sk_max_tiles) {
+      int S = (int)std::min<long long>(8, cus_all / rem);
+      S = std::min(S, nks / 8);                                  // at least 8 K-steps per slice (ups[3], 8 K-steps in all: the hand-off costs more than the tail it removes, 27 against 23 us)
+      while (S > 1 && rem * S * TM * TN > sk_slab_floats) --S;
+      if (S >= 2) { g.ksplit = S; g.split_from = (int)(tiles - rem); }
+    }
+  }
   if (cnk::conv_cfg_tm(cfg) == 32) {
     // (grouped launches: one split factor for all problems, sized by the longest K loop)
     const int TM = cnk::conv_cfg_tm(cfg), TN = cnk::conv_cfg_tn(cfg);
@@ -88,8 +107,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   double fl = 0.0;
   for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)g.p[p].n * g.p[p].T * g.p[p].Cout * g.p[p].ktaps * g.p[p].Cin;
   // (pipelined vocoder: its persistent launches leave `reserve_cus` CUs to the other internal streams, see launch_rb)
-  const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
-  profiled(cnk::conv_cfg_name(cfg), fl, st, [&] { cnk::launch_conv(g, nprob, cfg, st, cus); });
+  profiled(cnk::conv_cfg_name(cfg), fl, st, [&] { cnk::launch_conv(g, nprob, cfg, st, cus_all); });
 }
 
 // every launch of the matrix kernels goes through here: between conan_profile_begin / _end it is bracketed by HIP

@@ -306,6 +306,16 @@ class Streams:
         """One cnk::profile_mark_kernel dispatch on the current stream (marker for rocprofv3 post-processing)."""
         _lib.check(self.lib.conan_profile_mark(self.h, _stream()))
 
+    def step_clock(self, capacity):
+        """Record a completion stamp per pipelined step on the internal vocoder stream (conan_step_clock); 0 = off."""
+        _lib.check(self.lib.conan_step_clock(self.h, int(capacity)))
+
+    def step_clock_read(self, cap=4096):
+        """Intervals (ms) between the completions of consecutive pipelined steps since step_clock()."""
+        buf = (C.c_double * cap)()
+        n = _lib.check(self.lib.conan_step_clock_read(self.h, buf, cap))
+        return [buf[i] for i in range(n)]
+
     def profile_begin(self):
         _lib.check(self.lib.conan_profile_begin(self.h))
 

@@ -253,6 +253,12 @@ int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, 
 /* Enqueue one dispatch of the empty kernel cnk::profile_mark_kernel on `stream`: a marker that tools/summarize_pmc.py
  * uses to keep only the timed steps of a rocprofv3 counter-collection run (bench.py --marks). */
 int conan_profile_mark(conan_streams* s, void* stream);
+/* Step-time distribution of pipelined steps without touching their schedule: conan_step_clock(s, capacity > 0) makes every
+ * following conan_step_async record one timing event on the internal vocoder stream when the step's audio is complete
+ * (up to `capacity` steps; 0 switches it off); conan_step_clock_read waits for the last recorded step and writes the
+ * intervals between consecutive completions in milliseconds to ms_out[cap], returning their count. */
+int conan_step_clock(conan_streams* s, int capacity);
+int conan_step_clock_read(conan_streams* s, double* ms_out, int cap);
 
 /* Introspection for tests / INTEGRATION.md. */
 int conan_hop_size(const conan_ctx* ctx);             /* prod(upsample_rates) */
