@@ -74,6 +74,8 @@ _PROTOS = {
     "conan_profile_mark": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_step_clock": (C.c_int, [C.c_void_p, C.c_int]),
     "conan_step_clock_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
+    "conan_step_timeline": (C.c_int, [C.c_void_p, C.c_int]),
+    "conan_step_timeline_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "conan_profile_begin": (C.c_int, [C.c_void_p]),
     "conan_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "conan_profile_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

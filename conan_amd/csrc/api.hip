@@ -376,6 +376,8 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     // inputs are ready in the caller's stream order
     HIP_CHECK(hipEventRecord(s->ev_in[p], (hipStream_t)stream));
     HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_in[p], 0));
+    const bool tl = s->tl_on && s->tl_n < (int)s->tl_ev.size() / 6;
+    hipEvent_t* te = tl ? &s->tl_ev[(size_t)s->tl_n * 6] : nullptr;
     // a changed slot list rewrites the table the in-flight decoder / vocoder still read: drain them first
     bool same = (int)s->h_slots.size() == n;
     for (int i = 0; same && i < n; ++i) same = s->h_slots[i] == slots[i];
@@ -389,11 +391,16 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     // launch has left - so the decoder must not have to wait for the Emformer of its own chunk)
     if (t >= NP) HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_front[p], 0));
     int* codes_seg = s->codes_hand[p];
-    s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_emf);
+    // developer timing switch (results are then meaningless): CONAN_SKIP_STAGE bit 0 skips the Emformer launch, bit 1 the decoder's
+    static const int skip = getenv("CONAN_SKIP_STAGE") ? atoi(getenv("CONAN_SKIP_STAGE")) : 0;
+    if (tl) HIP_CHECK(hipEventRecord(te[0], s->st_emf));
+    if (!(skip & 1)) s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_emf);
+    if (tl) HIP_CHECK(hipEventRecord(te[1], s->st_emf));
     HIP_CHECK(hipEventRecord(s->ev_emf[p], s->st_emf));
     HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_emf[p], 0));
     // the mel hand-off buffer at this ring position is free once the vocoder of step t-NP has copied it into its ring
     if (t >= NP) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p], 0));
+    if (tl) HIP_CHECK(hipEventRecord(te[2], s->st_front));
     if (codes_dev) HIP_CHECK(hipMemcpyAsync(codes_dev, codes_seg, (size_t)n * seg * sizeof(int), hipMemcpyDeviceToDevice, s->st_front));
     const int* codes_emit = codes_seg;
     if (emit != seg && n > 1) {
@@ -402,8 +409,9 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
       codes_emit = compact;
     }
     float* mel = s->mel_hand[p];
-    { conan_decoder_taps none; memset(&none, 0, sizeof(none)); s->decoder_step(n, emit, codes_emit, mel, none, s->st_front); }
+    if (!(skip & 2)) { conan_decoder_taps none; memset(&none, 0, sizeof(none)); s->decoder_step(n, emit, codes_emit, mel, none, s->st_front); }
     if (mel_out_dev) HIP_CHECK(hipMemcpyAsync(mel_out_dev, mel, (size_t)n * emit * s->ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, s->st_front));
+    if (tl) HIP_CHECK(hipEventRecord(te[3], s->st_front));
     HIP_CHECK(hipEventRecord(s->ev_front[p], s->st_front));
     HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_front[p], 0));
     if (s->fence_set) {      // the caller's output fence: only the stage that writes the audio buffer waits for it
@@ -411,7 +419,9 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
       HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_fence[p], 0));
       s->fence_set = false;
     }
+    if (tl) HIP_CHECK(hipEventRecord(te[4], s->st_voc));
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, s->st_voc);
+    if (tl) { HIP_CHECK(hipEventRecord(te[5], s->st_voc)); s->tl_n++; }
     HIP_CHECK(hipEventRecord(s->ev_voc[p], s->st_voc));
     if (s->clock_on && s->clock_n < (int)s->clock_ev.size()) HIP_CHECK(hipEventRecord(s->clock_ev[s->clock_n++], s->st_voc));   // step completion stamp
     s->async_steps = t + 1;
@@ -425,6 +435,32 @@ int conan_step_clock(conan_streams* s, int capacity) {
     while ((int)s->clock_ev.size() < capacity) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); s->clock_ev.push_back(e); }
     s->clock_on = capacity > 0; s->clock_n = 0;
   });
+}
+
+int conan_step_timeline(conan_streams* s, int capacity) {
+  return guarded([&] {
+    if (!s || capacity < 0 || capacity > 1024) throw Error(CONAN_ERR_INVALID, "conan_step_timeline: capacity in [0, 1024]");
+    HIP_CHECK(hipSetDevice(s->ctx->device));
+    while ((int)s->tl_ev.size() < capacity * 6) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); s->tl_ev.push_back(e); }
+    s->tl_on = capacity > 0; s->tl_n = 0;
+  });
+}
+
+int conan_step_timeline_read(conan_streams* s, double* ms_out, int cap_steps) {
+  int cnt = 0;
+  const int rc = guarded([&] {
+    if (!s || (!ms_out && cap_steps > 0)) throw Error(CONAN_ERR_INVALID, "null argument");
+    if (s->tl_n < 1) return;
+    HIP_CHECK(hipEventSynchronize(s->tl_ev[(size_t)s->tl_n * 6 - 1]));
+    HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < s->tl_n && cnt < cap_steps; ++i, ++cnt)
+      for (int e = 0; e < 6; ++e) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, s->tl_ev[0], s->tl_ev[(size_t)i * 6 + e]));
+        ms_out[(size_t)cnt * 6 + e] = ms;
+      }
+  });
+  return rc < 0 ? rc : cnt;
 }
 
 int conan_step_clock_read(conan_streams* s, double* ms_out, int cap) {

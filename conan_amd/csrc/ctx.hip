@@ -251,11 +251,11 @@ void conan_ctx::finalize_hifigan() {
           pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c." + std::to_string(d), P + rb + ".convs." + std::to_string(d) + ".conv");
         } else {
           const int Cs = c.voc_initial_channel >> (i + 1);
-          // stages too wide for the fused pass (C = 256) run their convs through rowconv.hip's 32-row stream tiles
-          const bool rc = !cnk::resblock_fused_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
+          const bool rc = false;      // (the rowconv layout of these convs was an experiment: nothing launches it)
           pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv", 1, rc);
           pack_weightnorm("voc.rb." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv", 1, rc);
-          if (cnk::resblock_fused_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d])) {
+          if (cnk::resblock_fused_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]) ||
+              cnk::resblock_pair_supported(Cs, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d], 32)) {
             pack_fragments("voc.rbf." + std::to_string(ridx) + ".c1." + std::to_string(d), P + rb + ".convs1." + std::to_string(d) + ".conv");
             pack_fragments("voc.rbf." + std::to_string(ridx) + ".c2." + std::to_string(d), P + rb + ".convs2." + std::to_string(d) + ".conv");
           }

@@ -128,6 +128,31 @@ bool resblock_fused_can_merge(int C, int rows);   // a merged-branch build exist
 const char* resblock_fused_name(int C, int rows, bool merge = false);
 
 
+// One ResBlock1 unit per branch for the wide first stage (C = 256, <= 32 rows per stream and step), a PAIR of workgroups per
+// (branch, stream) tile: c1 split over output columns, c2 over input channels, partial sums exchanged at the end of the tile;
+// the k-1 rows of xt in front of a tile come from a per-unit history ring (resblock_pair.hip).
+struct RPProb {
+  const float* w1; const float* w2;   // fragment-major like RBProb: [16 column tiles][k + 1 taps][16 K groups][64 lanes][4]
+  const float* b1; const float* b2;   // [256]
+  TRef x, y;                          // raw input / raw output
+  TRef xh;                            // history of leaky_relu(c1 + b1): a ring with >= k - 1 rows of history, same rate as x
+  int k, dil;
+};
+struct RPArgs {
+  RPProb p[3];
+  const int* slots; const int* pos;
+  const int* tiles; int ntiles;       // filled by launch_resblock_pair
+  int* sched;                         // queue state, 2 ints, zero before the first launch (re-armed by the kernel)
+  float* xb;                          // exchange buffers, resblock_pair_xb_floats()
+  unsigned* xflag; unsigned* mbox; unsigned* xcount;   // [pairs][8] flags, [pairs][4] tile mailboxes, [pairs][2] tile counts: zero at creation
+  int nprob, n, T;                    // branches, slots, rows per slot (<= 32)
+  float slope;
+};
+bool resblock_pair_supported(int C, int kmax, int span_max, int T);
+size_t resblock_pair_xb_floats(int num_cu);
+bool launch_resblock_pair(const RPArgs& a, int num_cu, hipStream_t st);
+const char* resblock_pair_name(int T);
+
 // Frame-rate conv / linear of the decoder step with an optional LayerNorm in front (rowconv.hip).
 struct RowConvArgs {
   TRef x;               // input rows; with ln: the raw rows of THIS step (earlier rows come from `hist`)

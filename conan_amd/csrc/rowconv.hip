@@ -419,7 +419,8 @@ static int rc_variant(const RowConvArgs& a) {
   // a single row tile (<= 16 rows in the launch): K split over the waves of a block, one 16-column strip per block
   if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 16) == 0 && !no_ksplit) return 2;
   // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
-  return a.Cout_pad >= 1024 ? 1 : 0;
+  static const int wide_min = getenv("CONAN_RC_WIDE_MIN") ? atoi(getenv("CONAN_RC_WIDE_MIN")) : 1024;    // developer switch
+  return (a.Cout_pad >= wide_min && a.Cout_pad % 256 == 0) ? 1 : 0;
 }
 const char* rowconv_kernel_name(const RowConvArgs& a) {
   static const char* names[4] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 1, 4>", "cnk::rowlin_kernel"};

@@ -21,6 +21,8 @@ struct VocStage {
   std::vector<std::vector<Ring>> xa;        // leaky_relu(xo) for the outputs that feed another c1
   int C = 0, rate = 1;
   bool fused = false;                       // ResBlock1 units run as one tile pass each (resblock_fused.hip): no xt / activated twins
+  bool pair = false;                        // ... by pairs of workgroups (resblock_pair.hip: the wide first stage); xh = history of activated xt per unit
+  std::vector<std::vector<Ring>> xh;
 };
 
 // Small host tables (slot lists, reference lengths) go to the device through a ring of pinned staging buffers: an
@@ -75,6 +77,10 @@ struct conan_streams {
   bool rb_merge = true;         // merged-branch last-dilation launches (CONAN_RB_NOMERGE=1 at creation: separate branches + mean_act)
   int* cp_ticket[3] = {nullptr, nullptr, nullptr};   // conv_post's last-workgroup ticket, per internal stream
   int* rb_sched[2] = {nullptr, nullptr};   // work-queue counters of the fused resblock launches, per stream like the split-K workspaces
+  // resblock_pair workspaces (per stream like rb_sched): exchange buffers, and one block of zero-initialised words:
+  // [pairs][8] flags | [pairs][4] mailboxes | [pairs][2] tile counts | 2 queue words
+  float* rp_xb[2] = {nullptr, nullptr};
+  unsigned* rp_words[2] = {nullptr, nullptr};
   long long sk_slab_floats = 0;
   int sk_max_tiles = 0;
   std::vector<int> h_slots;
@@ -148,6 +154,8 @@ struct conan_streams {
   long long async_steps = 0;                   // steps enqueued since creation
   std::vector<hipEvent_t> clock_ev;            // conan_step_clock: one timing event per pipelined step, on the vocoder stream
   bool clock_on = false; int clock_n = 0;
+  std::vector<hipEvent_t> tl_ev;               // conan_step_timeline: 6 timing events per pipelined step (start / end of each stage on its stream)
+  bool tl_on = false; int tl_n = 0;
   void async_init();
   void join(hipStream_t st);                   // make `st` wait for everything enqueued by conan_step_async
 
@@ -160,6 +168,7 @@ struct conan_streams {
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : clock_ev) (void)hipEventDestroy(e);
+    for (auto& e : tl_ev) (void)hipEventDestroy(e);
   }
 
   void build_vocoder();
@@ -179,6 +188,7 @@ struct conan_streams {
   std::vector<ProfKernel> prof_kernels;          // filled by conan_profile_end: per template instantiation
   void launch_group(const ConvGroup& g, int nprob, int cfg, hipStream_t st);
   bool launch_rb(const cnk::RBArgs& a, int C, hipStream_t st, const TRef* ymean = nullptr);   // true: the launch stored the branch mean (merged)
+  void launch_rp(const cnk::RPArgs& a, hipStream_t st);
   bool use_rowconv = true;                  // frame-rate decoder layers through rowconv.hip (CONAN_ROWCONV=0: conv_mfma + LayerNorm launches)
   bool rowconv_ok(const PackedConv& pc, int dil, int T) const { return use_rowconv && pc.wf && cnk::rowconv_supported(pc.Cin, pc.k, dil, T); }
   cnk::RowConvArgs mk_rc(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, int dil = 1) const;

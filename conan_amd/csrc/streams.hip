@@ -168,6 +168,20 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   return a.merge != 0;
 }
 
+// one ResBlock1 unit per branch of the wide first stage, a pair of workgroups per (branch, stream) tile
+void conan_streams::launch_rp(const cnk::RPArgs& ain, hipStream_t st) {
+  cnk::RPArgs a = ain;
+  const int w = ws_index(st) == 1 ? 1 : 0;
+  const int pairs = ctx->num_cu / 2;
+  a.xb = rp_xb[w]; a.xflag = rp_words[w]; a.mbox = rp_words[w] + (size_t)pairs * 8; a.xcount = rp_words[w] + (size_t)pairs * 12;
+  a.sched = reinterpret_cast<int*>(rp_words[w] + (size_t)pairs * 14);
+  double fl = 0.0;
+  for (int p = 0; p < a.nprob; ++p) fl += 2.0 * 2.0 * (double)a.n * a.T * 256.0 * 256.0 * a.p[p].k;
+  profiled(cnk::resblock_pair_name(a.T), fl, st, [&] {
+    if (!cnk::launch_resblock_pair(a, ctx->num_cu, st)) throw Error(CONAN_ERR_HIP, "resblock pair launch failed");
+  });
+}
+
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
   if (n <= 0 || n > max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
   bool same = (int)h_slots.size() == n;
@@ -256,6 +270,18 @@ void conan_streams::build_vocoder() {
     for (int b = 0; b < c.voc_num_resblocks && s.fused; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d)
         s.fused = s.fused && cnk::resblock_fused_supported(ch_, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
+    // The wide first stage (C = 256): too few rows per stream for whole-width tiles - pairs of workgroups per (branch, stream)
+    // tile (resblock_pair.hip).  A tile is all rows of a stream's step, so the stream-set must not take more than 32 rows per
+    // step in this stage (windowed / whole-utterance stream-sets keep the two-launch plan), and it needs enough streams to
+    // give the chip tiles.
+    if (!s.fused && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
+        c.voc_num_resblocks <= kMaxBranches && max_slots >= (getenv("CONAN_RP_MIN_SLOTS") ? atoi(getenv("CONAN_RP_MIN_SLOTS")) : 16) && max_frames * rate <= 32) {
+      s.pair = true;
+      for (int b = 0; b < c.voc_num_resblocks; ++b)
+        for (int d = 0; d < c.voc_rb_num_dil; ++d)
+          s.pair = s.pair && cnk::resblock_pair_supported(ch_, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d], max_frames * rate);
+      s.fused = s.pair;      // ring plan of the fused stages: raw tensors only
+    }
     int up_hist = (maxk - 1) * c.voc_rb_dilations[0][0];
     if (s.fused) for (int b = 0; b < c.voc_num_resblocks; ++b) up_hist = std::max(up_hist, (c.voc_rb_kernels[b] - 1) * (c.voc_rb_dilations[b][0] + 1));
     s.up = mk_ring(ch_, rate, up_hist, &voc_state);
@@ -273,6 +299,16 @@ void conan_streams::build_vocoder() {
         s.xo[b].push_back(mk_ring(ch_, rate, h, &voc_state));
         if (!s.fused && d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
       }
+    if (s.pair) {
+      s.xh.resize(c.voc_num_resblocks);
+      for (int b = 0; b < c.voc_num_resblocks; ++b)
+        for (int d = 0; d < c.voc_rb_num_dil; ++d) s.xh[b].push_back(mk_ring(ch_, rate, c.voc_rb_kernels[b] - 1, &voc_state));
+      for (int w = 0; w < 2 && !rp_xb[w]; ++w) {
+        const int pairs = ctx->num_cu / 2;
+        rp_xb[w] = alloc(cnk::resblock_pair_xb_floats(ctx->num_cu));
+        rp_words[w] = reinterpret_cast<unsigned*>(alloc((size_t)pairs * 14 + 4));       // (alloc zero-fills)
+      }
+    }
   }
 }
 
@@ -324,7 +360,23 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       conv(a, st);
       if (taps) tap(taps->ups[i], s.up, T);
     }
-    for (int d = 0; d < ND && s.fused; ++d) {   // ResBlock1 (hifigan_causal.py:230-238): c1 -> lrelu -> c2 -> + x in one tile pass per branch
+    for (int d = 0; d < ND && s.pair; ++d) {    // ResBlock1 of the wide first stage: pairs of workgroups per (branch, stream) tile
+      if (T > 32) throw Error(CONAN_ERR_INVALID, "more frames in a step than this stream-set was created for");
+      cnk::RPArgs ra; memset(&ra, 0, sizeof(ra));
+      for (int b = 0; b < NB; ++b) {
+        const std::string base = "voc.rbf." + std::to_string(ridx + b);
+        cnk::RPProb& pr = ra.p[b];
+        pr.w1 = ctx->vec(base + ".c1." + std::to_string(d) + ".w"); pr.b1 = ctx->vec(base + ".c1." + std::to_string(d) + ".b");
+        pr.w2 = ctx->vec(base + ".c2." + std::to_string(d) + ".w"); pr.b2 = ctx->vec(base + ".c2." + std::to_string(d) + ".b");
+        pr.x = d == 0 ? s.up.ref() : s.xo[b][d - 1].ref();
+        pr.y = s.xo[b][d].ref();
+        pr.xh = s.xh[b][d].ref();
+        pr.k = c.voc_rb_kernels[b]; pr.dil = c.voc_rb_dilations[b][d];
+      }
+      ra.slots = d_slots; ra.pos = pos; ra.nprob = NB; ra.n = n; ra.T = T; ra.slope = LR;
+      launch_rp(ra, st);
+    }
+    for (int d = 0; d < ND && s.fused && !s.pair; ++d) {   // ResBlock1 (hifigan_causal.py:230-238): c1 -> lrelu -> c2 -> + x in one tile pass per branch
       cnk::RBArgs ra; memset(&ra, 0, sizeof(ra));
       for (int b = 0; b < NB; ++b) {
         const std::string base = "voc.rbf." + std::to_string(ridx + b);

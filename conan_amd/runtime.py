@@ -316,6 +316,16 @@ class Streams:
         n = _lib.check(self.lib.conan_step_clock_read(self.h, buf, cap))
         return [buf[i] for i in range(n)]
 
+    def step_timeline(self, capacity):
+        """Record start / end events of the three stages of every following pipelined step (conan_step_timeline); 0 = off."""
+        _lib.check(self.lib.conan_step_timeline(self.h, int(capacity)))
+
+    def step_timeline_read(self, cap=1024):
+        """Per recorded step [emf start, emf end, dec start, dec end, voc start, voc end] in ms since the first event."""
+        buf = (C.c_double * (cap * 6))()
+        n = _lib.check(self.lib.conan_step_timeline_read(self.h, buf, cap))
+        return [[buf[i * 6 + e] for e in range(6)] for i in range(n)]
+
     def profile_begin(self):
         _lib.check(self.lib.conan_profile_begin(self.h))
 

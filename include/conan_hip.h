@@ -259,6 +259,12 @@ int conan_profile_mark(conan_streams* s, void* stream);
  * intervals between consecutive completions in milliseconds to ms_out[cap], returning their count. */
 int conan_step_clock(conan_streams* s, int capacity);
 int conan_step_clock_read(conan_streams* s, double* ms_out, int cap);
+/* Stage timeline of pipelined steps (developer diagnostics): with capacity > 0 every following conan_step_async records timing
+ * events at the start and at the end of its Emformer, decoder and vocoder stage on their internal streams;
+ * conan_step_timeline_read writes, per recorded step, the six times in milliseconds since the first step's first event
+ * {emf start, emf end, dec start, dec end, voc start, voc end} to ms_out[cap_steps][6] and returns the number of steps. */
+int conan_step_timeline(conan_streams* s, int capacity);
+int conan_step_timeline_read(conan_streams* s, double* ms_out, int cap_steps);
 
 /* Introspection for tests / INTEGRATION.md. */
 int conan_hop_size(const conan_ctx* ctx);             /* prod(upsample_rates) */

@@ -96,3 +96,71 @@ def test_fence_free_handoffs_match_the_fenced_build_under_concurrency():
     assert not bad, f"steps whose fence-free result differs from the fenced one: {bad[:10]}"
     assert all(torch.isfinite(w).all() for _, _, w in res["plain"])
     plain.close(); fenced.close(); ctx.close()
+
+
+def test_wide_stage_pairs_match_reference_goldens():
+    """The first vocoder stage (C = 256) on stream-sets of >= 16 slots runs resblock_pair.hip: a pair of workgroups per
+    (branch, stream) tile, xt history ring instead of a halo.  Reference goldens (tools/make_goldens.py: wav_150, wav_12,
+    pre_tanh_12) streamed through slot 11 of a 24-slot stream-set while the other slots carry other streams, in steps
+    of 4 frames with a ragged tail (150 = 37 x 4 + 2; then 12 frames as 3 + 1 + 4 + 2 + 2: 24, 8, 32, 16 and 16 rows in
+    the wide stage)."""
+    from tests.conftest import load_golden
+    vhp = configs.hifigan_hparams()
+    ctx = _voc_ctx(vhp)
+    g = load_golden("hifigan_full.npz")
+    S = 24
+    st = ctx.streams(S, max_frames=4, max_ref_frames=16)
+    ids = list(range(S))
+    st.reset(ids)
+    mel = torch.from_numpy(synth.mel(150, 77, S)).cuda()                               # other streams
+    mel[11] = torch.from_numpy(g["mel_150"][0].T).cuda()
+    outs = []
+    for i in range(0, 150, 4):
+        outs.append(st.hifigan_step(ids, mel[:, i:i + 4].contiguous())[11])
+    wav = torch.cat(outs).cpu().numpy()
+    np.testing.assert_allclose(wav, g["wav_150"], atol=1e-4, rtol=0)
+    # ragged steps on a subset of the slots, pre-tanh against the golden too
+    sub = [3, 11, 20]
+    st.reset(sub)
+    m12 = torch.from_numpy(g["mel_12"]).transpose(1, 2).contiguous().cuda().expand(3, -1, -1).contiguous()
+    pres, wavs, p = [], [], 0
+    for n in (3, 1, 4, 2, 2):
+        w, pr = st.hifigan_step(sub, m12[:, p:p + n].contiguous(), want_pre_tanh=True)
+        wavs.append(w); pres.append(pr); p += n
+    wav12, pre12 = torch.cat(wavs, 1).cpu().numpy(), torch.cat(pres, 1).cpu().numpy()
+    for r in range(3):
+        np.testing.assert_allclose(wav12[r], g["wav_12"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(pre12[r], g["pre_tanh_12"][0], atol=1e-4 * max(1.0, np.abs(g["pre_tanh_12"]).max()), rtol=0)
+    st.close(); ctx.close()
+
+
+def test_wide_stage_pairs_equal_the_two_launch_plan_per_stage():
+    """Same streams through a 24-slot stream-set (pair kernel in the first stage) and through a 24-slot stream-set created
+    with CONAN_RB_NOPAIR=1 (conv_mfma two-launch plan there): per-stage tensors and audio agree to fp32 re-association."""
+    vhp = configs.hifigan_hparams()
+    ctx = _voc_ctx(vhp)
+    S = 24
+    old = os.environ.get("CONAN_RB_NOPAIR")
+    try:
+        os.environ.pop("CONAN_RB_NOPAIR", None)
+        a = ctx.streams(S, max_frames=4, max_ref_frames=16)
+        os.environ["CONAN_RB_NOPAIR"] = "1"
+        b = ctx.streams(S, max_frames=4, max_ref_frames=16)
+    finally:
+        if old is None:
+            os.environ.pop("CONAN_RB_NOPAIR", None)
+        else:
+            os.environ["CONAN_RB_NOPAIR"] = old
+    ids = list(range(S))
+    mel = torch.from_numpy(synth.mel(24, 5, S)).cuda()
+    for st in (a, b):
+        st.reset(ids)
+    for i in range(0, 24, 4):
+        wa, pa, ca, ua = a.hifigan_step_taps(ids, mel[:, i:i + 4].contiguous())
+        wb, pb, cb, ub = b.hifigan_step_taps(ids, mel[:, i:i + 4].contiguous())
+        for x, y in zip(ua, ub):
+            s = max(1.0, float(y.abs().max()))
+            assert float((x - y).abs().max()) <= 2e-5 * s
+        assert float((pa - pb).abs().max()) <= 2e-5 * max(1.0, float(pb.abs().max()))
+        assert float((wa - wb).abs().max()) <= 2e-5
+    a.close(); b.close(); ctx.close()
