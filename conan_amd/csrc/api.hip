@@ -131,6 +131,9 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
       s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
       { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
+      { const char* e = getenv("CONAN_DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
+      { const char* e = getenv("CONAN_MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }
+      s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
@@ -401,7 +404,10 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     // the mel hand-off buffer at this ring position is free once the vocoder of step t-NP has copied it into its ring
     if (t >= NP) HIP_CHECK(hipStreamWaitEvent(s->st_front, s->ev_voc[p], 0));
     if (tl) HIP_CHECK(hipEventRecord(te[2], s->st_front));
-    if (codes_dev) HIP_CHECK(hipMemcpyAsync(codes_dev, codes_seg, (size_t)n * seg * sizeof(int), hipMemcpyDeviceToDevice, s->st_front));
+    // the caller's copies of the step's codes and mel frames travel with the decoder step (operators of its one launch)
+    conan_streams::DecExtra ex;
+    if (codes_dev) { ex.codes_dst = codes_dev; ex.codes_src = codes_seg; ex.codes_words = n * seg; }
+    ex.mel_out2 = mel_out_dev;
     const int* codes_emit = codes_seg;
     if (emit != seg && n > 1) {
       int* compact = s->d_codes + (size_t)s->max_slots * s->max_frames;
@@ -409,8 +415,7 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
       codes_emit = compact;
     }
     float* mel = s->mel_hand[p];
-    if (!(skip & 2)) { conan_decoder_taps none; memset(&none, 0, sizeof(none)); s->decoder_step(n, emit, codes_emit, mel, none, s->st_front); }
-    if (mel_out_dev) HIP_CHECK(hipMemcpyAsync(mel_out_dev, mel, (size_t)n * emit * s->ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, s->st_front));
+    if (!(skip & 2)) { conan_decoder_taps none; memset(&none, 0, sizeof(none)); s->decoder_step(n, emit, codes_emit, mel, none, s->st_front, &ex); }
     if (tl) HIP_CHECK(hipEventRecord(te[3], s->st_front));
     HIP_CHECK(hipEventRecord(s->ev_front[p], s->st_front));
     HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_front[p], 0));

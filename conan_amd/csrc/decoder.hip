@@ -8,21 +8,151 @@ static cnk::LNArgs mk_ln(const TRef& x, const TRef& y, float* g, float* b, const
   return a;
 }
 
-void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st) {
+// ------------------------------------------------------------------------------------------------ operator sinks
+// Every launch of the decoder step goes through one of these (and conan_streams::rowconv / launch_group): they either
+// launch, or - while run_mega() records the step - append the operator to the megakernel's program.
+
+void conan_streams::mega_push(cnk::MegaOp& op, int lds_floats) {
+  op.barrier = 1;
+  mega_rec_lds = std::max(mega_rec_lds, lds_floats);
+  if ((int)mega_rec->size() >= kMegaMaxOps) { mega_rec_ok = false; return; }
+  mega_rec->push_back(op);
+}
+void conan_streams::op_embed(const cnk::EmbedArgs& a, hipStream_t st) {
+  if (!mega_rec) { cnk::launch_embed(a, st); return; }
+  cnk::MegaOp op; memset(&op, 0, sizeof(op));
+  op.type = cnk::MOP_EMBED; op.nbx = a.n * a.T; op.nby = 1; op.u.em = a;
+  mega_push(op, 0);
+}
+void conan_streams::op_ln(const cnk::LNArgs& a, hipStream_t st) {
+  if (!mega_rec) { cnk::launch_layernorm(a, st); return; }
+  if (a.C > 512) { mega_rec_ok = false; return; }
+  cnk::MegaOp op; memset(&op, 0, sizeof(op));
+  op.type = cnk::MOP_LN; op.nbx = (a.n * a.T + 3) / 4; op.nby = 1; op.u.ln = a;
+  mega_push(op, 0);
+}
+void conan_streams::op_xattn(const cnk::XAttnArgs& a, hipStream_t st) {
+  if (!mega_rec) { cnk::launch_xattn(a, st); return; }
+  if (a.H > 4 || a.E > 1024 || a.attn_avg) { mega_rec_ok = false; return; }
+  cnk::MegaOp op; memset(&op, 0, sizeof(op));
+  op.type = cnk::MOP_XATTN; op.nbx = a.n * a.T; op.nby = 1; op.u.xa = a;
+  cnk::MegaOp probe = op;
+  mega_push(op, cnk::decoder_mega_lds_floats(probe, 0));
+}
+void conan_streams::op_pitch(const cnk::PitchHeadArgs& a, hipStream_t st) {
+  if (!mega_rec) { cnk::launch_pitch_head(a, st); return; }
+  cnk::MegaOp op; memset(&op, 0, sizeof(op));
+  op.type = cnk::MOP_PITCH; op.nbx = (a.n * a.T + 3) / 4; op.nby = 1; op.u.ph = a;
+  const double mn = 1127.0 * log(1.0 + 50.0 / 700.0), mxx = 1127.0 * log(1.0 + 900.0 / 700.0);     // launch_pitch_head's constants
+  op.f0 = (float)mn; op.f1 = (float)(mxx - mn);
+  mega_push(op, 0);
+}
+void conan_streams::op_advance(int* pos, int n, int delta, hipStream_t st) {
+  if (!mega_rec) { cnk::launch_advance(pos, d_slots, n, delta, st); return; }
+  cnk::MegaOp op; memset(&op, 0, sizeof(op));
+  op.type = cnk::MOP_ADVANCE; op.nbx = 1; op.nby = 1;
+  op.u.adv.pos = pos; op.u.adv.slots = d_slots; op.u.adv.n = n; op.u.adv.delta = delta;
+  mega_push(op, 0);
+  mega_rec->back().barrier = 0;       // the step's last operator
+}
+
+// The decoder step as ONE persistent launch.  The operator list of a (slot count, frames, buffer set) is recorded once by
+// running decoder_ops() in recording mode, kept in a small LRU cache (the pipelined step rotates through 4 hand-off
+// buffers: 4 entries that hit for ever) and replayed.  false: this step has an operator the megakernel does not cover.
+bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out, const DecExtra& ex, hipStream_t st) {
+  const long long key[6] = {((long long)n << 32) | (unsigned)T, (long long)(uintptr_t)codes, (long long)(uintptr_t)mel_out, (long long)(uintptr_t)ex.mel_out2,
+                            (long long)(uintptr_t)ex.codes_dst, (long long)(uintptr_t)ex.codes_src ^ ((long long)ex.codes_words << 48)};
+  MegaProgram* e = nullptr;
+  for (auto& m : mega_cache) if (m.dev && memcmp(m.key, key, sizeof(key)) == 0) { e = &m; break; }
+  if (!e) {
+    if ((int)mega_cache.size() < kMegaEntries) { mega_cache.emplace_back(); e = &mega_cache.back(); }
+    else { e = &mega_cache[0]; for (auto& m : mega_cache) if (m.stamp < e->stamp) e = &m; }
+    if (!e->dev) {
+      HIP_CHECK(hipMalloc((void**)&e->dev, sizeof(cnk::MegaOp) * kMegaMaxOps));
+      HIP_CHECK(hipHostMalloc((void**)&e->pinned, sizeof(cnk::MegaOp) * kMegaMaxOps, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&e->copied, hipEventDisableTiming));
+    }
+    std::vector<cnk::MegaOp> ops;
+    mega_rec = &ops; mega_rec_ok = true; mega_rec_lds = 0; mega_rec_flops = 0.0;
+    try {
+      if (ex.codes_dst) {      // the caller's copy of the step's codes: independent of everything else
+        cnk::MegaOp op; memset(&op, 0, sizeof(op));
+        op.type = cnk::MOP_COPY32; op.nbx = 1; op.nby = 1;
+        op.u.cp.dst = reinterpret_cast<unsigned*>(ex.codes_dst); op.u.cp.src = reinterpret_cast<const unsigned*>(ex.codes_src); op.u.cp.n = ex.codes_words;
+        mega_push(op, 0);
+        ops.back().barrier = 0;
+      }
+      conan_decoder_taps none; memset(&none, 0, sizeof(none));
+      decoder_ops(n, T, codes, mel_out, none, st);
+      if (ex.mel_out2 && mega_rec_ok) {
+        // the caller's copy of the mel frames: the mel_out layer once more into the second buffer (the operator before the
+        // counter advance is mel_out; both read the same input, no barrier between them)
+        const int lt = ops.size() >= 2 ? ops[ops.size() - 2].type : -1;
+        if (ops.back().type != cnk::MOP_ADVANCE || (lt != cnk::MOP_RC111 && lt != cnk::MOP_RC114)) mega_rec_ok = false;
+        else {
+          cnk::MegaOp twin = ops[ops.size() - 2];
+          twin.u.rc.y = ch::lin_ref(ex.mel_out2, T, ctx->cfg.num_mels);
+          ops[ops.size() - 2].barrier = 0;
+          ops.insert(ops.end() - 1, twin);
+        }
+      }
+    } catch (...) { mega_rec = nullptr; throw; }
+    mega_rec = nullptr;
+    memcpy(e->key, key, sizeof(key));
+    e->ok = mega_rec_ok && !ops.empty() && (int)ops.size() <= kMegaMaxOps;
+    if (e->ok) {
+      // geometry: njobs 16-row tiles; one group per tile (at most mega_grid / 8 groups) of GS workgroups; a single tile is
+      // worked on by the whole grid as one group, with 16-column strips (K split over the waves of a workgroup)
+      int nb = 0, maxs = 1;
+      for (auto& op : ops) {
+        nb += op.barrier ? 1 : 0;
+        if (op.type <= cnk::MOP_ROWLIN) maxs = std::max(maxs, op.nbx);
+      }
+      const int njobs = (n * T + 15) / 16;
+      e->njobs = njobs; e->kw4 = 0; e->n = n; e->T = T;
+      if (njobs == 1) { e->groups = 1; e->group_size = std::max(1, std::min(mega_grid, maxs)); }
+      else { e->group_size = 8; e->groups = std::max(1, std::min(njobs, mega_grid / 8)); }
+      e->nops = (int)ops.size(); e->barriers = nb; e->flops = mega_rec_flops;
+      e->lds_bytes = mega_rec_lds * 4;
+      HIP_CHECK(hipEventSynchronize(e->copied));            // (the entry's previous upload, if any, has long completed)
+      memcpy(e->pinned, ops.data(), sizeof(cnk::MegaOp) * ops.size());
+      HIP_CHECK(hipMemcpyAsync(e->dev, e->pinned, sizeof(cnk::MegaOp) * ops.size(), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipEventRecord(e->copied, st));
+    }
+  }
+  e->stamp = ++mega_clock;
+  if (!e->ok) return false;
+  launch_mega(*e, st);
+  return true;
+}
+
+void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st, const DecExtra* extra) {
+  for (int i = 0; i < n; ++i)
+    if (!has_ref[h_slots[i]]) throw Error(CONAN_ERR_STATE, "conan_decoder_step before conan_set_reference for slot " + std::to_string(h_slots[i]) +
+                                                            " (the reference raises ValueError when ref is None)");
+  const bool notaps = !taps.uv_pred && !taps.f0_denorm_pred && !taps.pitch_bins && !taps.decoder_inp && !taps.content_embed_proj && !taps.attn[0] && !taps.attn[1];
+  DecExtra ex; if (extra) ex = *extra;
+  // (a job is a 16-row tile taken through the whole operator list by its own group of workgroups: a stream's frames of the
+  // step must all fall into one tile - 16 % frames == 0, or a single tile in all)
+  const bool tiles_ok = (16 % T == 0) || n * T <= 16;
+  if (use_mega && notaps && tiles_ok && mega_bar && run_mega(n, T, codes, mel_out, ex, st)) return;
+  if (ex.codes_dst) HIP_CHECK(hipMemcpyAsync(ex.codes_dst, ex.codes_src, (size_t)ex.codes_words * sizeof(int), hipMemcpyDeviceToDevice, st));
+  decoder_ops(n, T, codes, mel_out, taps, st);
+  if (ex.mel_out2) HIP_CHECK(hipMemcpyAsync(ex.mel_out2, mel_out, (size_t)n * T * ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, st));
+}
+
+void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st) {
   float* const uv_pred = taps.uv_pred; float* const f0 = taps.f0_denorm_pred; int32_t* const bins = taps.pitch_bins;
   float* const dec_inp = taps.decoder_inp;
   const conan_cfg& c = ctx->cfg;
   const int H = c.hidden_size;
   const int* pos = pos_dec;
-  for (int i = 0; i < n; ++i)
-    if (!has_ref[h_slots[i]]) throw Error(CONAN_ERR_STATE, "conan_decoder_step before conan_set_reference for slot " + std::to_string(h_slots[i]) +
-                                                            " (the reference raises ValueError when ref is None)");
   // content_embedding (Conan.py:140)
   {
     cnk::EmbedArgs a; memset(&a, 0, sizeof(a));
     a.y = c_emb.ref(); a.table = ctx->vec("conan.content_embedding"); a.idx = codes; a.slots = d_slots; a.pos = pos;
     a.T = T; a.n = n; a.C = H; a.vocab = c.content_vocab;
-    cnk::launch_embed(a, st);
+    op_embed(a, st);
   }
   // content_proj: CausalConv1d k3 + LeakyReLU(0.01) (Conan.py:57-60, :142); pitch_inp = content + style (Conan.py:162)
   if (rowconv_ok(ctx->conv("conan.content_proj"), 1, T)) {
@@ -62,7 +192,7 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
       cnk::XAttnArgs a; memset(&a, 0, sizeof(a));
       a.q = c_q.ref(); a.out = c_att.ref(); a.kv = c_kv + (size_t)l * S_max * 2 * H; a.kv_slot_stride = (long long)2 * S_max * 2 * H;
       a.kmask = c_kmask; a.slen = c_slen; a.attn_avg = taps.attn[l]; a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.E = H; a.H = nh; a.S_max = S_max;
-      cnk::launch_xattn(a, st);
+      op_xattn(a, st);
     }
     if (rowconv_ok(ctx->conv(nm + ".out"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T); a.res = src->ref(); a.has_res = 1; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }
@@ -71,18 +201,18 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
       a.ln = 1; a.hist = c_a2.ref(); a.gamma = ctx->vec(nm + ".norm1.g"); a.beta = ctx->vec(nm + ".norm1.b");
       a.out_act = cnk::ACT_RELU; rowconv(a, st);
     } else {
-      cnk::launch_layernorm(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
+      op_ln(mk_ln(c_a1.ref(), c_a2.ref(), ctx->vec(nm + ".norm1.g"), ctx->vec(nm + ".norm1.b"), d_slots, pos, n, T, H), st);
       ConvArgs a = mk(ctx->conv(nm + ".ff1"), c_a2.ref(), c_ff.ref(), n, T, pos); a.out_act = cnk::ACT_RELU; conv(a, st);
     }
     // ff2 (K = 2048) -> c_a1 (free again): rowlin - a 33 KB block that shares CUs with the vocoder's, where the split-K conv_mfma
     // build (126 KB of LDS) needs CUs of its own; a handful of rows (one row tile) keep the split-K build, which spreads K over blocks
-    if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && n * T > 16) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
+    if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && (n * T > 16 || mega_rec)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
     if (l == 0 && rowconv_ok(ctx->conv("conan.align.1.q"), 1, T)) n2_pending = true;      // norm2 -> c_x[0] happens in layer 1's q launch
     else {
       cnk::LNArgs ln = mk_ln(c_a1.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
       if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
-      cnk::launch_layernorm(ln, st);
+      op_ln(ln, st);
     }
     src = &c_x[0];
   }
@@ -102,7 +232,7 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
     a.gamma = ctx->vec("conan.uv.ln.g"); a.beta = ctx->vec("conan.uv.ln.b"); a.w = ctx->vec("conan.uv.lin.w"); a.b = ctx->vec("conan.uv.lin.b");
     a.pitch_embed = ctx->vec("conan.pitch_embed"); a.codes = codes; a.uv_pred = uv_pred; a.f0 = f0; a.bins = bins;
     a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.Cp = 128; a.E = H; a.silent_token = c.silent_token;
-    cnk::launch_pitch_head(a, st);
+    op_pitch(a, st);
   }
   if (dec_inp) {
     cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
@@ -134,7 +264,7 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
       }
       cnk::LNArgs ln = mk_ln(c_x[cur].ref(), lr.ref(), ctx->vec(nm + ".ln.g"), ctx->vec(nm + ".ln.b"), d_slots, pos, n, T, H);
       if (j == 0) { ln.mask_out = blkmask; ln.has_mask_out = 1; }
-      cnk::launch_layernorm(ln, st);
+      op_ln(ln, st);
       { ConvArgs a = mk(ctx->conv(nm + ".c1"), lr.ref(), c_h.ref(), n, T, pos, c.dec_dilations[b]); a.out_scale = kscale; a.out_act = cnk::ACT_GELU; conv(a, st); }
       {
         ConvArgs a = mk(ctx->conv(nm + ".c2"), c_h.ref(), c_x[cur ^ 1].ref(), n, T, pos);
@@ -153,12 +283,12 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   } else {
     cnk::LNArgs ln = mk_ln(c_x[cur].ref(), c_lastr.ref(), ctx->vec("conan.dec.last.g"), ctx->vec("conan.dec.last.b"), d_slots, pos, n, T, H);
     ln.m1 = c_mask_out.ref(); ln.has_m1 = 1;
-    cnk::launch_layernorm(ln, st);
+    op_ln(ln, st);
     ConvArgs a = mk(ctx->conv("conan.dec.post"), c_lastr.ref(), c_post.ref(), n, T, pos); a.m1 = c_mask_out.ref(); a.has_m1 = 1; conv(a, st);
   }
   if (rowconv_ok(ctx->conv("conan.mel_out"), 1, T)) rowconv(mk_rc(ctx->conv("conan.mel_out"), c_post.ref(), ch::lin_ref(mel_out, T, c.num_mels), n, T), st);
   else conv(mk(ctx->conv("conan.mel_out"), c_post.ref(), ch::lin_ref(mel_out, T, c.num_mels), n, T, pos), st);
-  cnk::launch_advance(pos_dec, d_slots, n, T, st);
+  op_advance(pos_dec, n, T, st);
 }
 
 // ------------------------------------------------------------------------------------------------ style pass

@@ -173,7 +173,7 @@ struct RowConvArgs {
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);
 void launch_rowconv(const RowConvArgs& a, hipStream_t st);
 const char* rowconv_kernel_name(const RowConvArgs& a);   // as rocprofv3 prints it
-const char* rowconv_kernel_name(const RowConvArgs& a);   // as rocprofv3 prints it
+int rowconv_plan(RowConvArgs& a, int* nbx, int* nby, int* lds_floats);   // tile geometry for the decoder megakernel
 
 // LayerNorm over the channel axis of each row:
 //   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])
@@ -325,6 +325,30 @@ void launch_mean_act(const MeanActArgs& a, hipStream_t st);
 struct ConvPostArgs { TRef x[3]; TRef xmean; int nsrc; float slope; const float* w; float bias; float* wav; float* pre; const int* slots; const int* pos; int T, n, C, k;
                       int* adv_pos; int adv_delta; int* adv_ticket; };
 void launch_conv_post(const ConvPostArgs& a, hipStream_t st);
+
+// The decoder step as ONE persistent launch (decoder_mega.hip): a list of row-wise operators (rowops.h) walked by every
+// workgroup, tiles of an operator dealt round-robin over the grid, a grid barrier between dependent operators.
+enum MegaOpType { MOP_RC111 = 0, MOP_RC114 = 1, MOP_ROWLIN = 2, MOP_LN = 3, MOP_XATTN = 4, MOP_PITCH = 5, MOP_EMBED = 6, MOP_COPY32 = 7, MOP_ADVANCE = 8 };
+struct MegaCopy { unsigned* dst; const unsigned* src; long long n; };          // n 32-bit words (plain accesses: inputs of the launch -> outputs read after it)
+struct MegaAdvance { int* pos; const int* slots; int n, delta; };              // pos[slots[q]] += delta (the step's last operator)
+struct MegaOp {
+  int type, nbx, nby;
+  int barrier;            // 1: the operators after this one read what it wrote - grid barrier behind it
+  float f0, f1;           // pitch head: mel_min, mel_max - mel_min
+  int pad_[2];
+  union U { RowConvArgs rc; LNArgs ln; XAttnArgs xa; PitchHeadArgs ph; EmbedArgs em; MegaCopy cp; MegaAdvance adv; } u;
+};
+int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats);
+// prog: device copy of nops operators.  njobs 16-row tiles are dealt over `groups` groups of `group_size` workgroups; kw4: the
+// step is one tile and its strips are 16 columns with the K loop split over a workgroup's waves.  gbar: one zero-initialised
+// counter per group, 16 words apart; bar: the grid barrier's counter, counts for ever - bar_base is its value before this
+// launch (the host adds groups * group_size per launch).
+struct MegaLaunch {
+  const MegaOp* prog; int nops, njobs, groups, group_size, kw4, lds_bytes;
+  const int* slots; const int* pos; int n, T;
+  unsigned* gbar; unsigned* bar; unsigned bar_base; unsigned long long* dbg;
+};
+void launch_decoder_mega(const MegaLaunch& m, hipStream_t st);
 
 struct ArgmaxArgs { const float* x; int* idx; int rows, C; };
 void launch_argmax(const ArgmaxArgs& a, hipStream_t st);

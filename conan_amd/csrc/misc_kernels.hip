@@ -3,6 +3,7 @@
 // per-utterance style-pass helpers.  All tensors are channel-last fp32 (see kernels.h: TRef).
 // Reductions use 64-lane wavefront shuffles; one wave owns one row.
 #include "kernels.h"
+#include "rowops.h"
 
 namespace cnk {
 
@@ -30,52 +31,7 @@ __device__ __forceinline__ float* trowptr(const TRef& r, int i, int slot, const 
 }
 
 // ------------------------------------------------------------------------------------ LayerNorm
-constexpr int LN_MAXV = 8;  // C <= 512
-__global__ __launch_bounds__(256) void layernorm_kernel(const LNArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= a.n * a.T) return;
-  const int i = m / a.T, t = m - i * a.T;
-  if (a.lens && t >= a.lens[i]) return;
-  const int slot = a.slots ? a.slots[i] : i;
-  const float* x = trowptr(a.x, i, slot, a.pos, t);
-  const float* pre = a.has_pre ? trowptr(a.pre, i, slot, a.pos, t) : nullptr;
-  float v[LN_MAXV];
-  float s = 0.f, sa = 0.f;
-#pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    int c = lane + 64 * k;
-    float u = 0.f;
-    if (c < a.C) { u = x[c]; sa += fabsf(u); if (pre) u += pre[c]; }
-    v[k] = u; s += u;
-  }
-  s = wave_sum(s);
-  const float mean = s / (float)a.C;
-  float q = 0.f;
-#pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) { int c = lane + 64 * k; if (c < a.C) { float d = v[k] - mean; q += d * d; } }
-  q = wave_sum(q);
-  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
-  float mk = 1.f;
-  if (a.has_m1) mk *= *trowptr(a.m1, i, slot, a.pos, t);
-  if (a.has_m2) mk *= *trowptr(a.m2, i, slot, a.pos, t);
-  if (a.has_mask_out) {
-    sa = wave_sum(sa);
-    if (lane == 0) *trowptr(a.mask_out, i, slot, a.pos, t) = sa > 0.f ? 1.f : 0.f;
-  }
-  float* y = trowptr(a.y, i, slot, a.pos, t);
-  const float* post = a.has_post ? trowptr(a.post, i, slot, a.pos, t) : nullptr;
-#pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    int c = lane + 64 * k;
-    if (c < a.C) {
-      float o = (v[k] - mean) * rstd * a.gamma[c] + a.beta[c];
-      if (a.has_m1 | a.has_m2) o *= mk;
-      if (post) o += post[c];
-      y[c] = o;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void layernorm_kernel(const LNArgs a) { ro::layernorm_tile<false>(a, blockIdx.x); }
 void launch_layernorm(const LNArgs& a, hipStream_t st) {
   int rows = a.n * a.T;
   if (rows <= 0) return;
@@ -99,16 +55,7 @@ void launch_copy_rows(const CopyArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(copy_rows_kernel, dim3(rows), dim3(bs), 0, st, a);
 }
 
-__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) {
-  const int m = blockIdx.x;
-  const int i = m / a.T, t = m - i * a.T;
-  const int slot = a.slots ? a.slots[i] : i;
-  int id = a.idx[m];
-  id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
-  float* y = trowptr(a.y, i, slot, a.pos, t);
-  const float* e = a.table + (long long)id * a.C;
-  for (int c = threadIdx.x; c < a.C; c += blockDim.x) y[c] = e[c];
-}
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedArgs a) { ro::embed_tile<false>(a, blockIdx.x); }
 void launch_embed(const EmbedArgs& a, hipStream_t st) {
   int rows = a.n * a.T;
   if (rows <= 0) return;
@@ -293,58 +240,10 @@ void launch_emf_mem_out(const float* x, float* out, int n, int rows, int row, in
 // ------------------------------------------------------------------------------------ cross attention
 // block = one query row (slot, t); wave h = head h.  Scores: lane-per-key dot over dh dims with q
 // broadcast from LDS; softmax by wave reductions; output: lane-per-dim sum over keys.
-constexpr int XA_MAX_S = 512;
-constexpr int XA_MAX_H = 4;
+using ro::XA_MAX_S; using ro::XA_MAX_H;
 __global__ __launch_bounds__(256) void xattn_kernel(const XAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sq[1024];
-  __shared__ float sp[XA_MAX_H][XA_MAX_S];
-  const int m = blockIdx.x;
-  const int i = m / a.T, t = m - i * a.T;
-  const int slot = a.slots[i];
-  const int S = a.slen[slot];
-  const int dh = a.E / a.H;
-  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float* q = trowptr(a.q, i, slot, a.pos, t);
-  for (int c = threadIdx.x; c < a.E; c += blockDim.x) sq[c] = q[c];
-  __syncthreads();
-  const float* kv = a.kv + (long long)slot * a.kv_slot_stride;
-  const float* km = a.kmask + (long long)slot * a.S_max;
-  if (h < a.H) {
-    float mx = -INFINITY;
-    for (int s = lane; s < S; s += 64) {
-      const float4* kp = reinterpret_cast<const float4*>(kv + (long long)s * 2 * a.E + h * dh);
-      const float4* qp = reinterpret_cast<const float4*>(sq + h * dh);
-      float sc = 0.f;
-      for (int d = 0; d < dh / 4; ++d) { float4 k4 = kp[d], q4 = qp[d]; sc += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w; }
-      sc += km[s];
-      sp[h][s] = sc;
-      mx = fmaxf(mx, sc);
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int s = lane; s < S; s += 64) { float p = expf(sp[h][s] - mx); sp[h][s] = p; sum += p; }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    for (int s = lane; s < S; s += 64) sp[h][s] *= inv;
-  }
-  __syncthreads();
-  if (h < a.H) {
-    float* o = trowptr(a.out, i, slot, a.pos, t);
-    for (int d = lane; d < dh; d += 64) {
-      float acc = 0.f;
-      const float* vp = kv + a.E + h * dh + d;
-      for (int s = 0; s < S; ++s) acc += sp[h][s] * vp[(long long)s * 2 * a.E];
-      o[h * dh + d] = acc;
-    }
-  }
-  if (a.attn_avg) {
-    float* w = a.attn_avg + ((long long)i * a.T + t) * a.S_max;
-    for (int s = threadIdx.x; s < a.S_max; s += blockDim.x) {
-      float v = 0.f;
-      if (s < S) { for (int hh = 0; hh < a.H; ++hh) v += sp[hh][s]; v /= (float)a.H; }
-      w[s] = v;
-    }
-  }
+  __shared__ __attribute__((aligned(16))) float xl[ro::XA_LDS_FLOATS];
+  ro::xattn_tile<false>(a, blockIdx.x, xl);
 }
 void launch_xattn(const XAttnArgs& a, hipStream_t st) {
   int rows = a.n * a.T;
@@ -355,52 +254,7 @@ void launch_xattn(const XAttnArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------ uv / f0 head
 // PitchPredictor tail (nar_tts_modules.py:141-146) + add_orig_pitch (Conan.py:330-340) + denorm_f0 /
 // f0_to_coarse (pitch/utils.py:71-82, :17-28) + pitch_embed add (Conan.py:301, :181); fp32 op order kept.
-__global__ __launch_bounds__(256) void pitch_head_kernel(const PitchHeadArgs a, float mel_min, float mel_den) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= a.n * a.T) return;
-  const int i = m / a.T, t = m - i * a.T;
-  const int slot = a.slots[i];
-  const float* x = trowptr(a.h, i, slot, a.pos, t);
-  float v[4];
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; v[k] = c < a.Cp ? x[c] : 0.f; s += v[k]; }
-  s = wave_sum(s);
-  const float mean = s / (float)a.Cp;
-  float q = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; if (c < a.Cp) { float d = v[k] - mean; q += d * d; } }
-  q = wave_sum(q);
-  const float rstd = 1.0f / sqrtf(q / (float)a.Cp + 1e-5f);
-  float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int c = lane + 64 * k;
-    if (c < a.Cp) { float y = (v[k] - mean) * rstd * a.gamma[c] + a.beta[c]; d0 += y * a.w[c]; d1 += y * a.w[a.Cp + c]; }
-  }
-  d0 = wave_sum(d0) + a.b[0];
-  d1 = wave_sum(d1) + a.b[1];
-  const int code = a.codes[m];
-  const bool uv = (d0 > 0.f) || (code == a.silent_token);
-  float f0 = exp2f(d1);
-  f0 = fminf(fmaxf(f0, 50.f), 900.f);
-  if (uv) f0 = 0.f;
-  float fm = 1127.f * logf(1.f + f0 / 700.f);
-  if (fm > 0.f) fm = (fm - mel_min) * 254.f / mel_den + 1.f;
-  if (fm <= 1.f) fm = 1.f;
-  if (fm > 255.f) fm = 255.f;
-  const int bin = (int)(fm + 0.5f);
-  if (lane == 0) {
-    if (a.uv_pred) { a.uv_pred[(long long)m * 2] = d0; a.uv_pred[(long long)m * 2 + 1] = d1; }
-    if (a.f0) a.f0[m] = f0;
-    if (a.bins) a.bins[m] = bin;
-  }
-  const float* pi = trowptr(a.pitch_inp, i, slot, a.pos, t);
-  float* di = trowptr(a.dec_inp, i, slot, a.pos, t);
-  const float* pe = a.pitch_embed + (long long)bin * a.E;
-  for (int c = lane; c < a.E; c += 64) di[c] = pi[c] + pe[c];
-}
+__global__ __launch_bounds__(256) void pitch_head_kernel(const PitchHeadArgs a, float mel_min, float mel_den) { ro::pitch_head_tile<false>(a, mel_min, mel_den, blockIdx.x); }
 void launch_pitch_head(const PitchHeadArgs& a, hipStream_t st) {
   int rows = a.n * a.T;
   if (rows <= 0) return;

@@ -1,0 +1,1045 @@
+// Device-side tile functions of the frame-rate (row-wise) operators of the Conan decoder step: rowconv / rowlin (conv and
+// linear layers with an optional LayerNorm prologue, rowconv.hip), LayerNorm, embedding gather, cross attention against the
+// cached prosody K/V, the uv / f0 head.  Each operator is written once, as a function of (arguments, tile index, LDS base):
+//   * the stand-alone kernels (rowconv.hip, misc_kernels.hip) are thin __global__ wrappers with COH = false;
+//   * the decoder megakernel (decoder_mega.hip) runs the whole step in ONE persistent launch, walking a list of these
+//     operators with a grid barrier between dependent ones.  Inside one launch the per-XCD L2s are not coherent, so with
+//     COH = true every activation an operator writes goes out as an agent-scope write-through store and every activation it
+//     reads comes in through an sc1 load (measured: 0 stale reads and 2.3 us per barrier round at 128 workgroups; plain
+//     accesses are 100 % stale across XCDs, release / acquire fences at the barrier cost 6.6 us per round -
+//     tools/experiments/uncached_barrier.hip).  Weights, per-utterance caches and the frame counters are read-only inside a
+//     launch and stay plain.
+#pragma once
+#include "kernels.h"
+
+namespace cnk {
+namespace ro {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gcf4;
+typedef f32x4 __attribute__((address_space(1)))* gf4;
+typedef const float __attribute__((address_space(1)))* gcf1;
+typedef float __attribute__((address_space(1)))* gf1;
+typedef const int __attribute__((address_space(1)))* gci;
+typedef unsigned long long u64;
+
+// activation accesses: plain (stand-alone kernels) or agent-scope (megakernel: write-through stores, L1-bypassing loads)
+typedef const u64 __attribute__((address_space(1)))* gcu64;
+typedef u64 __attribute__((address_space(1)))* gu64;
+template <bool COH> __device__ __forceinline__ float4 ld4(const float* p) {
+  if constexpr (COH) {
+    const u64 a = __hip_atomic_load((gcu64)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 b = __hip_atomic_load((gcu64)(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+  } else {
+    const f32x4 v = *(gcf4)(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+template <bool COH> __device__ __forceinline__ float ld1(const float* p) {
+  if constexpr (COH) return __hip_atomic_load((gcf1)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *(gcf1)(p);
+}
+template <bool COH> __device__ __forceinline__ void st4(float* p, const float4 v) {
+  if constexpr (COH) {
+    __hip_atomic_store((gu64)(p), (u64)__float_as_uint(v.x) | ((u64)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gu64)(p) + 1, (u64)__float_as_uint(v.z) | ((u64)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *(gf4)(p) = (f32x4){v.x, v.y, v.z, v.w};
+  }
+}
+template <bool COH> __device__ __forceinline__ void st1(float* p, const float v) {
+  if constexpr (COH) __hip_atomic_store((gf1)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *(gf1)(p) = v;
+}
+// read-only data (weights, biases, per-utterance caches, slot tables, frame counters)
+__device__ __forceinline__ float4 ldw4(const float* p) { const f32x4 v = *(gcf4)(p); return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ float ldw1(const float* p) { return *(gcf1)(p); }
+__device__ __forceinline__ int ldi(const int* p) { return *(gci)(p); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// row t of (batch index i / slot) of a tensor; `pos` is the slot's frame counter (ring tensors)
+// (TR: TRef, or TRef in the constant address space - the megakernel reads operator arguments where they are used, through
+// the scalar cache, instead of holding ~110 words of them in registers)
+template <class TR>
+__device__ __forceinline__ float* row(const TR& r, int i, int slot, int pos, int t) {
+  if (r.mode == 0) return r.base + (long long)slot * r.slot_stride + (long long)(((unsigned)pos * (unsigned)r.rate + (unsigned)(r.off + t)) & (unsigned)r.lmask) * r.C;
+  return r.base + (long long)i * r.slot_stride + (long long)(r.off + t) * r.C;
+}
+
+// ------------------------------------------------------------------------------------------------ rowconv
+// (see rowconv.hip for the design: 16 output rows x 64 * NCW columns per tile, LDS window with the LayerNorm applied in
+// place, fragment-major weights through a register ring, no barrier in the K loop)
+constexpr int RC_TM = 16;          // output rows per MFMA row tile
+constexpr int RC_MAXSEG = 8;       // streams a tile may touch (T >= 2)
+
+template <int NCW, int NRW, int KW, bool COH, class A>
+__device__ __forceinline__ void rowconv_tile(const A& a, const int bx, const int by, float* __restrict__ lds) {
+  static_assert(KW == 1 || (NCW == 1 && NRW == 1), "K split: one tile per wave");
+  constexpr int RC_D = (KW > 1) ? 4 : (NCW * NRW == 1) ? 8 : 4;
+  constexpr int TMB = RC_TM * NRW;                     // output rows per block
+  int tid = threadIdx.x;
+  // (megakernel: the tile loop around this function must not hoist per-lane address arithmetic out of it - the values would
+  // stay live across the whole tile and the 80-register bound is tight)
+  if constexpr (COH) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, n = a.n, Mtot = n * T;
+  // bx = column strip (fastest), by = row tile: workgroups are dealt round-robin over the 8 XCDs, so with 8 (or 4) strips
+  // an XCD always draws the same strip(s) and its L2 fetches their weights once for all row tiles
+  const int m0 = by * TMB;
+  const int ntile = bx;                               // 64*NCW output columns
+  const int Cin = a.Cin, LDX = Cin + 8, C4 = Cin >> 2;
+  const int k = a.ktaps, d = a.dil, halo = (k - 1) * d;
+  // ---- window geometry: output row r of the tile is (stream i_r, time t_r); the rows of one stream are consecutive, each
+  // stream segment is preceded by its `halo` rows of left context
+  int* const tab = reinterpret_cast<int*>(lds);        // [0..32): window row of output row r at tap 0
+  float* const win = lds + 32;                          // [wr_max][LDX]
+  __shared__ int seg_i[RC_MAXSEG + 1], seg_t0[RC_MAXSEG + 1], seg_off[RC_MAXSEG + 1], seg_slot[RC_MAXSEG + 1], seg_pos[RC_MAXSEG + 1];
+  __shared__ int s_wr;
+  // one lane per output row (wave 0): rows of one stream are consecutive; a segment starts where the stream changes.
+  // Window layout [halo_0 | rows_0 | halo_1 | rows_1 | ...]: segment s starting at tile row r0 begins at r0 + s*halo and
+  // tap 0 of tile row r reads window row r + s*halo.  The slot / position loads of all segments fly together.
+  if (tid < 64) {
+    if (tid <= RC_MAXSEG) { seg_i[tid] = -1; seg_off[tid] = 0x7fffffff; }
+    const int r = lane, m = m0 + r;
+    const bool valid = r < TMB && m < Mtot;
+    const int i = valid ? m / T : -1, t = valid ? m - i * T : 0;
+    const int iprev = __shfl_up(i, 1);
+    const bool start = valid && (r == 0 || i != iprev);
+    const unsigned long long sb = __ballot(start);
+    const int sidx = __popcll(sb & ((2ull << r) - 1ull)) - 1;
+    const int slot = start ? (a.slots ? ldi(a.slots + i) : i) : 0;
+    const int pos = start ? (a.pos ? ldi(a.pos + slot) : 0) : 0;
+    if (r < TMB) tab[r] = valid ? r + sidx * halo : 0;
+    if (start) { seg_i[sidx] = i; seg_t0[sidx] = t; seg_off[sidx] = r + sidx * halo; seg_slot[sidx] = slot; seg_pos[sidx] = pos; }
+    if (lane == 0) { const int nvalid = Mtot - m0 < TMB ? Mtot - m0 : TMB; s_wr = nvalid + __popcll(sb) * halo; }
+  }
+  __syncthreads();
+  const int WR = s_wr;
+  // ---- gather the window (raw), 8 rows-of-16-bytes per thread in flight at a time
+  auto wseg = [&](int w) __attribute__((always_inline)) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < RC_MAXSEG; ++q) s += (w >= seg_off[q]) ? 1 : 0;      // seg_off of unused segments is INT_MAX
+    return s;
+  };
+  const int total = WR * C4;
+  constexpr int GB = COH ? 4 : 8;                       // 16-byte loads per thread in flight
+  for (int e0 = 0; e0 < total; e0 += 256 * GB) {
+    float4 v[GB];
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int e = e0 + tid + 256 * u;
+      const int w = e < total ? e / C4 : 0, c4 = e < total ? e - w * C4 : 0;
+      const int sg = wseg(w);
+      const int tau = seg_t0[sg] - halo + (w - seg_off[sg]);   // time index within this step (negative: earlier steps)
+      const float* src = (a.ln && tau >= 0) ? row(a.x, seg_i[sg], seg_slot[sg], seg_pos[sg], tau)        // new rows: raw layer input
+                                            : row(a.ln ? a.hist : a.x, seg_i[sg], seg_slot[sg], seg_pos[sg], tau);   // ring (history, or plain input)
+      v[u] = ld4<COH>(src + c4 * 4);
+    }
+    const float isl = a.in_lrelu ? a.in_slope : 1.0f;      // LeakyReLU on the way in (HiFi-GAN resblock convs)
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int e = e0 + tid + 256 * u;
+      float4 q = v[u];
+      q.x *= q.x > 0.f ? 1.0f : isl; q.y *= q.y > 0.f ? 1.0f : isl; q.z *= q.z > 0.f ? 1.0f : isl; q.w *= q.w > 0.f ? 1.0f : isl;
+      if (e < total) { const int w = e / C4, c4 = e - w * C4; *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = q; }
+    }
+  }
+  __syncthreads();
+  // ---- LayerNorm of the new rows in place: 16 lanes per row, 4 rows per wave at a time; the first column tile appends
+  // them to the layer's ring and writes the block mask (row has any non-zero input: nonpadding of a residual block)
+  if (a.ln) {
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int w = wave * 4 + sub; w < ((WR + 15) & ~15); w += 16) {
+      const bool inw = w < WR;
+      const int sg = wseg(inw ? w : 0);
+      const int tau = seg_t0[sg] - halo + ((inw ? w : 0) - seg_off[sg]);
+      const bool live = inw && tau >= 0;
+      float* wrow = win + (inw ? w : 0) * LDX;
+      float4 v[8];                                          // Cin <= 512: 8 float4 per lane
+      float sum = 0.f, sa = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
+      const float mean = sum / (float)Cin;
+      float var = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+      const float rstd = 1.0f / sqrtf(var / (float)Cin + a.eps);
+      if (live) {
+        float mk = 1.f;
+        if (a.has_lnmask) mk = ld1<COH>(row(a.lnmask, seg_i[sg], seg_slot[sg], seg_pos[sg], tau));
+        float* hrow = row(a.hist, seg_i[sg], seg_slot[sg], seg_pos[sg], tau);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = (l16 + 16 * q) * 4;
+          if (c < Cin) {
+            const float4 g = ldw4(a.gamma + c), bb = ldw4(a.beta + c);
+            const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
+                                         ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
+            *reinterpret_cast<float4*>(wrow + c) = o;
+            if (ntile == 0) st4<COH>(hrow + c, o);
+          }
+        }
+        if (a.has_mask_out && ntile == 0 && l16 == 0) st1<COH>(row(a.mask_out, seg_i[sg], seg_slot[sg], seg_pos[sg], tau), sa > 0.f ? 1.f : 0.f);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- K loop: wave w owns column tiles ct0 .. ct0 + NCW - 1 of this block's strip
+  const int KQ = Cin >> 4;                              // 16-deep K groups per tap (power of two)
+  const int NG = k * KQ;
+  const int ct0 = KW > 1 ? ntile : (ntile * 4 + wave) * NCW;
+  const int g_lo = KW > 1 ? (NG / KW) * wave : 0, g_hi = KW > 1 ? g_lo + NG / KW : NG;    // NG % (KW * RC_D) == 0 (host)
+  const int lr = lane & 15, lg = lane >> 4;
+  const float* abase[NRW];
+#pragma unroll
+  for (int r = 0; r < NRW; ++r) abase[r] = win + tab[r * RC_TM + lr] * LDX + 4 * lg;
+  const long long ct_stride = (long long)(k + 1) * KQ * 256;      // floats per column tile (k taps + one zero tap)
+  const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+  const bool active = ct0 * 16 < a.Cout_pad;            // column tiles past the padded width have no weights
+  // one row tile x one column tile per wave: its MFMAs would form ONE dependent chain (40-cycle latency against a 32-cycle
+  // issue interval) - even and odd K groups accumulate separately and are summed at the end
+  constexpr int NACC = (NCW * NRW == 1) ? 2 : 1;
+  f32x4 accs[NACC][NRW][NCW];
+#pragma unroll
+  for (int s2 = 0; s2 < NACC; ++s2)
+#pragma unroll
+    for (int r = 0; r < NRW; ++r)
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) accs[s2][r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    float4 bw[RC_D][NCW];
+#pragma unroll
+    for (int u = 0; u < RC_D; ++u) {
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) bw[u][c] = ldw4(wl + c * ct_stride + (long long)(g_lo + u) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
+    const int tstep = d * LDX;
+    float4 af[NRW];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) af[r] = *reinterpret_cast<const float4*>(abase[r] + (g_lo >> kqs) * tstep + (g_lo & kqm) * 16);
+    for (int G0 = g_lo; G0 < g_hi; G0 += RC_D) {
+#pragma unroll
+      for (int u = 0; u < RC_D; ++u) {
+        const int Gn = G0 + u + 1;                      // next group's A fragments (past the end: an in-bounds dummy)
+        const int jn = Gn >> kqs, qn = Gn & kqm;
+        const int aoff = Gn < g_hi ? jn * tstep + qn * 16 : 0;
+        float4 afn[NRW];
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) afn[r] = *reinterpret_cast<const float4*>(abase[r] + aoff);
+        f32x4 (&acc)[NRW][NCW] = accs[NACC == 2 ? (u & 1) : 0];
+        // (NACC == 2: the x/z products go to this group's set, the y/w products of the same group to the other one - two
+        // interleaved chains; the sum of the two sets is the same K sum in a different association)
+        f32x4 (&acb)[NRW][NCW] = accs[NACC == 2 ? ((u & 1) ^ 1) : 0];
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].x, bw[u][c].x, acc[r][c], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acb[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].y, bw[u][c].y, acb[r][c], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].z, bw[u][c].z, acc[r][c], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acb[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r].w, bw[u][c].w, acb[r][c], 0, 0, 0);
+        // refill this ring slot with group G + RC_D (the packed weights end with a zero tap: reads past the last group stay in bounds)
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) bw[u][c] = ldw4(wl + c * ct_stride + (long long)(G0 + u + RC_D) * 256);
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) af[r] = afn[r];
+      }
+    }
+  }
+  bool fin = true;          // this wave writes outputs
+  if constexpr (KW > 1) {   // partial tiles of waves 1 .. KW-1 -> LDS (behind the window); wave 0 sums in wave order
+    float* const red = win + a.wr_max * LDX;
+    const f32x4 part = accs[0][0][0] + accs[NACC - 1][0][0];
+    if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = part;
+    __syncthreads();
+    fin = wave == 0;
+    if (fin) {
+      f32x4 sum = part;
+#pragma unroll
+      for (int w = 1; w < KW; ++w) sum += *reinterpret_cast<const f32x4*>(red + ((w - 1) * 64 + lane) * 4);
+      accs[0][0][0] = sum; accs[NACC - 1][0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // ---- epilogue: lane (g, n) holds rows 4g .. 4g+3 of column n of each of its column tiles
+  const float scale = a.out_scale;
+  const int act = a.out_act;
+  if (fin) {
+#pragma unroll
+  for (int c = 0; c < NCW; ++c) {
+    const int col = (ct0 + c) * 16 + lr;
+    if (!active || col >= a.Cout) continue;
+    const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < NRW; ++rr)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = rr * RC_TM + 4 * lg + e, m = m0 + r;
+      if (m >= Mtot) continue;
+      const int i = m / T, t = m - i * T;
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < RC_MAXSEG; ++q) if (seg_i[q] == i) s = q;
+      const int slot = seg_slot[s], pos = seg_pos[s];
+      float v = ((NACC == 2 && KW == 1 ? accs[0][rr][c][e] + accs[NACC - 1][rr][c][e] : accs[0][rr][c][e]) + bias) * scale;
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+      if (a.bvec) v += ldw1(a.bvec + (long long)slot * a.bvec_stride + col);
+      if (a.has_res) v += ld1<COH>(row(a.res, i, slot, pos, t) + col);
+      if (a.has_m1) v *= ld1<COH>(row(a.m1, i, slot, pos, t));
+      if (a.has_m2) v *= ld1<COH>(row(a.m2, i, slot, pos, t));
+      st1<COH>(row(a.y, i, slot, pos, t) + col, v);
+    }
+  }
+  }
+}
+
+// rowlin: the 1x1 layers whose input is wider than rowconv's window (aligner ff2: 2048 -> 256).  Same tile (16 rows x 64
+// columns per block, one 16-column strip per wave, fragment-major weights through an 8-deep register ring, no barrier in
+// the K loop), but the rows' channels pass through LDS in chunks of 512: gather chunk, barrier, 32 K groups, barrier.  No
+// left context (k = 1), no LayerNorm prologue; the epilogue is rowconv's.
+constexpr int RL_CW = 512, RL_LDX = RL_CW + 8, RL_D = 8;
+
+template <bool COH, class A>
+__device__ __forceinline__ void rowlin_tile(const A& a, const int bx, const int by, float* __restrict__ win) {   // win: [16][RL_LDX]
+  __shared__ int r_i[RC_TM], r_t[RC_TM], r_slot[RC_TM], r_pos[RC_TM];
+  int tid = threadIdx.x;
+  if constexpr (COH) asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, Mtot = a.n * T, Cin = a.Cin;
+  const int m0 = by * RC_TM, ntile = bx;
+  if (tid < RC_TM) {       // one lane per row: stream, time, slot, position (the loads of all rows fly together)
+    const int m = m0 + tid, mm = m < Mtot ? m : Mtot - 1;
+    const int i = mm / T, t = mm - i * T;
+    const int slot = a.slots ? ldi(a.slots + i) : i;
+    r_i[tid] = i; r_t[tid] = t; r_slot[tid] = slot; r_pos[tid] = a.pos ? ldi(a.pos + slot) : 0;
+  }
+  __syncthreads();
+  const int KQ = Cin >> 4;
+  const int ct0 = ntile * 4 + wave;
+  const int lr = lane & 15, lg = lane >> 4;
+  const float* const abase = win + lr * RL_LDX + 4 * lg;
+  const long long ct_stride = 2ll * KQ * 256;                    // one tap + the zero tap
+  const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+  const bool active = ct0 * 16 < a.Cout_pad;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // two interleaved chains (rowconv_tile)
+  float4 bw[RL_D];
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < RL_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
+  }
+  // a thread's share of a chunk: 16 rows x 128 float4 = 2048 float4 -> 8 per thread, fetched four at a time (the kernel is
+  // bounded to 80 VGPRs and the 8-deep weight ring lives across the chunks); row u of a thread is (tid >> 7) + 2 u
+  const int gw = tid >> 7, gc4 = tid & 127;
+  for (int c0 = 0; c0 < Cin; c0 += RL_CW) {
+    if (c0 > 0) __syncthreads();                                  // every wave is done with the previous chunk
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int w = gw + 2 * (4 * h + u); v[u] = ld4<COH>(row(a.x, r_i[w], r_slot[w], r_pos[w], r_t[w]) + gc4 * 4 + c0); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int w = gw + 2 * (4 * h + u); *reinterpret_cast<float4*>(win + w * RL_LDX + gc4 * 4) = v[u]; }
+    }
+    __syncthreads();
+    if (active) {
+      const int g0 = c0 >> 4;
+      float4 af = *reinterpret_cast<const float4*>(abase);
+      for (int G0 = 0; G0 < RL_CW / 16; G0 += RL_D) {
+#pragma unroll
+        for (int u = 0; u < RL_D; ++u) {
+          const int Gn = G0 + u + 1;
+          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < RL_CW / 16 ? Gn * 16 : 0));
+          f32x4& p = (u & 1) ? acc1 : acc0;
+          f32x4& q = (u & 1) ? acc0 : acc1;
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+          bw[u] = ldw4(wl + (long long)(g0 + G0 + u + RL_D) * 256);      // (past the last group: the zero tap, in bounds)
+          af = afn;
+        }
+      }
+    }
+  }
+  const int col = ct0 * 16 + lr;
+  if (active && col < a.Cout) {
+    const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * lg + e, m = m0 + r;
+      if (m >= Mtot) continue;
+      const int i = r_i[r], t = r_t[r], slot = r_slot[r], pos = r_pos[r];
+      float v = ((acc0[e] + acc1[e]) + bias) * a.out_scale;
+      if (a.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (a.out_act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (a.out_act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+      if (a.bvec) v += ldw1(a.bvec + (long long)slot * a.bvec_stride + col);
+      if (a.has_res) v += ld1<COH>(row(a.res, i, slot, pos, t) + col);
+      if (a.has_m1) v *= ld1<COH>(row(a.m1, i, slot, pos, t));
+      if (a.has_m2) v *= ld1<COH>(row(a.m2, i, slot, pos, t));
+      st1<COH>(row(a.y, i, slot, pos, t) + col, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row, 4 rows per tile:  y = (LN(x (+ pre)) * gamma + beta) * m1 * m2 (+ post), optional mask_out = (sum |x| > 0)
+constexpr int LN_MAXV = 8;  // C <= 512
+template <bool COH, class A>
+__device__ __forceinline__ void layernorm_tile(const A& a, const int bx) {
+  const int lane = threadIdx.x & 63;
+  const int m = bx * 4 + (threadIdx.x >> 6);
+  if (m >= a.n * a.T) return;
+  const int i = m / a.T, t = m - i * a.T;
+  if (a.lens && t >= ldi(a.lens + i)) return;
+  const int slot = a.slots ? ldi(a.slots + i) : i;
+  const int pos = a.pos ? ldi(a.pos + slot) : 0;
+  const float* x = row(a.x, i, slot, pos, t);
+  const float* pre = a.has_pre ? row(a.pre, i, slot, pos, t) : nullptr;
+  float v[LN_MAXV];
+  float s = 0.f, sa = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int c = lane + 64 * k;
+    float u = 0.f;
+    if (c < a.C) { u = ld1<COH>(x + c); sa += fabsf(u); if (pre) u += ld1<COH>(pre + c); }
+    v[k] = u; s += u;
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) { int c = lane + 64 * k; if (c < a.C) { float d = v[k] - mean; q += d * d; } }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  float mk = 1.f;
+  if (a.has_m1) mk *= ld1<COH>(row(a.m1, i, slot, pos, t));
+  if (a.has_m2) mk *= ld1<COH>(row(a.m2, i, slot, pos, t));
+  if (a.has_mask_out) {
+    sa = wave_sum(sa);
+    if (lane == 0) st1<COH>(row(a.mask_out, i, slot, pos, t), sa > 0.f ? 1.f : 0.f);
+  }
+  float* y = row(a.y, i, slot, pos, t);
+  const float* post = a.has_post ? row(a.post, i, slot, pos, t) : nullptr;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int c = lane + 64 * k;
+    if (c < a.C) {
+      float o = (v[k] - mean) * rstd * ldw1(a.gamma + c) + ldw1(a.beta + c);
+      if (a.has_m1 | a.has_m2) o *= mk;
+      if (post) o += ld1<COH>(post + c);
+      st1<COH>(y + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding gather
+// one row per tile: y[i][t][:] = table[idx[i][t]][:]
+template <bool COH, class A>
+__device__ __forceinline__ void embed_tile(const A& a, const int bx) {
+  const int m = bx;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = a.slots ? ldi(a.slots + i) : i;
+  const int pos = a.pos ? ldi(a.pos + slot) : 0;
+  int id = ldi(a.idx + m);
+  id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+  float* y = row(a.y, i, slot, pos, t);
+  const float* e = a.table + (long long)id * a.C;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) st1<COH>(y + c, ldw1(e + c));
+}
+
+// ------------------------------------------------------------------------------------------------ cross attention
+// tile = one query row (slot, t); wave h = head h.  Scores: lane-per-key dot over dh dims with q broadcast from LDS;
+// softmax by wave reductions; output: lane-per-dim sum over keys.  LDS: sq[1024] | sp[XA_MAX_H][XA_MAX_S] (12 KB).
+constexpr int XA_MAX_S = 512;
+constexpr int XA_MAX_H = 4;
+constexpr int XA_LDS_FLOATS = 1024 + XA_MAX_H * XA_MAX_S;
+template <bool COH, class A>
+__device__ __forceinline__ void xattn_tile(const A& a, const int bx, float* __restrict__ lds) {
+  float* const sq = lds;
+  float (*sp)[XA_MAX_S] = reinterpret_cast<float (*)[XA_MAX_S]>(lds + 1024);
+  const int m = bx;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = ldi(a.slots + i);
+  const int pos = a.pos ? ldi(a.pos + slot) : 0;
+  const int S = ldi(a.slen + slot);
+  const int dh = a.E / a.H;
+  const int h = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* q = row(a.q, i, slot, pos, t);
+  for (int c = threadIdx.x; c < a.E; c += blockDim.x) sq[c] = ld1<COH>(q + c);
+  __syncthreads();
+  const float* kv = a.kv + (long long)slot * a.kv_slot_stride;
+  const float* km = a.kmask + (long long)slot * a.S_max;
+  if (h < a.H) {
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) {
+      const float* kp = kv + (long long)s * 2 * a.E + h * dh;
+      const float4* qp = reinterpret_cast<const float4*>(sq + h * dh);
+      float sc = 0.f;
+      for (int d = 0; d < dh / 4; ++d) { float4 k4 = ldw4(kp + 4 * d), q4 = qp[d]; sc += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w; }
+      sc += ldw1(km + s);
+      sp[h][s] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) { float p = expf(sp[h][s] - mx); sp[h][s] = p; sum += p; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int s = lane; s < S; s += 64) sp[h][s] *= inv;
+  }
+  __syncthreads();
+  if (h < a.H) {
+    float* o = row(a.out, i, slot, pos, t);
+    for (int d = lane; d < dh; d += 64) {
+      float acc = 0.f;
+      const float* vp = kv + a.E + h * dh + d;
+      for (int s = 0; s < S; ++s) acc += sp[h][s] * ldw1(vp + (long long)s * 2 * a.E);
+      st1<COH>(o + h * dh + d, acc);
+    }
+  }
+  if (a.attn_avg) {      // (a tap for the caller: read after the launch, plain stores)
+    float* w = a.attn_avg + ((long long)i * a.T + t) * a.S_max;
+    for (int s = threadIdx.x; s < a.S_max; s += blockDim.x) {
+      float v = 0.f;
+      if (s < S) { for (int hh = 0; hh < a.H; ++hh) v += sp[hh][s]; v /= (float)a.H; }
+      w[s] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ uv / f0 head
+// PitchPredictor tail (nar_tts_modules.py:141-146) + add_orig_pitch (Conan.py:330-340) + denorm_f0 /
+// f0_to_coarse (pitch/utils.py:71-82, :17-28) + pitch_embed add (Conan.py:301, :181); fp32 op order kept.  4 rows per tile.
+template <bool COH, class A>
+__device__ __forceinline__ void pitch_head_tile(const A& a, const float mel_min, const float mel_den, const int bx) {
+  const int lane = threadIdx.x & 63;
+  const int m = bx * 4 + (threadIdx.x >> 6);
+  if (m >= a.n * a.T) return;
+  const int i = m / a.T, t = m - i * a.T;
+  const int slot = ldi(a.slots + i);
+  const int pos = a.pos ? ldi(a.pos + slot) : 0;
+  const float* x = row(a.h, i, slot, pos, t);
+  float v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; v[k] = c < a.Cp ? ld1<COH>(x + c) : 0.f; s += v[k]; }
+  s = wave_sum(s);
+  const float mean = s / (float)a.Cp;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; if (c < a.Cp) { float d = v[k] - mean; q += d * d; } }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)a.Cp + 1e-5f);
+  float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = lane + 64 * k;
+    if (c < a.Cp) { float y = (v[k] - mean) * rstd * ldw1(a.gamma + c) + ldw1(a.beta + c); d0 += y * ldw1(a.w + c); d1 += y * ldw1(a.w + a.Cp + c); }
+  }
+  d0 = wave_sum(d0) + ldw1(a.b);
+  d1 = wave_sum(d1) + ldw1(a.b + 1);
+  const int code = ldi(a.codes + m);
+  const bool uv = (d0 > 0.f) || (code == a.silent_token);
+  float f0 = exp2f(d1);
+  f0 = fminf(fmaxf(f0, 50.f), 900.f);
+  if (uv) f0 = 0.f;
+  float fm = 1127.f * logf(1.f + f0 / 700.f);
+  if (fm > 0.f) fm = (fm - mel_min) * 254.f / mel_den + 1.f;
+  if (fm <= 1.f) fm = 1.f;
+  if (fm > 255.f) fm = 255.f;
+  const int bin = (int)(fm + 0.5f);
+  if (lane == 0) {
+    if (a.uv_pred) { a.uv_pred[(long long)m * 2] = d0; a.uv_pred[(long long)m * 2 + 1] = d1; }
+    if (a.f0) a.f0[m] = f0;
+    if (a.bins) a.bins[m] = bin;
+  }
+  const float* pi = row(a.pitch_inp, i, slot, pos, t);
+  float* di = row(a.dec_inp, i, slot, pos, t);
+  const float* pe = a.pitch_embed + (long long)bin * a.E;
+  for (int c = lane; c < a.E; c += 64) st1<COH>(di + c, ld1<COH>(pi + c) + ldw1(pe + c));
+}
+
+// ================================================================================================ decoder megakernel
+// The same operators restructured for decoder_mega.hip: a JOB is one 16-row tile taken through the whole operator list by a
+// group of workgroups.  The tile's row table (stream, frame, slot, frame counter per row) is built once per job; a conv /
+// linear operator is split into mg_stage (gather the input window, LayerNorm in place - once per member and operator) and
+// mg_strip (K loop + epilogue of one output strip); row-wise operators take (row of the tile) instead of (tile).  All
+// activation accesses are agent-scope (COH).
+struct RowTab {
+  int nvalid, nseg;                       // rows of the tile inside the step, stream segments among them
+  int row_seg[RC_TM];                     // segment of tile row r
+  int seg_i[RC_MAXSEG + 1], seg_t0[RC_MAXSEG + 1], seg_r0[RC_MAXSEG + 1], seg_slot[RC_MAXSEG + 1], seg_pos[RC_MAXSEG + 1];
+  int tab[RC_TM];                         // per operator: window row of tile row r at tap 0
+};
+constexpr int ROWTAB_FLOATS = 96;
+static_assert(sizeof(RowTab) <= ROWTAB_FLOATS * 4, "row table");
+
+// rows of one stream are consecutive; a segment starts where the stream changes (wave 0; callers synchronise around it)
+__device__ __forceinline__ void rowtab_setup(RowTab& tb, const int* slots, const int* pos, const int n, const int T, const int m0) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int lane = tid;
+    if (lane <= RC_MAXSEG) { tb.seg_i[lane] = -1; tb.seg_r0[lane] = 0x3fffffff; tb.seg_t0[lane] = 0; tb.seg_slot[lane] = 0; tb.seg_pos[lane] = 0; }
+    const int Mtot = n * T;
+    const int r = lane, m = m0 + r;
+    const bool valid = r < RC_TM && m < Mtot;
+    const int i = valid ? m / T : -1, t = valid ? m - i * T : 0;
+    const int iprev = __shfl_up(i, 1);
+    const bool start = valid && (r == 0 || i != iprev);
+    const unsigned long long sbm = __ballot(start);
+    const int sidx = __popcll(sbm & ((2ull << r) - 1ull)) - 1;
+    const int slot = start ? (slots ? ldi(slots + i) : i) : 0;
+    const int ps = start ? (pos ? ldi(pos + slot) : 0) : 0;
+    if (r < RC_TM) tb.row_seg[r] = valid ? sidx : 0;
+    if (start) { tb.seg_i[sidx] = i; tb.seg_t0[sidx] = t; tb.seg_r0[sidx] = r; tb.seg_slot[sidx] = slot; tb.seg_pos[sidx] = ps; }
+    if (lane == 0) { tb.nvalid = Mtot - m0 < RC_TM ? (Mtot - m0 > 0 ? Mtot - m0 : 0) : RC_TM; tb.nseg = __popcll(sbm); }
+  }
+}
+// stream index / frame / slot / frame counter of tile row r
+struct RowId { int i, t, slot, pos; };
+__device__ __forceinline__ RowId row_id(const RowTab& tb, const int r) {
+  const int s = tb.row_seg[r];
+  return RowId{tb.seg_i[s], tb.seg_t0[s] + (r - tb.seg_r0[s]), tb.seg_slot[s], tb.seg_pos[s]};
+}
+
+// gather the tile's input window of operator `a` into LDS (win = lds: [wr_max][Cin + 8]), LayerNorm of the new rows in place;
+// `first` (the member that owns strip 0) appends the normalised rows to the layer's ring and writes the block mask
+template <class A>
+__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const bool first) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));             // (no hoisting of per-lane arithmetic out of this function: the 80-register bound is tight)
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cin = a.Cin, LDX = Cin + 8, C4 = Cin >> 2;
+  const int k = a.ktaps, d = a.dil, halo = (k - 1) * d;
+  __syncthreads();                          // every wave is done with the previous operator's window
+  if (tid < RC_TM) tb.tab[tid] = tid < tb.nvalid ? tid + tb.row_seg[tid] * halo : 0;
+  const int WR = tb.nvalid + tb.nseg * halo;
+  auto wseg = [&](int w) __attribute__((always_inline)) {
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < RC_MAXSEG; ++q) s += (w >= tb.seg_r0[q] + q * halo) ? 1 : 0;      // seg_r0 of unused segments is huge
+    return s;
+  };
+  const int total = WR * C4;
+  constexpr int GB = 4;
+  for (int e0 = 0; e0 < total; e0 += 256 * GB) {
+    float4 v[GB];
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int e = e0 + tid + 256 * u;
+      const int w = e < total ? e / C4 : 0, c4 = e < total ? e - w * C4 : 0;
+      const int sg = wseg(w);
+      const int tau = tb.seg_t0[sg] - halo + (w - (tb.seg_r0[sg] + sg * halo));   // time index within this step (negative: earlier steps)
+      const float* src = (a.ln && tau >= 0) ? row(a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau)
+                                            : row(a.ln ? a.hist : a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau);
+      v[u] = ld4<true>(src + c4 * 4);
+    }
+    const float isl = a.in_lrelu ? a.in_slope : 1.0f;
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int e = e0 + tid + 256 * u;
+      float4 q = v[u];
+      q.x *= q.x > 0.f ? 1.0f : isl; q.y *= q.y > 0.f ? 1.0f : isl; q.z *= q.z > 0.f ? 1.0f : isl; q.w *= q.w > 0.f ? 1.0f : isl;
+      if (e < total) { const int w = e / C4, c4 = e - w * C4; *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = q; }
+    }
+  }
+  __syncthreads();
+  if (a.ln) {
+    const int sub = lane >> 4, l16 = lane & 15;
+    for (int w = wave * 4 + sub; w < ((WR + 15) & ~15); w += 16) {
+      const bool inw = w < WR;
+      const int sg = wseg(inw ? w : 0);
+      const int tau = tb.seg_t0[sg] - halo + ((inw ? w : 0) - (tb.seg_r0[sg] + sg * halo));
+      const bool live = inw && tau >= 0;
+      float* wrow = win + (inw ? w : 0) * LDX;
+      float4 v[8];                                          // Cin <= 512: 8 float4 per lane
+      float sum = 0.f, sa = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
+      const float mean = sum / (float)Cin;
+      float var = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+      const float rstd = 1.0f / sqrtf(var / (float)Cin + a.eps);
+      if (live) {
+        float mk = 1.f;
+        if (a.has_lnmask) mk = ld1<true>(row(a.lnmask, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau));
+        float* hrow = row(a.hist, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = (l16 + 16 * q) * 4;
+          if (c < Cin) {
+            const float4 g = ldw4(a.gamma + c), bb = ldw4(a.beta + c);
+            const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
+                                         ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
+            *reinterpret_cast<float4*>(wrow + c) = o;
+            if (first) st4<true>(hrow + c, o);
+          }
+        }
+        if (a.has_mask_out && first && l16 == 0) st1<true>(row(a.mask_out, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau), sa > 0.f ? 1.f : 0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// K loop + epilogue of output strip bx of the staged operator: 64 columns (one 16-column tile per wave), or - KW = 4, a single
+// row tile in the step - 16 columns with the K groups split over the 4 waves (partial tiles meet in LDS behind the window)
+template <int KW, class A>
+__device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win) {
+  constexpr int RC_D = (KW > 1) ? 4 : 8;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cin = a.Cin, LDX = Cin + 8;
+  const int k = a.ktaps, d = a.dil;
+  const int KQ = Cin >> 4;
+  const int NG = k * KQ;
+  const int ct0 = KW > 1 ? bx : bx * 4 + wave;
+  const int g_lo = KW > 1 ? (NG / KW) * wave : 0, g_hi = KW > 1 ? g_lo + NG / KW : NG;
+  const int lr = lane & 15, lg = lane >> 4;
+  const float* const abase = win + tb.tab[lr] * LDX + 4 * lg;
+  const long long ct_stride = (long long)(k + 1) * KQ * 256;
+  const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+  const bool active = ct0 * 16 < a.Cout_pad;
+  f32x4 accs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};     // two interleaved chains (rowconv_tile)
+  if (active) {
+    float4 bw[RC_D];
+#pragma unroll
+    for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)(g_lo + u) * 256); __builtin_amdgcn_sched_barrier(0); }
+    const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
+    const int tstep = d * LDX;
+    float4 af = *reinterpret_cast<const float4*>(abase + (g_lo >> kqs) * tstep + (g_lo & kqm) * 16);
+    for (int G0 = g_lo; G0 < g_hi; G0 += RC_D) {
+#pragma unroll
+      for (int u = 0; u < RC_D; ++u) {
+        const int Gn = G0 + u + 1;
+        const int jn = Gn >> kqs, qn = Gn & kqm;
+        const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < g_hi ? jn * tstep + qn * 16 : 0));
+        f32x4& p = accs[u & 1];
+        f32x4& q = accs[(u & 1) ^ 1];
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+        q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+        q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+        bw[u] = ldw4(wl + (long long)(G0 + u + RC_D) * 256);      // (past the last group: the zero tap, in bounds)
+        af = afn;
+      }
+    }
+  }
+  bool fin = true;
+  f32x4 res = accs[0] + accs[1];
+  if constexpr (KW > 1) {
+    float* const red = win + a.wr_max * LDX;
+    __syncthreads();                       // wave 0 has read the previous strip's partial tiles
+    if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = res;
+    __syncthreads();
+    fin = wave == 0;
+    if (fin) {
+#pragma unroll
+      for (int w = 1; w < KW; ++w) res += *reinterpret_cast<const f32x4*>(red + ((w - 1) * 64 + lane) * 4);
+    }
+  }
+  const int col = ct0 * 16 + lr;
+  if (fin && active && col < a.Cout) {
+    const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
+    const float scale = a.out_scale;
+    const int act = a.out_act;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * lg + e;
+      if (r >= tb.nvalid) continue;
+      const RowId id = row_id(tb, r);
+      float v = (res[e] + bias) * scale;
+      if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+      if (a.bvec) v += ldw1(a.bvec + (long long)id.slot * a.bvec_stride + col);
+      if (a.has_res) v += ld1<true>(row(a.res, id.i, id.slot, id.pos, id.t) + col);
+      if (a.has_m1) v *= ld1<true>(row(a.m1, id.i, id.slot, id.pos, id.t));
+      if (a.has_m2) v *= ld1<true>(row(a.m2, id.i, id.slot, id.pos, id.t));
+      st1<true>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v);
+    }
+  }
+}
+
+// one 64-column strip of a 1x1 layer wider than the window (aligner ff2): the rows' channels pass through LDS in chunks of 512
+template <class A>
+__device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win) {   // win: [16][RL_LDX]
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Cin = a.Cin;
+  const int KQ = Cin >> 4;
+  const int ct0 = bx * 4 + wave;
+  const int lr = lane & 15, lg = lane >> 4;
+  const float* const abase = win + lr * RL_LDX + 4 * lg;
+  const long long ct_stride = 2ll * KQ * 256;
+  const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+  const bool active = ct0 * 16 < a.Cout_pad;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float4 bw[RL_D];
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < RL_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
+  }
+  const int gw = tid >> 7, gc4 = tid & 127;
+  for (int c0 = 0; c0 < Cin; c0 += RL_CW) {
+    __syncthreads();                                              // every wave is done with the previous chunk / operator
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w = gw + 2 * (4 * h + u);
+        const RowId id = row_id(tb, w < tb.nvalid ? w : 0);
+        v[u] = ld4<true>(row(a.x, id.i, id.slot, id.pos, id.t) + gc4 * 4 + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int w = gw + 2 * (4 * h + u); *reinterpret_cast<float4*>(win + w * RL_LDX + gc4 * 4) = v[u]; }
+    }
+    __syncthreads();
+    if (active) {
+      const int g0 = c0 >> 4;
+      float4 af = *reinterpret_cast<const float4*>(abase);
+      for (int G0 = 0; G0 < RL_CW / 16; G0 += RL_D) {
+#pragma unroll
+        for (int u = 0; u < RL_D; ++u) {
+          const int Gn = G0 + u + 1;
+          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < RL_CW / 16 ? Gn * 16 : 0));
+          f32x4& p = (u & 1) ? acc1 : acc0;
+          f32x4& q = (u & 1) ? acc0 : acc1;
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+          bw[u] = ldw4(wl + (long long)(g0 + G0 + u + RL_D) * 256);
+          af = afn;
+        }
+      }
+    }
+  }
+  const int col = ct0 * 16 + lr;
+  if (active && col < a.Cout) {
+    const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * lg + e;
+      if (r >= tb.nvalid) continue;
+      const RowId id = row_id(tb, r);
+      float v = ((acc0[e] + acc1[e]) + bias) * a.out_scale;
+      if (a.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (a.out_act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+      else if (a.out_act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+      if (a.bvec) v += ldw1(a.bvec + (long long)id.slot * a.bvec_stride + col);
+      if (a.has_res) v += ld1<true>(row(a.res, id.i, id.slot, id.pos, id.t) + col);
+      if (a.has_m1) v *= ld1<true>(row(a.m1, id.i, id.slot, id.pos, id.t));
+      if (a.has_m2) v *= ld1<true>(row(a.m2, id.i, id.slot, id.pos, id.t));
+      st1<true>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v);
+    }
+  }
+}
+
+// LayerNorm of tile row r (one wave)
+template <class A>
+__device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, const int r) {
+  if (r >= tb.nvalid) return;
+  const int lane = threadIdx.x & 63;
+  const RowId id = row_id(tb, r);
+  const float* x = row(a.x, id.i, id.slot, id.pos, id.t);
+  const float* pre = a.has_pre ? row(a.pre, id.i, id.slot, id.pos, id.t) : nullptr;
+  float v[LN_MAXV];
+  float s = 0.f, sa = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int c = lane + 64 * k;
+    float u = 0.f;
+    if (c < a.C) { u = ld1<true>(x + c); sa += fabsf(u); if (pre) u += ld1<true>(pre + c); }
+    v[k] = u; s += u;
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) { int c = lane + 64 * k; if (c < a.C) { float d = v[k] - mean; q += d * d; } }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  float mk = 1.f;
+  if (a.has_m1) mk *= ld1<true>(row(a.m1, id.i, id.slot, id.pos, id.t));
+  if (a.has_m2) mk *= ld1<true>(row(a.m2, id.i, id.slot, id.pos, id.t));
+  if (a.has_mask_out) {
+    sa = wave_sum(sa);
+    if (lane == 0) st1<true>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f);
+  }
+  float* y = row(a.y, id.i, id.slot, id.pos, id.t);
+  const float* post = a.has_post ? row(a.post, id.i, id.slot, id.pos, id.t) : nullptr;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    int c = lane + 64 * k;
+    if (c < a.C) {
+      float o = (v[k] - mean) * rstd * ldw1(a.gamma + c) + ldw1(a.beta + c);
+      if (a.has_m1 | a.has_m2) o *= mk;
+      if (post) o += ld1<true>(post + c);
+      st1<true>(y + c, o);
+    }
+  }
+}
+
+// embedding row r of the tile (one wave)
+template <class A>
+__device__ __forceinline__ void mg_embed_row(const A& a, const RowTab& tb, const int r) {
+  if (r >= tb.nvalid) return;
+  const int lane = threadIdx.x & 63;
+  const RowId id = row_id(tb, r);
+  int idx = ldi(a.idx + id.i * a.T + id.t);
+  idx = idx < 0 ? 0 : (idx >= a.vocab ? a.vocab - 1 : idx);
+  float* y = row(a.y, id.i, id.slot, id.pos, id.t);
+  const float* e = a.table + (long long)idx * a.C;
+  for (int c = lane; c < a.C; c += 64) st1<true>(y + c, ldw1(e + c));
+}
+
+// cross attention of tile rows r0, r0 + 1 (two heads: waves 0-1 take row r0, waves 2-3 row r0 + 1); LDS: 2 x [sq 1024 | sp 2 x 512]
+constexpr int XA2_LDS_FLOATS = 1024 + 2 * XA_MAX_S;
+template <class A>
+__device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, const int r0, float* __restrict__ lds) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = wv >> 1, h = wv & 1, ht = threadIdx.x & 127;
+  const int r = r0 + half;
+  const bool live = r < tb.nvalid;
+  float* const sq = lds + half * XA2_LDS_FLOATS;
+  float (*sp)[XA_MAX_S] = reinterpret_cast<float (*)[XA_MAX_S]>(sq + 1024);
+  const RowId id = row_id(tb, live ? r : 0);
+  const int S = ldi(a.slen + id.slot);
+  const int dh = a.E / a.H;
+  if (live) { const float* q = row(a.q, id.i, id.slot, id.pos, id.t); for (int c = ht; c < a.E; c += 128) sq[c] = ld1<true>(q + c); }
+  __syncthreads();
+  const float* kv = a.kv + (long long)id.slot * a.kv_slot_stride;
+  const float* km = a.kmask + (long long)id.slot * a.S_max;
+  if (live && h < a.H) {
+    float mx = -INFINITY;
+    for (int s = lane; s < S; s += 64) {
+      const float* kp = kv + (long long)s * 2 * a.E + h * dh;
+      const float4* qp = reinterpret_cast<const float4*>(sq + h * dh);
+      float sc = 0.f;
+      for (int d = 0; d < dh / 4; ++d) { float4 k4 = ldw4(kp + 4 * d), q4 = qp[d]; sc += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w; }
+      sc += ldw1(km + s);
+      sp[h][s] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < S; s += 64) { float p = expf(sp[h][s] - mx); sp[h][s] = p; sum += p; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int s = lane; s < S; s += 64) sp[h][s] *= inv;
+  }
+  __syncthreads();
+  if (live && h < a.H) {
+    float* o = row(a.out, id.i, id.slot, id.pos, id.t);
+    for (int d = lane; d < dh; d += 64) {
+      float acc = 0.f;
+      const float* vp = kv + a.E + h * dh + d;
+      for (int s = 0; s < S; ++s) acc += sp[h][s] * ldw1(vp + (long long)s * 2 * a.E);
+      st1<true>(o + h * dh + d, acc);
+    }
+  }
+}
+
+// uv / f0 head of tile row r (one wave)
+template <class A>
+__device__ __forceinline__ void mg_pitch_row(const A& a, const RowTab& tb, const float mel_min, const float mel_den, const int r) {
+  if (r >= tb.nvalid) return;
+  const int lane = threadIdx.x & 63;
+  const RowId id = row_id(tb, r);
+  const int m = id.i * a.T + id.t;
+  const float* x = row(a.h, id.i, id.slot, id.pos, id.t);
+  float v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; v[k] = c < a.Cp ? ld1<true>(x + c) : 0.f; s += v[k]; }
+  s = wave_sum(s);
+  const float mean = s / (float)a.Cp;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; if (c < a.Cp) { float d = v[k] - mean; q += d * d; } }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)a.Cp + 1e-5f);
+  float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = lane + 64 * k;
+    if (c < a.Cp) { float y = (v[k] - mean) * rstd * ldw1(a.gamma + c) + ldw1(a.beta + c); d0 += y * ldw1(a.w + c); d1 += y * ldw1(a.w + a.Cp + c); }
+  }
+  d0 = wave_sum(d0) + ldw1(a.b);
+  d1 = wave_sum(d1) + ldw1(a.b + 1);
+  const int code = ldi(a.codes + m);
+  const bool uv = (d0 > 0.f) || (code == a.silent_token);
+  float f0 = exp2f(d1);
+  f0 = fminf(fmaxf(f0, 50.f), 900.f);
+  if (uv) f0 = 0.f;
+  float fm = 1127.f * logf(1.f + f0 / 700.f);
+  if (fm > 0.f) fm = (fm - mel_min) * 254.f / mel_den + 1.f;
+  if (fm <= 1.f) fm = 1.f;
+  if (fm > 255.f) fm = 255.f;
+  const int bin = (int)(fm + 0.5f);
+  const float* pi = row(a.pitch_inp, id.i, id.slot, id.pos, id.t);
+  float* di = row(a.dec_inp, id.i, id.slot, id.pos, id.t);
+  const float* pe = a.pitch_embed + (long long)bin * a.E;
+  for (int c = lane; c < a.E; c += 64) st1<true>(di + c, ld1<true>(pi + c) + ldw1(pe + c));
+}
+
+}  // namespace ro
+}  // namespace cnk

@@ -159,7 +159,9 @@ struct conan_streams {
   void async_init();
   void join(hipStream_t st);                   // make `st` wait for everything enqueued by conan_step_async
 
+  void mega_print_stamps();
   ~conan_streams() {
+    if (mega_dbg) mega_print_stamps();
     if (st_emf) (void)hipStreamDestroy(st_emf);
     if (st_front) (void)hipStreamDestroy(st_front);
     if (st_voc) (void)hipStreamDestroy(st_voc);
@@ -168,6 +170,7 @@ struct conan_streams {
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : clock_ev) (void)hipEventDestroy(e);
+    for (auto& m : mega_cache) { if (m.copied) (void)hipEventDestroy(m.copied); if (m.pinned) (void)hipHostFree(m.pinned); if (m.dev) (void)hipFree(m.dev); }
     for (auto& e : tl_ev) (void)hipEventDestroy(e);
   }
 
@@ -197,9 +200,43 @@ struct conan_streams {
   void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;
 
+  // --- decoder megakernel (decoder_mega.hip): the decoder step's operator list, recorded once per (slot count, frames,
+  // buffer set) and replayed as one persistent launch
+  struct DecExtra { float* mel_out2 = nullptr; int* codes_dst = nullptr; const int* codes_src = nullptr; int codes_words = 0; };
+  struct MegaProgram {
+    long long key[6] = {0, 0, 0, 0, 0, 0};
+    bool ok = false;
+    int nops = 0, groups = 0, group_size = 0, njobs = 0, kw4 = 0, lds_bytes = 0, barriers = 0, n = 0, T = 0;
+    double flops = 0.0;
+    cnk::MegaOp* dev = nullptr;        // device copy (capacity kMegaMaxOps)
+    cnk::MegaOp* pinned = nullptr;     // host staging of this entry; reused only after `copied` has fired
+    hipEvent_t copied = nullptr;
+    long long stamp = 0;               // least-recently-used replacement
+  };
+  static constexpr int kMegaMaxOps = 80, kMegaEntries = 12;
+  std::vector<MegaProgram> mega_cache;
+  long long mega_clock = 0;
+  bool use_mega = true;                          // CONAN_DEC_MEGA=0: the decoder step as separate launches
+  int mega_grid = 128;                           // CONAN_MEGA_GRID
+  unsigned* mega_bar = nullptr;                  // the grid barrier's arrival counter (counts for ever); the group counters follow it, 16 words apart
+  unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished
+  unsigned long long* mega_dbg = nullptr;        // CONAN_MEGA_STAMPS=1: per-operator clock stamps of the last launch (printed at destruction)
+  const MegaProgram* mega_dbg_prog = nullptr;
+  std::vector<cnk::MegaOp>* mega_rec = nullptr;  // != nullptr: decoder_ops() records its operators instead of launching them
+  bool mega_rec_ok = true; int mega_rec_lds = 0; double mega_rec_flops = 0.0;
+  void mega_push(cnk::MegaOp& op, int lds_floats);
+  bool run_mega(int n, int T, const int32_t* codes, float* mel_out, const DecExtra& ex, hipStream_t st);
+  void launch_mega(MegaProgram& e, hipStream_t st);
+  void decoder_ops(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st);
+  void op_embed(const cnk::EmbedArgs& a, hipStream_t st);
+  void op_ln(const cnk::LNArgs& a, hipStream_t st);
+  void op_xattn(const cnk::XAttnArgs& a, hipStream_t st);
+  void op_pitch(const cnk::PitchHeadArgs& a, hipStream_t st);
+  void op_advance(int* pos, int n, int delta, hipStream_t st);
+
   void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps = nullptr);
   void emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st);
-  void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st);
+  void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st, const DecExtra* extra = nullptr);
   void set_reference(const int32_t* slots, int n, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st);
   void conv_blocks_noncausal(const std::string& name, int nblocks, int k, int C, Lin* x, Lin& ln, Lin& h, Lin& blkm, const TRef& npm,
                              const int* lens, int n, int T, int& cur, hipStream_t st);

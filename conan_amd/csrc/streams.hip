@@ -48,6 +48,7 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
 }
 
 void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipStream_t st) {
+  if (mega_rec) { mega_rec_ok = false; return; }      // (a conv_mfma layer is not a megakernel operator: that step keeps its separate launches)
   ConvGroup g = gin;
   for (int p = 0; p < nprob; ++p) {
     // layers that touch no per-slot ring need neither the slot table nor the position counters: dropping them
@@ -141,6 +142,16 @@ cnk::RowConvArgs conan_streams::mk_rc(const PackedConv& pc, const TRef& x, const
 
 void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
   const double fl = 2.0 * (double)a.n * a.T * a.Cout * a.ktaps * a.Cin;
+  if (mega_rec) {      // recording the decoder step's operator list (decoder_mega.hip)
+    cnk::MegaOp op; memset(&op, 0, sizeof(op));
+    op.u.rc = a;
+    int ldsf = 0;
+    const int v = cnk::rowconv_plan(op.u.rc, &op.nbx, &op.nby, &ldsf);
+    op.type = v == 3 ? cnk::MOP_ROWLIN : (v == 2 ? cnk::MOP_RC114 : cnk::MOP_RC111);
+    mega_rec_flops += fl;
+    mega_push(op, ldsf);
+    return;
+  }
   profiled(cnk::rowconv_kernel_name(a), fl, st, [&] { cnk::launch_rowconv(a, st); });
 }
 
@@ -180,6 +191,35 @@ void conan_streams::launch_rp(const cnk::RPArgs& ain, hipStream_t st) {
   profiled(cnk::resblock_pair_name(a.T), fl, st, [&] {
     if (!cnk::launch_resblock_pair(a, ctx->num_cu, st)) throw Error(CONAN_ERR_HIP, "resblock pair launch failed");
   });
+}
+
+void conan_streams::mega_print_stamps() {
+  if (!mega_dbg || !mega_dbg_prog) return;
+  (void)hipDeviceSynchronize();
+  const MegaProgram& e = *mega_dbg_prog;
+  std::vector<unsigned long long> h(e.nops + 2);
+  if (hipMemcpy(h.data(), mega_dbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+  static const char* names[] = {"rowconv<1,1,1>", "rowconv<1,1,4>", "rowlin", "layernorm", "xattn", "pitch_head", "embed", "copy32", "advance"};
+  fprintf(stderr, "[decoder_mega] last launch: %d groups x %d workgroups, %d jobs, %d operators, %d group barriers, %.1f us in all (workgroup 0; first job per operator below)\n",
+          e.groups, e.group_size, e.njobs, e.nops, e.barriers, (h[e.nops + 1] - h[0]) / 100.0);
+  for (int o = 0; o < e.nops; ++o) {
+    const cnk::MegaOp& op = e.pinned[o];
+    fprintf(stderr, "  op %2d %-15s strips %4d  barrier %d  %7.2f us", o, names[op.type], op.nbx, op.barrier, (h[o + 1] - h[o]) / 100.0);
+    if (op.type <= cnk::MOP_ROWLIN) fprintf(stderr, "   Cin %4d Cout %4d k %d ln %d", op.u.rc.Cin, op.u.rc.Cout, op.u.rc.ktaps, op.u.rc.ln);
+    fprintf(stderr, "\n");
+  }
+}
+
+void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
+  static const bool stamps = getenv("CONAN_MEGA_STAMPS") != nullptr;
+  if (stamps && !mega_dbg) mega_dbg = reinterpret_cast<unsigned long long*>(alloc(2 * (kMegaMaxOps + 4)));
+  if (stamps) mega_dbg_prog = &e;
+  cnk::MegaLaunch m; memset(&m, 0, sizeof(m));
+  m.prog = e.dev; m.nops = e.nops; m.njobs = e.njobs; m.groups = e.groups; m.group_size = e.group_size; m.kw4 = e.kw4; m.lds_bytes = e.lds_bytes;
+  m.slots = d_slots; m.pos = pos_dec; m.n = e.n; m.T = e.T;
+  m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg;
+  profiled("cnk::decoder_mega_kernel", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
+  mega_bar_count += (unsigned)(e.groups * e.group_size);
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
