@@ -133,6 +133,7 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
       { const char* e = getenv("CONAN_DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
       { const char* e = getenv("CONAN_MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }
+      { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
       s->pin.init((size_t)max_slots);

@@ -111,7 +111,7 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
       const int njobs = (n * T + 15) / 16;
       e->njobs = njobs; e->kw4 = 0; e->n = n; e->T = T;
       if (njobs == 1) { e->groups = 1; e->group_size = std::max(1, std::min(mega_grid, maxs)); }
-      else { e->group_size = 8; e->groups = std::max(1, std::min(njobs, mega_grid / 8)); }
+      else { e->group_size = mega_gs; e->groups = std::max(1, std::min(njobs, mega_grid / mega_gs)); }
       e->nops = (int)ops.size(); e->barriers = nb; e->flops = mega_rec_flops;
       e->lds_bytes = mega_rec_lds * 4;
       HIP_CHECK(hipEventSynchronize(e->copied));            // (the entry's previous upload, if any, has long completed)
@@ -134,7 +134,10 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   DecExtra ex; if (extra) ex = *extra;
   // (a job is a 16-row tile taken through the whole operator list by its own group of workgroups: a stream's frames of the
   // step must all fall into one tile - 16 % frames == 0, or a single tile in all)
-  const bool tiles_ok = (16 % T == 0) || n * T <= 16;
+  // A single tile (<= 4 streams) keeps the separate launches: its operators are latency chains that 128 workgroups cannot
+  // shorten, and a grid-wide barrier per operator costs what the launch boundaries do (0.47 against 0.39 ms at one stream).
+  static const bool mega_single = getenv("CONAN_MEGA_SINGLE") != nullptr;
+  const bool tiles_ok = (16 % T == 0 && n * T > 16) || (n * T <= 16 && mega_single);
   if (use_mega && notaps && tiles_ok && mega_bar && run_mega(n, T, codes, mel_out, ex, st)) return;
   if (ex.codes_dst) HIP_CHECK(hipMemcpyAsync(ex.codes_dst, ex.codes_src, (size_t)ex.codes_words * sizeof(int), hipMemcpyDeviceToDevice, st));
   decoder_ops(n, T, codes, mel_out, taps, st);
@@ -180,11 +183,21 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
   // Post-LN layers: where the consumer of a LayerNorm is a rowconv launch the norm is that launch's prologue (the
   // normalised rows also go to `hist`, where the residual adds read them): norm1 -> ff1, and layer 0's norm2 -> layer 1's q.
   bool n2_pending = false;                       // the previous layer's norm2 is still to be applied (by this layer's q)
+  // Megakernel, several row tiles: the feed-forward of a layer is ONE operator (ff1 -> ReLU -> ff2 with the hidden columns
+  // split over the 8 members of a group, decoder_mega.hip MOP_FFN); what ff2 would have written to c_a1 then exists as 8
+  // partial tensors + bias + residual, summed by whoever reads it (the norm2 behind it).
+  static const bool ffn_fuse_on = getenv("CONAN_MEGA_NOFFN") == nullptr;
+  bool ffn_parts = false;
+  const long long part_stride = (long long)max_slots * max_frames * H;
+  auto x_parts = [&](auto& a, const PackedConv& ff2) {
+    a.xp = c_part.base; a.xp_stride = part_stride; a.xparts = mega_gs; a.xp_ld = H; a.xbias = ff2.bias; a.xres = c_a2.ref(); a.has_xres = 1;
+  };
   for (int l = 0; l < 2; ++l) {
     const std::string nm = "conan.align." + std::to_string(l);
     if (rowconv_ok(ctx->conv(nm + ".q"), 1, T)) {
       cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".q"), n2_pending ? c_a1.ref() : src->ref(), c_q.ref(), n, T);
       if (n2_pending) { a.ln = 1; a.hist = src->ref(); a.gamma = ctx->vec("conan.align." + std::to_string(l - 1) + ".norm2.g"); a.beta = ctx->vec("conan.align." + std::to_string(l - 1) + ".norm2.b"); }
+      if (n2_pending && ffn_parts) x_parts(a, ctx->conv("conan.align." + std::to_string(l - 1) + ".ff2"));
       a.out_scale = (float)std::sqrt(1.0 / (double)dh); rowconv(a, st);
     } else { ConvArgs a = mk(ctx->conv(nm + ".q"), src->ref(), c_q.ref(), n, T, pos); a.out_scale = (float)std::sqrt(1.0 / (double)dh); conv(a, st); }
     n2_pending = false;
@@ -196,7 +209,21 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
     }
     if (rowconv_ok(ctx->conv(nm + ".out"), 1, T)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T); a.res = src->ref(); a.has_res = 1; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".out"), c_att.ref(), c_a1.ref(), n, T, pos); a.res = src->ref(); a.has_res = 1; conv(a, st); }
-    if (rowconv_ok(ctx->conv(nm + ".ff1"), 1, T)) {       // norm1 (prologue; normalised rows -> c_a2, ff2's residual) -> ff1 -> ReLU
+    ffn_parts = false;
+    {
+      const PackedConv &f1 = ctx->conv(nm + ".ff1"), &f2 = ctx->conv(nm + ".ff2");
+      if (mega_rec && ffn_fuse_on && n * T > 16 && rowconv_ok(f1, 1, T) && f2.wf && f1.k == 1 && f2.k == 1 && f1.Cout % (64 * mega_gs) == 0 && f1.Cout / mega_gs <= 256 &&
+          f2.Cin == f1.Cout && f2.Cout == H && H % 64 == 0) {
+        cnk::RowConvArgs a = mk_rc(f1, c_a1.ref(), c_ff.ref(), n, T);
+        a.ln = 1; a.hist = c_a2.ref(); a.gamma = ctx->vec(nm + ".norm1.g"); a.beta = ctx->vec(nm + ".norm1.b");
+        a.out_act = cnk::ACT_RELU;
+        a.w2 = f2.wf; a.part = c_part.base; a.part_stride = part_stride; a.Cout2 = f2.Cout; a.Cout2_pad = f2.wf_cout_pad;
+        rowconv(a, st);
+        ffn_parts = true;
+      }
+    }
+    if (ffn_parts) {
+    } else if (rowconv_ok(ctx->conv(nm + ".ff1"), 1, T)) {       // norm1 (prologue; normalised rows -> c_a2, ff2's residual) -> ff1 -> ReLU
       cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff1"), c_a1.ref(), c_ff.ref(), n, T);
       a.ln = 1; a.hist = c_a2.ref(); a.gamma = ctx->vec(nm + ".norm1.g"); a.beta = ctx->vec(nm + ".norm1.b");
       a.out_act = cnk::ACT_RELU; rowconv(a, st);
@@ -206,12 +233,14 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
     }
     // ff2 (K = 2048) -> c_a1 (free again): rowlin - a 33 KB block that shares CUs with the vocoder's, where the split-K conv_mfma
     // build (126 KB of LDS) needs CUs of its own; a handful of rows (one row tile) keep the split-K build, which spreads K over blocks
-    if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && (n * T > 16 || mega_rec)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
+    if (ffn_parts) {
+    } else if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && (n * T > 16 || mega_rec)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
     if (l == 0 && rowconv_ok(ctx->conv("conan.align.1.q"), 1, T)) n2_pending = true;      // norm2 -> c_x[0] happens in layer 1's q launch
     else {
       cnk::LNArgs ln = mk_ln(c_a1.ref(), l == 0 ? c_x[0].ref() : c_pin2.ref(), ctx->vec(nm + ".norm2.g"), ctx->vec(nm + ".norm2.b"), d_slots, pos, n, T, H);
       if (l == 1) { ln.post = c_pin.ref(); ln.has_post = 1; }   // pitch_inp = pitch_inp + prosody (Conan.py:168)
+      if (ffn_parts) x_parts(ln, ctx->conv(nm + ".ff2"));
       op_ln(ln, st);
     }
     src = &c_x[0];

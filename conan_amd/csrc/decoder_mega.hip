@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __re
             for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4>(a, tab, bx, lds);
           }
         } break;
+        case MOP_FFN: {        // LayerNorm -> 1x1 -> activation -> 1x1 partial sums, the hidden columns split over the members
+          const auto& a = MG_AS4(RowConvArgs, &op->u);
+          ro::mg_stage(a, tab, lds, sb == 0);
+          ro::mg_ffn(a, tab, sb, GS, lds);
+        } break;
         case MOP_ROWLIN: {
           const auto& a = MG_AS4(RowConvArgs, &op->u);
           for (int bx = sb; bx < nbx; bx += GS) ro::mg_rowlin_strip(a, tab, bx, lds);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __re
 
 int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats) {
   switch (op.type) {
-    case MOP_RC111: case MOP_RC114: case MOP_ROWLIN: return rc_lds_floats + ro::ROWTAB_FLOATS;
+    case MOP_RC111: case MOP_RC114: case MOP_ROWLIN: case MOP_FFN: return rc_lds_floats + ro::ROWTAB_FLOATS;
     case MOP_XATTN: return 2 * ro::XA2_LDS_FLOATS + ro::ROWTAB_FLOATS;
     default: return ro::ROWTAB_FLOATS;
   }

@@ -169,6 +169,16 @@ struct RowConvArgs {
   int in_lrelu; float in_slope;   // LeakyReLU applied to the input window (HiFi-GAN resblock convs read raw tensors)
   int wr_max;           // filled by launch_rowconv: window rows of a tile
   int cw;               // filled by launch_rowconv: window channels (0: all of Cin; 1x1 layers wider than 512: chunks of 512)
+  // ---- decoder megakernel only (decoder_mega.hip)
+  // MOP_FFN: this conv (k = 1, Cout = hidden width, activation applied) is followed IN the workgroup by a second 1x1 conv
+  // hidden -> Cout2 whose K range is the member's own hidden columns: member s of the group writes the partial sums
+  // part[s][row][Cout2]; bias, residual and everything behind them are applied where the sum is consumed (xp.. below)
+  const float* w2;      // second conv, fragment-major [Cout2_pad/16][2][Cout/16][64][4]
+  float* part; long long part_stride;      // floats between the members' partial tensors, each [n*T][Cout2]
+  int Cout2, Cout2_pad;
+  // consumer side: the NEW rows of x are not a tensor but xparts partial tensors: x = ((p0 + p1 + ..) + xbias) + xres
+  const float* xp; long long xp_stride; int xparts, xp_ld;
+  const float* xbias; TRef xres; int has_xres;
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);
 void launch_rowconv(const RowConvArgs& a, hipStream_t st);
@@ -188,6 +198,9 @@ struct LNArgs {
   int has_pre, has_post, has_m1, has_m2, has_mask_out;
   int T, n, C;
   float eps;
+  // decoder megakernel only: x is the sum of xparts partial tensors (+ xbias, + xres) - see RowConvArgs
+  const float* xp; long long xp_stride; int xparts, xp_ld;
+  const float* xbias; TRef xres; int has_xres;
 };
 void launch_layernorm(const LNArgs& a, hipStream_t st);
 
@@ -328,7 +341,7 @@ void launch_conv_post(const ConvPostArgs& a, hipStream_t st);
 
 // The decoder step as ONE persistent launch (decoder_mega.hip): a list of row-wise operators (rowops.h) walked by every
 // workgroup, tiles of an operator dealt round-robin over the grid, a grid barrier between dependent operators.
-enum MegaOpType { MOP_RC111 = 0, MOP_RC114 = 1, MOP_ROWLIN = 2, MOP_LN = 3, MOP_XATTN = 4, MOP_PITCH = 5, MOP_EMBED = 6, MOP_COPY32 = 7, MOP_ADVANCE = 8 };
+enum MegaOpType { MOP_RC111 = 0, MOP_RC114 = 1, MOP_ROWLIN = 2, MOP_LN = 3, MOP_XATTN = 4, MOP_PITCH = 5, MOP_EMBED = 6, MOP_COPY32 = 7, MOP_ADVANCE = 8, MOP_FFN = 9 };
 struct MegaCopy { unsigned* dst; const unsigned* src; long long n; };          // n 32-bit words (plain accesses: inputs of the launch -> outputs read after it)
 struct MegaAdvance { int* pos; const int* slots; int n, delta; };              // pos[slots[q]] += delta (the step's last operator)
 struct MegaOp {

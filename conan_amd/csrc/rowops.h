@@ -669,6 +669,16 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
       const int w = e < total ? e / C4 : 0, c4 = e < total ? e - w * C4 : 0;
       const int sg = wseg(w);
       const int tau = tb.seg_t0[sg] - halo + (w - (tb.seg_r0[sg] + sg * halo));   // time index within this step (negative: earlier steps)
+      if (a.xparts > 0 && tau >= 0) {
+        // the new rows of x are the sum of the group members' partial tensors (+ bias, + residual), summed in member order
+        const long long off = (long long)(tb.seg_i[sg] * a.T + tau) * a.xp_ld + c4 * 4;
+        float4 acc = ld4<true>(a.xp + off);
+        for (int p = 1; p < a.xparts; ++p) { const float4 q = ld4<true>(a.xp + p * a.xp_stride + off); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+        if (a.xbias) { const float4 q = ldw4(a.xbias + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+        if (a.has_xres) { const float4 q = ld4<true>(row(a.xres, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau) + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+        v[u] = acc;
+        continue;
+      }
       const float* src = (a.ln && tau >= 0) ? row(a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau)
                                             : row(a.ln ? a.hist : a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau);
       v[u] = ld4<true>(src + c4 * 4);
@@ -815,6 +825,104 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
   }
 }
 
+// MOP_FFN (the aligner's feed-forward, prosody_util.py:139-158): after mg_stage (LayerNorm prologue) member `sb` computes ITS
+// HC = Cout / GS hidden columns of the first 1x1 conv (activation applied) into LDS and multiplies them straight away with its
+// K range of the second 1x1 conv: the hidden tensor never leaves the CU and the 2048-deep K loop is split over the group.
+// The member's partial sums [rows][Cout2] go to part[sb]; bias, residual and the norm behind them are applied where the sum is
+// consumed (RowConvArgs / LNArgs: xp ..).  LDS: window [wr_max][Cin + 8] | hidden [16][HC + 8].
+template <class A>
+__device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int sb, const int GS, float* __restrict__ win) {
+  constexpr int RC_D = 8;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int Cin = a.Cin, LDX = Cin + 8;
+  const int HC = a.Cout / GS, LDH = HC + 8;           // hidden columns of this member (a multiple of 64)
+  float* const hid = win + a.wr_max * LDX;
+  {   // ---- first conv: strips sb * HC/64 .. of 64 columns, one 16-column tile per wave, into LDS
+    const int KQ = Cin >> 4;
+    const long long ct_stride = 2ll * KQ * 256;       // k = 1: one tap + the zero tap
+    const float* const abase = win + tb.tab[lr] * LDX + 4 * lg;
+    for (int s = 0; s < HC / 64; ++s) {
+      const int ct0 = (sb * (HC / 64) + s) * 4 + wave;
+      const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float4 bw[RC_D];
+#pragma unroll
+      for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
+      float4 af = *reinterpret_cast<const float4*>(abase);
+      for (int G0 = 0; G0 < KQ; G0 += RC_D) {
+#pragma unroll
+        for (int u = 0; u < RC_D; ++u) {
+          const int Gn = G0 + u + 1;
+          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < KQ ? Gn * 16 : 0));
+          f32x4& p = (u & 1) ? acc1 : acc0;
+          f32x4& q = (u & 1) ? acc0 : acc1;
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+          bw[u] = ldw4(wl + (long long)(G0 + u + RC_D) * 256);      // (past the last group: the zero tap, in bounds)
+          af = afn;
+        }
+      }
+      const int col = ct0 * 16 + lr;
+      const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = ((acc0[e] + acc1[e]) + bias) * a.out_scale;
+        if (a.out_act == ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (a.out_act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        else if (a.out_act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
+        hid[(4 * lg + e) * LDH + (s * 4 + wave) * 16 + lr] = v;
+      }
+    }
+  }
+  __syncthreads();
+  {   // ---- second conv, this member's K range: hidden channels [sb * HC, (sb + 1) * HC) of every 16-column output tile
+    const int KQ2 = a.Cout >> 4, KQm = HC >> 4;       // K groups per tap in memory / of this member
+    const long long ct_stride2 = 2ll * KQ2 * 256;
+    const float* const abase = hid + lr * LDH + 4 * lg;
+    float* const pbase = a.part + (long long)sb * a.part_stride;
+    for (int ct = wave; ct * 16 < a.Cout2_pad; ct += 4) {
+      const float* wl = a.w2 + (long long)ct * ct_stride2 + (long long)(sb * KQm) * 256 + lane * 4;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float4 bw[RC_D];
+#pragma unroll
+      for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
+      float4 af = *reinterpret_cast<const float4*>(abase);
+      for (int G0 = 0; G0 < KQm; G0 += RC_D) {
+#pragma unroll
+        for (int u = 0; u < RC_D; ++u) {
+          const int Gn = G0 + u + 1;
+          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < KQm ? Gn * 16 : 0));
+          f32x4& p = (u & 1) ? acc1 : acc0;
+          f32x4& q = (u & 1) ? acc0 : acc1;
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+          // (past this member's range: the next member's groups / the zero tap - in bounds, never used)
+          bw[u] = ldw4(wl + (long long)(G0 + u + RC_D) * 256);
+          af = afn;
+        }
+      }
+      const int col = ct * 16 + lr;
+      if (col < a.Cout2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * lg + e;
+          if (r >= tb.nvalid) continue;
+          const RowId id = row_id(tb, r);
+          st1<true>(pbase + (long long)(id.i * a.T + id.t) * a.Cout2 + col, acc0[e] + acc1[e]);
+        }
+      }
+    }
+  }
+}
+
 // one 64-column strip of a 1x1 layer wider than the window (aligner ff2): the rows' channels pass through LDS in chunks of 512
 template <class A>
 __device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win) {   // win: [16][RL_LDX]
@@ -907,7 +1015,16 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
   for (int k = 0; k < LN_MAXV; ++k) {
     int c = lane + 64 * k;
     float u = 0.f;
-    if (c < a.C) { u = ld1<true>(x + c); sa += fabsf(u); if (pre) u += ld1<true>(pre + c); }
+    if (c < a.C) {
+      if (a.xparts > 0) {       // x = the sum of the group members' partial tensors (+ bias, + residual), in member order
+        const long long off = (long long)(id.i * a.T + id.t) * a.xp_ld + c;
+        u = ld1<true>(a.xp + off);
+        for (int p = 1; p < a.xparts; ++p) u += ld1<true>(a.xp + p * a.xp_stride + off);
+        if (a.xbias) u += ldw1(a.xbias + c);
+        if (a.has_xres) u += ld1<true>(row(a.xres, id.i, id.slot, id.pos, id.t) + c);
+      } else u = ld1<true>(x + c);
+      sa += fabsf(u); if (pre) u += ld1<true>(pre + c);
+    }
     v[k] = u; s += u;
   }
   s = wave_sum(s);

@@ -104,7 +104,7 @@ struct conan_streams {
   // --- conan decoder
   Ring c_emb, c_pin2, c_uvh[4], c_lastr;
   std::vector<Ring> c_lnrs;     // post-LN rings, one per (block, sub-layer)
-  Lin c_pin, c_q, c_att, c_a1, c_a2, c_ff, c_uv5, c_x[2], c_h, c_post, c_mask_blk, c_mask_out, c_mel;
+  Lin c_pin, c_q, c_att, c_a1, c_a2, c_ff, c_uv5, c_x[2], c_h, c_post, c_mask_blk, c_mask_out, c_mel, c_part;
   float* c_style = nullptr;     // [slot][H]
   float* c_kv = nullptr;        // [slot][2 layers][S_max][2H]
   float* c_kmask = nullptr;     // [slot][S_max]
@@ -218,6 +218,7 @@ struct conan_streams {
   long long mega_clock = 0;
   bool use_mega = true;                          // CONAN_DEC_MEGA=0: the decoder step as separate launches
   int mega_grid = 128;                           // CONAN_MEGA_GRID
+  int mega_gs = 8;                               // workgroups per group (CONAN_MEGA_GS: 4, 8 or 16)
   unsigned* mega_bar = nullptr;                  // the grid barrier's arrival counter (counts for ever); the group counters follow it, 16 words apart
   unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished
   unsigned long long* mega_dbg = nullptr;        // CONAN_MEGA_STAMPS=1: per-operator clock stamps of the last launch (printed at destruction)

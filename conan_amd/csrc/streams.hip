@@ -148,6 +148,12 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     int ldsf = 0;
     const int v = cnk::rowconv_plan(op.u.rc, &op.nbx, &op.nby, &ldsf);
     op.type = v == 3 ? cnk::MOP_ROWLIN : (v == 2 ? cnk::MOP_RC114 : cnk::MOP_RC111);
+    if (a.w2) {        // fused feed-forward: behind the window, the member's 16 x (Cout / 8 + 8) hidden tile
+      if (v != 0) { mega_rec_ok = false; return; }
+      op.type = cnk::MOP_FFN;
+      ldsf = op.u.rc.wr_max * (a.Cin + 8) + 16 * (a.Cout / mega_gs + 8);
+      mega_rec_flops += 2.0 * (double)a.n * a.T * a.Cout * a.Cout2;
+    }
     mega_rec_flops += fl;
     mega_push(op, ldsf);
     return;
@@ -667,6 +673,7 @@ void conan_streams::build_decoder() {
   c_pin = mk_lin(F, H); c_q = mk_lin(F, H); c_att = mk_lin(F, H); c_a1 = mk_lin(F, H); c_a2 = mk_lin(F, H);
   c_ff = mk_lin(F, 2048); c_uv5 = mk_lin(F, 128); c_x[0] = mk_lin(F, H); c_x[1] = mk_lin(F, H); c_h = mk_lin(F, 2 * H);
   c_post = mk_lin(F, H); c_mask_blk = mk_lin(F, 1); c_mask_out = mk_lin(F, 1); c_mel = mk_lin(F, c.num_mels);
+  c_part = mk_lin(F, 16 * H);       // decoder megakernel: the 8 group members' partial sums of a fused feed-forward, [member][row][H]
   S_max = (max_ref + 3) / 4;
   if (S_max > 512) throw Error(CONAN_ERR_UNSUPPORTED, "max_ref_frames > 2048");
   c_style = alloc((size_t)max_slots * H);

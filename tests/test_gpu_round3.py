@@ -164,3 +164,39 @@ def test_wide_stage_pairs_equal_the_two_launch_plan_per_stage():
         assert float((pa - pb).abs().max()) <= 2e-5 * max(1.0, float(pb.abs().max()))
         assert float((wa - wb).abs().max()) <= 2e-5
     a.close(); b.close(); ctx.close()
+
+
+def test_decoder_megakernel_equals_the_separate_launches():
+    """The decoder step as one persistent launch (decoder_mega.hip: row-tile groups, group barriers, agent-scope activation
+    accesses, fused feed-forward) against the same step as ~38 separate launches (CONAN_DEC_MEGA=0) on the same streams:
+    20 steps of 4 frames at 24 streams (6 row tiles), then the ragged tail (3 frames: separate launches in both).  mel within
+    fp32 re-association (the fused feed-forward sums its hidden units in a different order), and the megakernel twice gives
+    the same bits (no stale reads between its operators)."""
+    from conan_amd.runtime import Context
+    chp, vhp = configs.conan_hparams(), configs.hifigan_hparams()
+    ctx = Context(chp, None, 0, emformer=False, conan=True, hifigan=False)
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.finalize()
+    S = 24
+    old = os.environ.get("CONAN_DEC_MEGA")
+    try:
+        os.environ.pop("CONAN_DEC_MEGA", None)
+        a = ctx.streams(S, 4, 64); a2 = ctx.streams(S, 4, 64)
+        os.environ["CONAN_DEC_MEGA"] = "0"
+        b = ctx.streams(S, 4, 64)
+    finally:
+        if old is None:
+            os.environ.pop("CONAN_DEC_MEGA", None)
+        else:
+            os.environ["CONAN_DEC_MEGA"] = old
+    ids = list(range(S))
+    ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
+    codes = torch.from_numpy(synth.codes(83, S)).int().cuda()
+    for st in (a, a2, b):
+        st.reset(ids); st.set_reference(ids, ref)
+    for i in list(range(0, 80, 4)) + [80]:
+        c = codes[:, i:i + 4 if i < 80 else 83].contiguous()
+        ma, ma2, mb = a.decoder_step(ids, c), a2.decoder_step(ids, c), b.decoder_step(ids, c)
+        assert torch.equal(ma, ma2)
+        np.testing.assert_allclose(ma.cpu().numpy(), mb.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    a.close(); a2.close(); b.close(); ctx.close()

@@ -60,6 +60,20 @@ def test_co_residency_budgets(tmp_path):
         assert 2 * gran(f["vgpr"] + f["agpr"]) + 80 <= 512, (key, f)
         # its block + a rowconv block (16 + 4*4 window rows x (256 + 8) floats, 32 ints of row table, 240 B static) within 160 KB
         assert f["lds"] + (32 + 32 * 264) * 4 + 240 <= 160 * 1024, (key, f)
+    # The decoder megakernel's workgroups stay resident for a whole step: a vocoder workgroup that cannot be placed beside one
+    # would wait for the END of the decoder step.  80 registers (one wave per SIMD beside two of a fused pass), no static LDS
+    # (its dynamic LDS is the largest operator window + the 384-byte row table, checked below against every vocoder kernel),
+    # and at most a few registers of scratch for values that live across the operator loop (reloaded once per operator,
+    # outside the K loops).
+    mega = _find(ks, "decoder_mega_kernel")
+    assert gran(mega["vgpr"] + mega["agpr"]) <= 80 and mega["lds"] == 0
+    assert mega["spill"] <= 40 and mega["scratch"] <= 160, mega
+    mega_lds = (96 + 32 * 264) * 4            # row table + the k = 5, 256-channel window (= the fused feed-forward's window + hidden tile)
+    pair = _find(ks, "resblock_pair_kernelILi2E")
+    assert pair["spill"] == 0 and pair["scratch"] == 0
+    for key, f in list(fused.items()) + [("pair", pair)]:
+        assert 2 * gran(f["vgpr"] + f["agpr"]) + 80 <= 512, (key, f)
+        assert f["lds"] + mega_lds <= 160 * 1024, (key, f)
 
 
 def test_hot_kernels_do_not_spill(tmp_path):
