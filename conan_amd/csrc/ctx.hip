@@ -372,11 +372,31 @@ void conan_ctx::finalize_conan() {
     upload_vec(n + ".norm1.g", p + ".norm1.weight"); upload_vec(n + ".norm1.b", p + ".norm1.bias");
     upload_vec(n + ".norm2.g", p + ".norm2.weight"); upload_vec(n + ".norm2.b", p + ".norm2.bias");
   }
-  // uv predictor
-  for (int i = 0; i < 5; ++i) {
+  // The widths the reference's constructors hard-code - uv predictor n_chans = 128 and 5 layers (Conan.py:106-113), aligner
+  // dim_feedforward = 2048 and 2 layers (prosody_util.py:97,133, Conan.py:81) - are taken from the checkpoint's tensors, so a
+  // checkpoint trained with other widths loads; what the kernels cannot run fails HERE with CONAN_ERR_SHAPE, not in a step.
+  if (has(P + "align.layers.2.linear1.weight")) throw Error(CONAN_ERR_SHAPE, "ProsodyAligner with more than 2 layers (conan_decoder_taps carries two attention maps)");
+  for (int l = 0; l < 2; ++l) {
+    const ch::PackedConv &f1 = conv("conan.align." + std::to_string(l) + ".ff1"), &f2 = conv("conan.align." + std::to_string(l) + ".ff2");
+    if (f1.Cin != H || f2.Cout != H || f2.Cin != f1.Cout || f1.k != 1 || f2.k != 1) throw Error(CONAN_ERR_SHAPE, "aligner feed-forward shapes (linear1 [F,H], linear2 [H,F])");
+    if (l && f1.Cout != conv("conan.align.0.ff1").Cout) throw Error(CONAN_ERR_SHAPE, "aligner layers with different feed-forward widths");
+  }
+  scalars["conan.align.ffn"] = (float)conv("conan.align.0.ff1").Cout;
+  // uv predictor: conv.i for as many layers as the checkpoint holds (nar_tts_modules.py:113-122)
+  int n_uv = 0;
+  while (has(P + "uv_predictor.conv." + std::to_string(n_uv) + ".0.conv.weight")) ++n_uv;
+  if (n_uv < 1 || n_uv > 8) throw Error(CONAN_ERR_SHAPE, "uv_predictor: 1 to 8 conv layers expected");
+  for (int i = 0; i < n_uv; ++i) {
     std::string p = P + "uv_predictor.conv." + std::to_string(i) + ".0.conv";
     pack_from_keys("conan.uv." + std::to_string(i), p + ".weight", p + ".bias");
+    const ch::PackedConv& pc = conv("conan.uv." + std::to_string(i));
+    if (pc.Cin != (i == 0 ? H : conv("conan.uv." + std::to_string(i - 1)).Cout) || pc.k != c.predictor_kernel)
+      throw Error(CONAN_ERR_SHAPE, "uv_predictor.conv." + std::to_string(i) + ": input width / kernel size do not chain");
   }
+  const int uvh = conv("conan.uv." + std::to_string(n_uv - 1)).Cout;
+  if (uvh > 256 || get(P + "uv_predictor.post_ln.weight").numel() != uvh || get(P + "uv_predictor.linear.weight").numel() != 2 * (long long)uvh)
+    throw Error(CONAN_ERR_SHAPE, "uv_predictor: post_ln / linear do not match the last conv's width (at most 256 channels)");
+  scalars["conan.uv.n"] = (float)n_uv; scalars["conan.uv.hidden"] = (float)uvh;
   upload_vec("conan.uv.ln.g", P + "uv_predictor.post_ln.weight");
   upload_vec("conan.uv.ln.b", P + "uv_predictor.post_ln.bias");
   upload_vec("conan.uv.lin.w", P + "uv_predictor.linear.weight");
@@ -406,6 +426,15 @@ void conan_ctx::finalize_conan() {
   for (int i = 0; i < 4; ++i) {
     pack_weightnorm("conan.wn.in." + std::to_string(i), P + "prosody_extractor.wavenet.in_layers." + std::to_string(i));
     pack_weightnorm("conan.wn.rs." + std::to_string(i), P + "prosody_extractor.wavenet.res_skip_layers." + std::to_string(i));
+  }
+  {  // the style pass works on the reference mel itself: WN(hidden = num_mels), encoder width num_mels (prosody_util.py:173-181)
+    const int NM = c.num_mels;
+    if (conv("conan.global_conv_in").Cin != NM || conv("conan.global_conv_in").Cout != H) throw Error(CONAN_ERR_SHAPE, "global_conv_in must be num_mels -> hidden_size");
+    for (int i = 0; i < 4; ++i) {
+      const ch::PackedConv &wi = conv("conan.wn.in." + std::to_string(i)), &wr = conv("conan.wn.rs." + std::to_string(i));
+      if (wi.Cin != NM || wi.Cout != 2 * NM || wr.Cin != NM || wr.Cout != (i < 3 ? 2 * NM : NM)) throw Error(CONAN_ERR_SHAPE, "prosody_extractor.wavenet: WN(hidden = num_mels) expected");
+    }
+    if (conv("conan.penc.0.0.c1").Cin != NM) throw Error(CONAN_ERR_SHAPE, "prosody_extractor.encoder width must be num_mels");
   }
   {
     const HostTensor& e = get(P + "prosody_extractor.vqvae.embedding");

@@ -246,9 +246,10 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
     src = &c_x[0];
   }
   // uv_predictor: 5 x [CausalConv k5 + ReLU] (nar_tts_modules.py:113-122)
-  for (int i = 0; i < 5; ++i) {
+  const int n_uv = (int)ctx->scalars.at("conan.uv.n");
+  for (int i = 0; i < n_uv; ++i) {
     const TRef xin = i == 0 ? c_pin2.ref() : c_uvh[i - 1].ref();
-    const TRef yout = i == 4 ? c_uv5.ref() : c_uvh[i].ref();
+    const TRef yout = i == n_uv - 1 ? c_uv5.ref() : c_uvh[i].ref();
     const PackedConv& pc = ctx->conv("conan.uv." + std::to_string(i));
     if (rowconv_ok(pc, 1, T)) { cnk::RowConvArgs a = mk_rc(pc, xin, yout, n, T); a.out_act = cnk::ACT_RELU; rowconv(a, st); continue; }
     ConvArgs a = mk(pc, xin, yout, n, T, pos);
@@ -260,7 +261,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
     a.h = c_uv5.ref(); a.pitch_inp = c_pin2.ref(); a.dec_inp = c_x[0].ref();
     a.gamma = ctx->vec("conan.uv.ln.g"); a.beta = ctx->vec("conan.uv.ln.b"); a.w = ctx->vec("conan.uv.lin.w"); a.b = ctx->vec("conan.uv.lin.b");
     a.pitch_embed = ctx->vec("conan.pitch_embed"); a.codes = codes; a.uv_pred = uv_pred; a.f0 = f0; a.bins = bins;
-    a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.Cp = 128; a.E = H; a.silent_token = c.silent_token;
+    a.slots = d_slots; a.pos = pos; a.T = T; a.n = n; a.Cp = (int)ctx->scalars.at("conan.uv.hidden"); a.E = H; a.silent_token = c.silent_token;
     op_pitch(a, st);
   }
   if (dec_inp) {
@@ -352,7 +353,6 @@ void conan_streams::conv_blocks_noncausal(const std::string& name, int nblocks, 
 void conan_streams::set_reference(const int32_t* slots, int n_all, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st) {
   const conan_cfg& c = ctx->cfg;
   const int H = c.hidden_size, NM = c.num_mels;
-  if (NM != 80) throw Error(CONAN_ERR_UNSUPPORTED, "style pass expects 80 mel bins (WN(80), global_conv_in(80))");
   for (int i = 0; i < n_all; ++i)
     if (ref_len[i] <= 0 || ref_len[i] > max_len || ref_len[i] > max_ref) throw Error(CONAN_ERR_INVALID, "reference length out of range");
   for (int b0 = 0; b0 < n_all; b0 += sp_batch) {
@@ -401,21 +401,21 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
         ConvArgs a = mk(ctx->conv("conan.wn.in." + std::to_string(i)), s_wx.ref(PADR), s_win.ref(PADR), n, T, nullptr, 1, 1);
         a.slots = nullptr; a.lens = d_lens; conv(a, st);
       }
-      { cnk::WNGateArgs a; memset(&a, 0, sizeof(a)); a.xin = s_win.ref(PADR); a.acts = s_acts.ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.H = 80; cnk::launch_wn_gate(a, st); }
+      { cnk::WNGateArgs a; memset(&a, 0, sizeof(a)); a.xin = s_win.ref(PADR); a.acts = s_acts.ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.H = NM; cnk::launch_wn_gate(a, st); }
       {
         ConvArgs a = mk(ctx->conv("conan.wn.rs." + std::to_string(i)), s_acts.ref(PADR), s_rs.ref(PADR), n, T, nullptr);
         a.slots = nullptr; a.lens = d_lens; conv(a, st);
       }
       { cnk::WNUpdateArgs a; memset(&a, 0, sizeof(a)); a.rs = s_rs.ref(PADR); a.x = s_wx.ref(PADR); a.out = s_wout.ref(PADR); a.m = s_wnm.ref(PADR);
-        a.lens = d_lens; a.T = T; a.n = n; a.H = 80; a.last = i == 3; a.first = i == 0; cnk::launch_wn_update(a, st); }
+        a.lens = d_lens; a.T = T; a.n = n; a.H = NM; a.last = i == 3; a.first = i == 0; cnk::launch_wn_update(a, st); }
     }
-    { cnk::PoolArgs a; memset(&a, 0, sizeof(a)); a.x = s_wout.ref(PADR); a.m = s_wnm.ref(PADR); a.y = s_px[0].ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.C = 80; a.group = 4;
+    { cnk::PoolArgs a; memset(&a, 0, sizeof(a)); a.x = s_wout.ref(PADR); a.m = s_wnm.ref(PADR); a.y = s_px[0].ref(PADR); a.lens = d_lens; a.T = T; a.n = n; a.C = NM; a.group = 4;
       cnk::launch_group_pool(a, st); }
-    { cnk::RowMaskArgs a; memset(&a, 0, sizeof(a)); a.x = s_px[0].ref(PADR); a.m = s_pm.ref(PADR); a.lens = d_lens2; a.T = S; a.n = n; a.C = 80; a.mode = 0; cnk::launch_rowmask(a, st); }
+    { cnk::RowMaskArgs a; memset(&a, 0, sizeof(a)); a.x = s_px[0].ref(PADR); a.m = s_pm.ref(PADR); a.lens = d_lens2; a.T = S; a.n = n; a.C = NM; a.mode = 0; cnk::launch_rowmask(a, st); }
     int pc = 0;
-    conv_blocks_noncausal("conan.penc", 5, 5, 80, s_px, s_pln, s_phh, s_pblk, s_pm.ref(PADR), d_lens2, n, S, pc, st);
+    conv_blocks_noncausal("conan.penc", 5, 5, NM, s_px, s_pln, s_phh, s_pblk, s_pm.ref(PADR), d_lens2, n, S, pc, st);
     {
-      cnk::LNArgs l = mk_ln(s_px[pc].ref(PADR), s_pln.ref(PADR), ctx->vec("conan.penc.last.g"), ctx->vec("conan.penc.last.b"), nullptr, nullptr, n, S, 80);
+      cnk::LNArgs l = mk_ln(s_px[pc].ref(PADR), s_pln.ref(PADR), ctx->vec("conan.penc.last.g"), ctx->vec("conan.penc.last.b"), nullptr, nullptr, n, S, NM);
       l.lens = d_lens2; l.m1 = s_pm.ref(PADR); l.has_m1 = 1;
       cnk::launch_layernorm(l, st);
       ConvArgs a = mk(ctx->conv("conan.penc.post"), s_pln.ref(PADR), s_enc.ref(PADR), n, S, nullptr, 1, 1);

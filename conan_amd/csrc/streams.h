@@ -102,7 +102,8 @@ struct conan_streams {
   int emf_cluster = 0;          // workgroups per stream group of the fused step (0: per launch; CONAN_EMF_CLUSTER)
   cnk::EmfFusedArgs emf_fused_args;
   // --- conan decoder
-  Ring c_emb, c_pin2, c_uvh[4], c_lastr;
+  Ring c_emb, c_pin2, c_lastr;
+  std::vector<Ring> c_uvh;      // outputs of the uv predictor's conv layers but the last (each keeps its own left context)
   std::vector<Ring> c_lnrs;     // post-LN rings, one per (block, sub-layer)
   Lin c_pin, c_q, c_att, c_a1, c_a2, c_ff, c_uv5, c_x[2], c_h, c_post, c_mask_blk, c_mask_out, c_mel, c_part;
   float* c_style = nullptr;     // [slot][H]

@@ -665,13 +665,15 @@ void conan_streams::build_decoder() {
   const int H = c.hidden_size, F = max_frames;
   c_emb = mk_ring(H, 1, c.content_kernel - 1, &dec_state);
   c_pin2 = mk_ring(H, 1, c.predictor_kernel - 1, &dec_state);
-  for (int i = 0; i < 4; ++i) c_uvh[i] = mk_ring(128, 1, c.predictor_kernel - 1, &dec_state);
+  // (uv predictor depth / width and the aligner's feed-forward width come from the checkpoint's tensors, ctx.hip finalize_conan)
+  const int n_uv = (int)ctx->scalars.at("conan.uv.n"), uvh = (int)ctx->scalars.at("conan.uv.hidden"), ffn = (int)ctx->scalars.at("conan.align.ffn");
+  for (int i = 0; i + 1 < n_uv; ++i) c_uvh.push_back(mk_ring(ctx->conv("conan.uv." + std::to_string(i)).Cout, 1, c.predictor_kernel - 1, &dec_state));
   // one post-LN ring per (block, sub-layer): each layer keeps its own left context
   for (int b = 0; b < c.dec_num_blocks; ++b)
     for (int j = 0; j < c.dec_layers_in_block; ++j) c_lnrs.push_back(mk_ring(H, 1, (c.dec_kernel - 1) * c.dec_dilations[b], &dec_state));
   c_lastr = mk_ring(H, 1, c.dec_post_kernel - 1, &dec_state);
   c_pin = mk_lin(F, H); c_q = mk_lin(F, H); c_att = mk_lin(F, H); c_a1 = mk_lin(F, H); c_a2 = mk_lin(F, H);
-  c_ff = mk_lin(F, 2048); c_uv5 = mk_lin(F, 128); c_x[0] = mk_lin(F, H); c_x[1] = mk_lin(F, H); c_h = mk_lin(F, 2 * H);
+  c_ff = mk_lin(F, ffn); c_uv5 = mk_lin(F, uvh); c_x[0] = mk_lin(F, H); c_x[1] = mk_lin(F, H); c_h = mk_lin(F, 2 * H);
   c_post = mk_lin(F, H); c_mask_blk = mk_lin(F, 1); c_mask_out = mk_lin(F, 1); c_mel = mk_lin(F, c.num_mels);
   c_part = mk_lin(F, 16 * H);       // decoder megakernel: the 8 group members' partial sums of a fused feed-forward, [member][row][H]
   S_max = (max_ref + 3) / 4;
@@ -687,10 +689,11 @@ void conan_streams::build_decoder() {
   s_mel = mk_lin(TR, c.num_mels, sp_batch); s_np = mk_lin(TR, 1, sp_batch); s_wnm = mk_lin(TR, 1, sp_batch);
   s_x[0] = mk_lin(TR, H, sp_batch); s_x[1] = mk_lin(TR, H, sp_batch); s_ln = mk_lin(TR, H, sp_batch); s_h = mk_lin(TR, 2 * H, sp_batch);
   s_blkm = mk_lin(TR, 1, sp_batch);
-  s_wx = mk_lin(TR, 80, sp_batch); s_wout = mk_lin(TR, 80, sp_batch); s_win = mk_lin(TR, 160, sp_batch); s_acts = mk_lin(TR, 80, sp_batch);
-  s_rs = mk_lin(TR, 160, sp_batch);
-  s_ph = mk_lin(SR, 80, sp_batch); s_pm = mk_lin(SR, 1, sp_batch); s_px[0] = mk_lin(SR, 80, sp_batch); s_px[1] = mk_lin(SR, 80, sp_batch);
-  s_pln = mk_lin(SR, 80, sp_batch); s_phh = mk_lin(SR, 160, sp_batch); s_pblk = mk_lin(SR, 1, sp_batch);
+  const int NM = c.num_mels;      // WN hidden width = encoder width = mel bins
+  s_wx = mk_lin(TR, NM, sp_batch); s_wout = mk_lin(TR, NM, sp_batch); s_win = mk_lin(TR, 2 * NM, sp_batch); s_acts = mk_lin(TR, NM, sp_batch);
+  s_rs = mk_lin(TR, 2 * NM, sp_batch);
+  s_ph = mk_lin(SR, NM, sp_batch); s_pm = mk_lin(SR, 1, sp_batch); s_px[0] = mk_lin(SR, NM, sp_batch); s_px[1] = mk_lin(SR, NM, sp_batch);
+  s_pln = mk_lin(SR, NM, sp_batch); s_phh = mk_lin(SR, 2 * NM, sp_batch); s_pblk = mk_lin(SR, 1, sp_batch);
   s_enc = mk_lin(SR, H, sp_batch); s_dots = mk_lin(SR, c.nvq, sp_batch); s_cat = mk_lin(SR, 2 * H, sp_batch); s_tok = mk_lin(SR, H, sp_batch);
   s_kvtmp = mk_lin(SR, 2 * H, sp_batch);
   s_ids = (int*)alloc((size_t)sp_batch * S_max);

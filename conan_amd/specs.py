@@ -87,22 +87,25 @@ def conan_spec(hp):
             s[f"{p}.weight_v"] = (co, 80, k)
     s["l1.weight"] = (H, 2 * H)
     s["l1.bias"] = (H,)
+    # CrossAttenLayer(dim_feedforward=2048) and PitchPredictor(n_chans=128) are constructor constants of the reference
+    # (prosody_util.py:97, Conan.py:106-113); the optional keys below describe checkpoints trained with other widths
+    ffn = hp.get("align_ffn_dim", 2048)
     for l in range(2):
         p = f"align.layers.{l}"
         s[f"{p}.multihead_attn.in_proj_weight"] = (3 * H, H)
         s[f"{p}.multihead_attn.in_proj_bias"] = (3 * H,)
         s[f"{p}.multihead_attn.out_proj.weight"] = (H, H)
         s[f"{p}.multihead_attn.out_proj.bias"] = (H,)
-        s[f"{p}.linear1.weight"] = (2048, H)
-        s[f"{p}.linear1.bias"] = (2048,)
+        s[f"{p}.linear1.weight"] = (ffn, H)
+        s[f"{p}.linear1.bias"] = (ffn,)
         s[f"{p}.norm1.weight"] = (H,)
         s[f"{p}.norm1.bias"] = (H,)
-        s[f"{p}.linear2.weight"] = (H, 2048)
+        s[f"{p}.linear2.weight"] = (H, ffn)
         s[f"{p}.linear2.bias"] = (H,)
         s[f"{p}.norm2.weight"] = (H,)
         s[f"{p}.norm2.bias"] = (H,)
     s["embed_positions._float_tensor"] = (1,)
-    _pitch_predictor(s, "uv_predictor", H, 128, 5, hp["predictor_kernel"])
+    _pitch_predictor(s, "uv_predictor", H, hp.get("uv_predictor_hidden", 128), 5, hp["predictor_kernel"])
     return s
 
 

@@ -200,3 +200,54 @@ def test_decoder_megakernel_equals_the_separate_launches():
         assert torch.equal(ma, ma2)
         np.testing.assert_allclose(ma.cpu().numpy(), mb.cpu().numpy(), atol=2e-5, rtol=1e-5)
     a.close(); a2.close(); b.close(); ctx.close()
+
+
+@pytest.mark.parametrize("streams", [1, 12])
+def test_decoder_widths_come_from_the_checkpoint(streams):
+    """A checkpoint with a 64-channel uv predictor and a 512-wide aligner feed-forward (the reference hard-codes 128 / 2048 in
+    its constructors; hidden_size 128 here): the host plans size their buffers and kernels from the loaded tensors.  Style
+    pass + stateful decoder steps against the oracle; integer intermediates exact; 12 streams take the megakernel."""
+    from conan_amd.runtime import Context
+    from oracle import conan as oconan
+    from oracle.common import to_torch_sd
+    chp = dict(configs.conan_hparams(), hidden_size=128, uv_predictor_hidden=64, align_ffn_dim=512)
+    sd_np = synth.conan_state_dict(chp, 0)
+    assert sd_np["uv_predictor.conv.4.0.conv.weight"].shape[0] == 64 and sd_np["align.layers.0.linear1.weight"].shape == (512, 128)
+    ctx = Context(chp, None, 0, emformer=False, conan=True, hifigan=False)
+    ctx.load_state_dict("conan", sd_np)
+    ctx.finalize()
+    sd = to_torch_sd(sd_np)
+    T, Tr = 16, 40
+    ref = torch.from_numpy(synth.mel(Tr, 21, streams))
+    codes = torch.from_numpy(synth.codes(T, streams))
+    st = ctx.streams(streams, 4, 64)
+    ids = list(range(streams))
+    st.reset(ids); st.set_reference(ids, ref.cuda())
+    mels, bins, uvs = [], [], []
+    for p in range(0, T, 4):
+        m, tp = st.decoder_step(ids, codes[:, p:p + 4].int().cuda(), taps=True)
+        bins.append(tp["pitch_bins"].cpu()); uvs.append(tp["uv_pred"].cpu())
+    st.reset(ids, which=2)
+    for p in range(0, T, 4):                       # and without taps (12 streams: the megakernel)
+        mels.append(st.decoder_step(ids, codes[:, p:p + 4].int().cuda()).cpu())
+    mel, bins, uvs = torch.cat(mels, 1).numpy(), torch.cat(bins, 1).numpy(), torch.cat(uvs, 1).numpy()
+    for b in range(streams):
+        cache = oconan.style_pass(sd, chp, ref[b:b + 1])
+        want = oconan.decode_frames(sd, chp, codes[b:b + 1].long(), cache, {})
+        np.testing.assert_allclose(uvs[b], want["uv_pred"][0].numpy(), atol=2e-4, rtol=1e-4)
+        safe = np.abs(want["uv_pred"][0, :, 0].numpy()) > 1e-3
+        assert np.array_equal(bins[b][safe], want["pitch_bins"][0].numpy()[safe]) if "pitch_bins" in want else True
+        np.testing.assert_allclose(mel[b], want["mel_out"][0].numpy(), atol=1e-4, rtol=1e-4)
+    st.close(); ctx.close()
+    # a third aligner layer is refused when the checkpoint is packed, not in a step
+    from conan_amd import _lib
+    bad = dict(sd_np)
+    for k, v in sd_np.items():
+        if k.startswith("align.layers.1."):
+            bad[k.replace("layers.1.", "layers.2.")] = v
+    ctx2 = Context(chp, None, 0, emformer=False, conan=True, hifigan=False)
+    ctx2.load_state_dict("conan", bad)
+    with pytest.raises(_lib.ConanError) as ei:
+        ctx2.finalize()
+    assert ei.value.code == _lib.ERR_SHAPE
+    ctx2.close()
