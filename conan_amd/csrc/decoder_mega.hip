@@ -87,15 +87,19 @@ __global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __re
         case MOP_RC111: {      // 64-column strips
           const auto& a = MG_AS4(RowConvArgs, &op->u);
           if (sb < nbx) {      // (members without a strip skip the gather as well)
+            float4 bw[8];
+            ro::mg_wwarm<1>(a, sb);
             ro::mg_stage(a, tab, lds, sb == 0);
-            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<1>(a, tab, bx, lds);
+            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<1, false>(a, tab, bx, lds, bw);
           }
         } break;
         case MOP_RC114: {      // 16-column strips, K split over the waves (a single tile in the step)
           const auto& a = MG_AS4(RowConvArgs, &op->u);
           if (sb < nbx) {
+            float4 bw[4];
+            ro::mg_wwarm<4>(a, sb);
             ro::mg_stage(a, tab, lds, sb == 0);
-            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4>(a, tab, bx, lds);
+            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4, false>(a, tab, bx, lds, bw);
           }
         } break;
         case MOP_FFN: {        // LayerNorm -> 1x1 -> activation -> 1x1 partial sums, the hidden columns split over the members

@@ -746,8 +746,22 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
 
 // K loop + epilogue of output strip bx of the staged operator: 64 columns (one 16-column tile per wave), or - KW = 4, a single
 // row tile in the step - 16 columns with the K groups split over the 4 waves (partial tiles meet in LDS behind the window)
+// Warm the L2 with the first 8 KB of this wave's weight stream for strip bx (one dword per 128-byte line and lane, result
+// unused) BEFORE the window gather: the stream's cold start - an L2 miss to HBM - then overlaps the gather's round trip instead
+// of following it.  (Holding the fragments themselves in registers across the gather + LayerNorm spilled 200 registers.)
 template <int KW, class A>
-__device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win) {
+__device__ __forceinline__ void mg_wwarm(const A& a, const int bx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
+  const int ct0 = KW > 1 ? bx : bx * 4 + wave;
+  const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
+  const float* wl = a.w + (long long)ct0 * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
+  if (ct0 * 16 < a.Cout_pad) { float t; asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(wl) : "memory"); (void)t; }
+}
+
+template <int KW, bool PRE, class A>
+__device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win, float4 (&bw)[(KW > 1) ? 4 : 8]) {
   constexpr int RC_D = (KW > 1) ? 4 : 8;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -766,9 +780,10 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
   const bool active = ct0 * 16 < a.Cout_pad;
   f32x4 accs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};     // two interleaved chains (rowconv_tile)
   if (active) {
-    float4 bw[RC_D];
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)(g_lo + u) * 256); __builtin_amdgcn_sched_barrier(0); }
+      for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)(g_lo + u) * 256); __builtin_amdgcn_sched_barrier(0); }
+    }
     const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
     const int tstep = d * LDX;
     float4 af = *reinterpret_cast<const float4*>(abase + (g_lo >> kqs) * tstep + (g_lo & kqm) * 16);
@@ -1069,6 +1084,8 @@ __device__ __forceinline__ void mg_embed_row(const A& a, const RowTab& tb, const
 }
 
 // cross attention of tile rows r0, r0 + 1 (two heads: waves 0-1 take row r0, waves 2-3 row r0 + 1); LDS: 2 x [sq 1024 | sp 2 x 512]
+// The K / V rows of a slot are read-only for the launch: their loads are batched 8 deep (the serial form - one load, one
+// multiply-add - made this operator 26 us of L2 latency for 38 keys).
 constexpr int XA2_LDS_FLOATS = 1024 + 2 * XA_MAX_S;
 template <class A>
 __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, const int r0, float* __restrict__ lds) {
@@ -1091,7 +1108,13 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
       const float* kp = kv + (long long)s * 2 * a.E + h * dh;
       const float4* qp = reinterpret_cast<const float4*>(sq + h * dh);
       float sc = 0.f;
-      for (int d = 0; d < dh / 4; ++d) { float4 k4 = ldw4(kp + 4 * d), q4 = qp[d]; sc += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w; }
+      for (int d0 = 0; d0 < dh / 4; d0 += 8) {
+        float4 k4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k4[u] = d0 + u < dh / 4 ? ldw4(kp + 4 * (d0 + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (d0 + u < dh / 4) { const float4 q4 = qp[d0 + u]; sc += q4.x * k4[u].x + q4.y * k4[u].y + q4.z * k4[u].z + q4.w * k4[u].w; }
+      }
       sc += ldw1(km + s);
       sp[h][s] = sc;
       mx = fmaxf(mx, sc);
@@ -1109,7 +1132,13 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
     for (int d = lane; d < dh; d += 64) {
       float acc = 0.f;
       const float* vp = kv + a.E + h * dh + d;
-      for (int s = 0; s < S; ++s) acc += sp[h][s] * ldw1(vp + (long long)s * 2 * a.E);
+      for (int s0 = 0; s0 < S; s0 += 8) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = s0 + u < S ? ldw1(vp + (long long)(s0 + u) * 2 * a.E) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (s0 + u < S) acc += sp[h][s0 + u] * vv[u];       // (the same additions in the same order as the serial loop)
+      }
       st1<true>(o + h * dh + d, acc);
     }
   }

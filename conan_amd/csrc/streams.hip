@@ -403,7 +403,12 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       ConvArgs a = mk(ctx->conv("voc.ups." + std::to_string(i)), i == 0 ? v_pre.ref() : v_st[i - 1].xs.ref(), s.up.ref(), n, Tin, pos, 1,
                       lookahead ? 0 : -1);
       if (!s.fused) { a.y2_base = s.upa.base; a.y2_slope = LR; }
-      conv(a, st);
+      {
+        // developer switch: CONAN_UPS_CFG=c0,c1,c2,c3 forces the tile configuration (ConvCfg index) of the i-th upsampler
+        static const std::vector<int> forced = [] { std::vector<int> v; const char* e = getenv("CONAN_UPS_CFG"); if (e) { std::string t(e); size_t p = 0; while (p <= t.size()) { size_t q = t.find(',', p); if (q == std::string::npos) q = t.size(); v.push_back(atoi(t.substr(p, q - p).c_str())); p = q + 1; } } return v; }();
+        if (i < (int)forced.size() && forced[i] >= 0 && forced[i] < cnk::NUM_CFG) { ConvGroup g; g.p[0] = a; launch_group(g, 1, forced[i], st); }
+        else conv(a, st);
+      }
       if (taps) tap(taps->ups[i], s.up, T);
     }
     for (int d = 0; d < ND && s.pair; ++d) {    // ResBlock1 of the wide first stage: pairs of workgroups per (branch, stream) tile

@@ -10,9 +10,11 @@ cd /tmp && export TMPDIR=/tmp
 cd /root/repo
 O=gpurun_out/${R}_prof_$W; rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --workload $W --steps 30 --warmup 5 --no-cpu-baseline --no-b1 > $O/stats.log 2>&1
-# the same kernels in blocking steps only (the schedule bench.py's roofline events are taken in): under the tracer the pipelined
-# run above is host-bound and its stages collide in ways the untraced run does not show ("What the stages cost each other")
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_blocking -o run -- python3 bench.py --workload $W --steps 1 --warmup 0 --latency-steps 60 --no-cpu-baseline --no-b1 > $O/stats_blocking.log 2>&1
+# the same kernels in blocking steps only (the schedule bench.py's roofline events are taken in), restricted to the dispatches
+# between two profile marks (tools/blocking_trace.py: 6 timed steps; tools/marked_stats.py) - the per-utterance style pass runs
+# the same conv_mfma instantiations as the upsamplers and must not be averaged into them
+rocprofv3 --kernel-trace --output-format csv -d $O/stats_blocking -o run -- python3 tools/blocking_trace.py 64 > $O/stats_blocking.log 2>&1
+python3 tools/marked_stats.py $O/stats_blocking/run_kernel_trace.csv 6 > $O/stats_blocking/run_kernel_stats.csv
 CMD="python3 bench.py --workload $W --steps $STEPS --warmup 3 --marks"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   T=$(echo $C | tr ' ' '_')
