@@ -642,8 +642,10 @@ __device__ __forceinline__ RowId row_id(const RowTab& tb, const int r) {
 
 // gather the tile's input window of operator `a` into LDS (win = lds: [wr_max][Cin + 8]), LayerNorm of the new rows in place;
 // `first` (the member that owns strip 0) appends the normalised rows to the layer's ring and writes the block mask
+// (sb of nact: this member's index among the members that stage this operator - the normalised rows they all compute are
+// appended to the layer's ring / the block mask is written by member row % nact, so that no single member carries the stores)
 template <class A>
-__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const bool first) {
+__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const int sb, const int nact) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));             // (no hoisting of per-lane arithmetic out of this function: the 80-register bound is tight)
   const int lane = tid & 63;
@@ -694,51 +696,51 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
   }
   __syncthreads();
   if (a.ln) {
+    // only the tile's own rows are new (rows of earlier steps come out of the ring normalised): tile row r = window row tab[r],
+    // 16 lanes per row, the 16 rows in one pass over the 4 waves
     const int sub = lane >> 4, l16 = lane & 15;
-    for (int w = wave * 4 + sub; w < ((WR + 15) & ~15); w += 16) {
-      const bool inw = w < WR;
-      const int sg = wseg(inw ? w : 0);
-      const int tau = tb.seg_t0[sg] - halo + ((inw ? w : 0) - (tb.seg_r0[sg] + sg * halo));
-      const bool live = inw && tau >= 0;
-      float* wrow = win + (inw ? w : 0) * LDX;
-      float4 v[8];                                          // Cin <= 512: 8 float4 per lane
-      float sum = 0.f, sa = 0.f;
+    const int r = wave * 4 + sub;
+    const bool live = r < tb.nvalid;
+    const RowId id = row_id(tb, live ? r : 0);
+    float* wrow = win + (live ? r + (tb.row_seg[r] + 1) * halo : 0) * LDX;      // (tab[r] is the row's OLDEST tap; its own row is halo rows on)
+    float4 v[8];                                          // Cin <= 512: 8 float4 per lane
+    float sum = 0.f, sa = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = (l16 + 16 * q) * 4;
+      v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+      sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
+    const float mean = sum / (float)Cin;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = (l16 + 16 * q) * 4;
+      if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = 1.0f / sqrtf(var / (float)Cin + a.eps);
+    if (live) {
+      const bool mine = (r % nact) == sb;
+      float mk = 1.f;
+      if (a.has_lnmask) mk = ld1<true>(row(a.lnmask, id.i, id.slot, id.pos, id.t));
+      float* hrow = row(a.hist, id.i, id.slot, id.pos, id.t);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int c = (l16 + 16 * q) * 4;
-        v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
-        sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
-      const float mean = sum / (float)Cin;
-      float var = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = (l16 + 16 * q) * 4;
-        if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
-      const float rstd = 1.0f / sqrtf(var / (float)Cin + a.eps);
-      if (live) {
-        float mk = 1.f;
-        if (a.has_lnmask) mk = ld1<true>(row(a.lnmask, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau));
-        float* hrow = row(a.hist, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int c = (l16 + 16 * q) * 4;
-          if (c < Cin) {
-            const float4 g = ldw4(a.gamma + c), bb = ldw4(a.beta + c);
-            const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
-                                         ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
-            *reinterpret_cast<float4*>(wrow + c) = o;
-            if (first) st4<true>(hrow + c, o);
-          }
+        if (c < Cin) {
+          const float4 g = ldw4(a.gamma + c), bb = ldw4(a.beta + c);
+          const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
+                                       ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
+          *reinterpret_cast<float4*>(wrow + c) = o;
+          if (mine) st4<true>(hrow + c, o);
         }
-        if (a.has_mask_out && first && l16 == 0) st1<true>(row(a.mask_out, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau), sa > 0.f ? 1.f : 0.f);
       }
+      if (a.has_mask_out && mine && l16 == 0) st1<true>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f);
     }
     __syncthreads();
   }
@@ -749,15 +751,18 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
 // Warm the L2 with the first 8 KB of this wave's weight stream for strip bx (one dword per 128-byte line and lane, result
 // unused) BEFORE the window gather: the stream's cold start - an L2 miss to HBM - then overlaps the gather's round trip instead
 // of following it.  (Holding the fragments themselves in registers across the gather + LayerNorm spilled 200 registers.)
+// The loaded word is returned and must be kept alive (mg_keep) past the point where the weights are used: the register of a
+// load the compiler believes dead is reused while the load is still in flight.
+__device__ __forceinline__ void mg_keep(const float t) { asm volatile("" ::"v"(t)); }
 template <int KW, class A>
-__device__ __forceinline__ void mg_wwarm(const A& a, const int bx) {
+__device__ __forceinline__ float mg_wwarm(const A& a, const int bx) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
   const int ct0 = KW > 1 ? bx : bx * 4 + wave;
   const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
   const float* wl = a.w + (long long)ct0 * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
-  if (ct0 * 16 < a.Cout_pad) { float t; asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(wl) : "memory"); (void)t; }
+  return ct0 * 16 < a.Cout_pad ? ldw1(wl) : 0.f;
 }
 
 template <int KW, bool PRE, class A>
