@@ -671,16 +671,7 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
       const int w = e < total ? e / C4 : 0, c4 = e < total ? e - w * C4 : 0;
       const int sg = wseg(w);
       const int tau = tb.seg_t0[sg] - halo + (w - (tb.seg_r0[sg] + sg * halo));   // time index within this step (negative: earlier steps)
-      if (a.xparts > 0 && tau >= 0) {
-        // the new rows of x are the sum of the group members' partial tensors (+ bias, + residual), summed in member order
-        const long long off = (long long)(tb.seg_i[sg] * a.T + tau) * a.xp_ld + c4 * 4;
-        float4 acc = ld4<true>(a.xp + off);
-        for (int p = 1; p < a.xparts; ++p) { const float4 q = ld4<true>(a.xp + p * a.xp_stride + off); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
-        if (a.xbias) { const float4 q = ldw4(a.xbias + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
-        if (a.has_xres) { const float4 q = ld4<true>(row(a.xres, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau) + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
-        v[u] = acc;
-        continue;
-      }
+      if (a.xparts > 0 && tau >= 0) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // (summed from the partial tensors below)
       const float* src = (a.ln && tau >= 0) ? row(a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau)
                                             : row(a.ln ? a.hist : a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau);
       v[u] = ld4<true>(src + c4 * 4);
@@ -691,7 +682,34 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
       const int e = e0 + tid + 256 * u;
       float4 q = v[u];
       q.x *= q.x > 0.f ? 1.0f : isl; q.y *= q.y > 0.f ? 1.0f : isl; q.z *= q.z > 0.f ? 1.0f : isl; q.w *= q.w > 0.f ? 1.0f : isl;
-      if (e < total) { const int w = e / C4, c4 = e - w * C4; *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = q; }
+      if (e < total) {
+        const int w = e / C4, c4 = e - w * C4;
+        bool part = false;
+        if (a.xparts > 0) { const int sg = wseg(w); part = tb.seg_t0[sg] - halo + (w - (tb.seg_r0[sg] + sg * halo)) >= 0; }
+        if (!part) *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = q;
+      }
+    }
+  }
+  if (a.xparts > 0) {
+    // the NEW rows of x are the sum of the group members' partial tensors (+ bias, + residual), summed in member order; one
+    // 16-byte column group at a time with all its partial loads in flight
+    const int nq = tb.nvalid * C4;
+#pragma unroll 1
+    for (int e = tid; e < nq; e += 256) {
+      const int r = e / C4, c4 = e - r * C4;
+      const RowId id = row_id(tb, r);
+      const long long off = (long long)(id.i * a.T + id.t) * a.xp_ld + c4 * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p0 = 0; p0 < a.xparts; p0 += 8) {
+        float4 pv[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) pv[p] = p0 + p < a.xparts ? ld4<true>(a.xp + (p0 + p) * a.xp_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) if (p0 + p < a.xparts) { if (p0 + p == 0) acc = pv[p]; else { acc.x += pv[p].x; acc.y += pv[p].y; acc.z += pv[p].z; acc.w += pv[p].w; } }
+      }
+      if (a.xbias) { const float4 q = ldw4(a.xbias + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+      if (a.has_xres) { const float4 q = ld4<true>(row(a.xres, id.i, id.slot, id.pos, id.t) + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+      *reinterpret_cast<float4*>(win + (r + (tb.row_seg[r] + 1) * halo) * LDX + c4 * 4) = acc;
     }
   }
   __syncthreads();
@@ -1038,8 +1056,13 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
     if (c < a.C) {
       if (a.xparts > 0) {       // x = the sum of the group members' partial tensors (+ bias, + residual), in member order
         const long long off = (long long)(id.i * a.T + id.t) * a.xp_ld + c;
-        u = ld1<true>(a.xp + off);
-        for (int p = 1; p < a.xparts; ++p) u += ld1<true>(a.xp + p * a.xp_stride + off);
+        float pv[8];
+        for (int p0 = 0; p0 < a.xparts; p0 += 8) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p) pv[p] = p0 + p < a.xparts ? ld1<true>(a.xp + (p0 + p) * a.xp_stride + off) : 0.f;
+#pragma unroll
+          for (int p = 0; p < 8; ++p) if (p0 + p < a.xparts) u = p0 + p == 0 ? pv[p] : u + pv[p];
+        }
         if (a.xbias) u += ldw1(a.xbias + c);
         if (a.has_xres) u += ld1<true>(row(a.xres, id.i, id.slot, id.pos, id.t) + c);
       } else u = ld1<true>(x + c);
