@@ -138,7 +138,10 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   // shorten, and a grid-wide barrier per operator costs what the launch boundaries do (0.47 against 0.39 ms at one stream).
   static const bool mega_single = getenv("CONAN_MEGA_SINGLE") != nullptr;
   const bool tiles_ok = (16 % T == 0 && n * T > 16) || (n * T <= 16 && mega_single);
-  if (use_mega && notaps && tiles_ok && mega_bar && run_mega(n, T, codes, mel_out, ex, st)) return;
+  // (the per-op Emformer plan - memory bank, shapes the fused step does not cover - is ~90 launches whose conv_mfma workgroups
+  // need CUs of their own: beside 128 resident decoder workgroups they queue, b128s2mem4 2.13 against 2.00 ms per step)
+  const bool emf_ok = !(ctx->cfg.models & CONAN_MODEL_EMFORMER) || emf_fused;
+  if (use_mega && notaps && tiles_ok && emf_ok && mega_bar && run_mega(n, T, codes, mel_out, ex, st)) return;
   if (ex.codes_dst) HIP_CHECK(hipMemcpyAsync(ex.codes_dst, ex.codes_src, (size_t)ex.codes_words * sizeof(int), hipMemcpyDeviceToDevice, st));
   decoder_ops(n, T, codes, mel_out, taps, st);
   if (ex.mel_out2) HIP_CHECK(hipMemcpyAsync(ex.mel_out2, mel_out, (size_t)n * T * ctx->cfg.num_mels * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -8,7 +8,8 @@ sys.path.insert(0, '.')
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-ctx, chp, vhp = bench.build_context(0)
+WL = bench.WORKLOADS[sys.argv[3]] if len(sys.argv) > 3 else bench.WORKLOADS["b64"]      # optional third argument: a stateful bench workload (chunk size, memory bank)
+ctx, chp, vhp = bench.build_context(0, WL["chunk_ms"], WL.get("memory", 0))
 eng, chunks = bench.make_engine(ctx, B, 0)
 st, slots, seg, hop = eng.st, eng.slots, eng.seg, ctx.hop
 bufs = [torch.empty(B, seg * hop, device='cuda') for _ in range(4)]
