@@ -35,6 +35,9 @@
 
 namespace cnk {
 
+#ifndef MG_POLL_SLEEP
+#define MG_POLL_SLEEP 1
+#endif
 typedef const int __attribute__((address_space(4)))* mg_cci;
 #define MG_AS4(T, p) (*(const T __attribute__((address_space(4)))*)(p))
 
@@ -56,7 +59,7 @@ __device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target)
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before the workgroup's one arrival
-    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
   }
   __syncthreads();
 }

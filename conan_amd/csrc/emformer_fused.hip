@@ -174,8 +174,13 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
   // per-layer small parameters, staged in LDS one layer ahead (EmfLayerW::params)
   constexpr int PB_BQ = 0, PB_BKV = D, PB_BO = 3 * D, PB_B2 = 4 * D, PB_LNIN = 5 * D, PB_LNFF = 7 * D, PB_LNOUT = 9 * D, PB_B1 = 11 * D;
   static_assert(DH % 2 == 0 && DH <= 16, "head dim");
-  const int R = a.R, U = a.U, Q = R + U, H = a.H, G = ef_streams_per_block(Q, H);
-  const int nkmax = R + a.LC + U;
+  // Memory bank (torchaudio max_memory_size = M > 0): a stream takes two more rows of the tile - the summary token (mean of
+  // the normalised segment; a query only) and the layer's memory INPUT of this step (raw; through the key / value projection
+  // only, its K / V rows join the layer's bank for the following steps: the bank holds projected entries, which is the same
+  // arithmetic as projecting the raw entries again every step) - and its key table begins with the bank's valid entries.
+  const int M = a.M;
+  const int R = a.R, U = a.U, Q = R + U, QM = Q + (M > 0 ? 2 : 0), H = a.H, G = ef_streams_per_block(QM, H);
+  const int nkmax = M + R + a.LC + U;
   const int par = PB_B1 + a.F;           // floats per layer parameter block (multiple of 4)
   float* X = sm;                         // [16][ld] layer input / residual
   float* Y = X + EF_ROWS * ld;           // [16][ld] LN output
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
   float* PB = Hb + ef_scratch_floats(D, a.K);      // [2][par]
   float* KB = PB + 2 * par;              // [G][nkmax][ldk] keys:  rc | cached | utt
   float* VB = KB + G * nkmax * ldk;      // [G][nkmax][ldk] values
+  float* MEMB = VB + G * nkmax * ldk;    // [G][D] the layer's memory input (layer 0: mean of the raw segment; then the clamped summary output)
   float* RED = Hb;                       // [4][16][ld]
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -195,30 +201,37 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
   const int cluster = (int)(blockIdx.x >> csh), member = (int)(blockIdx.x & (cs - 1));
   const int i0 = cluster * G;
   const int ng = (a.n - i0) < G ? (a.n - i0) : G;      // streams in this block
-  const int nrows = ng * Q;
+  const int nrows = ng * QM;
   unsigned xtarget = 0;
   if (cs > 1) xtarget = __hip_atomic_load(a.xepoch + cluster, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 
   // ---- everything that depends on slots / past is computed once: no global loads other than the prefetches below
   // happen inside the layer loop (vmcnt retires in order, so a late small load would wait for the prefetches)
   // (a) this lane's GEMM output rows r = (lane>>4)*4 + r4: key-table row offset and ring append offset
-  int tab_off[4], ring_off[4];
+  int tab_off[4], ring_off[4], bank_off[4], rtok[4];
 #pragma unroll
   for (int r4 = 0; r4 < 4; ++r4) {
-    const int r = (lane >> 4) * 4 + r4, g = r / Q, tok = r - g * Q;
-    tab_off[r4] = -1; ring_off[r4] = -1;
+    const int r = (lane >> 4) * 4 + r4, g = r / QM, tok = r - g * QM;
+    tab_off[r4] = -1; ring_off[r4] = -1; bank_off[r4] = -1; rtok[r4] = g < ng ? tok : QM;
     if (g < ng) {
       const int slot = a.slots[i0 + g], past = a.past[slot], Lc = past < a.LC ? past : a.LC;
-      tab_off[r4] = (g * nkmax + (tok < R ? tok : R + Lc + (tok - R))) * ldk;
-      if (tok >= R && member == 0) ring_off[r4] = (int)(slot * a.ring_slot_stride) + (int)((unsigned)(past + tok - R) & (unsigned)a.lmask) * D;
+      const int nseg = M > 0 ? (past + U - 1) / U : 0, pm = nseg < M ? nseg : M;      // valid bank entries (_unpack_state)
+      if (tok < Q) tab_off[r4] = (g * nkmax + pm + (tok < R ? tok : R + Lc + (tok - R))) * ldk;
+      if (tok >= R && tok < Q && member == 0) ring_off[r4] = (int)(slot * a.ring_slot_stride) + (int)((unsigned)(past + tok - R) & (unsigned)a.lmask) * D;
+      if (tok == Q + 1 && member == 0) bank_off[r4] = (int)(slot * a.bank_slot_stride) + (nseg & (a.MB - 1)) * D;      // _pack_state: this step's entry
     }
   }
   // (b) attention: a 16-lane row per (stream, head)
   const int pr = tid >> 4, l16 = tid & 15;
   const bool pok = pr < ng * H;
   const int pg = pok ? pr / H : 0, ph = pok ? pr - pg * H : 0;
-  int nk = 0;
-  if (pok) { const int past = a.past[a.slots[i0 + pg]]; nk = R + (past < a.LC ? past : a.LC) + U; }
+  int nk = 0, pmq = 0;                   // keys of the (stream, head) row; of which memory entries (the summary query does not see them)
+  if (pok) {
+    const int past = a.past[a.slots[i0 + pg]];
+    const int nseg = M > 0 ? (past + U - 1) / U : 0;
+    pmq = nseg < M ? nseg : M;
+    nk = pmq + R + (past < a.LC ? past : a.LC) + U;
+  }
   // (c) cached-row prefetch plan (shared by K and V): unit e -> (g, j, c4); ring byte offset (-1: none), table offset
   constexpr int f4 = D / 4;
   int soff[EF_CR], doff[EF_CR];
@@ -231,24 +244,47 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       soff[i] = -1; doff[i] = 0;
       if (g < ng) {
         const int slot = a.slots[i0 + g], past = a.past[slot], Lc = past < a.LC ? past : a.LC;
+        const int nseg = M > 0 ? (past + U - 1) / U : 0, pm = nseg < M ? nseg : M;
         if (j < Lc) {
           soff[i] = ((int)(slot * a.ring_slot_stride) + (int)((unsigned)(past - Lc + j) & (unsigned)a.lmask) * D + c4 * 4) * 4;
-          doff[i] = (g * nkmax + R + j) * ldk + c4 * 4;
+          doff[i] = (g * nkmax + pm + R + j) * ldk + c4 * 4;
         }
+      }
+    }
+  }
+  // (d) bank-row prefetch plan: unit tid -> (g, m, c4), one per thread (G * M * D/4 <= 256)
+  int msoff = -1, mdoff = 0;
+  if (M > 0) {
+    const int per_g = M * f4, g = tid / per_g, rem = tid - g * per_g, m = rem / f4, c4 = rem - m * f4;
+    if (g < ng) {
+      const int slot = a.slots[i0 + g], past = a.past[slot];
+      const int nseg = (past + U - 1) / U, pm = nseg < M ? nseg : M;
+      if (m < pm) {       // entry of segment nseg - pm + m lives in bank row (nseg - pm + m) % MB
+        msoff = ((int)(slot * a.bank_slot_stride) + ((nseg - pm + m) & (a.MB - 1)) * D + c4 * 4) * 4;
+        mdoff = (g * nkmax + m) * ldk + c4 * 4;
       }
     }
   }
 
   // ---- load the chunk (token order [rc | utt]; the chunk is [utt(U) | rc(R)] per stream) and layer 0's parameters
   for (int e = tid; e < EF_ROWS * ld; e += 256) {
-    const int r = e / ld, c = e - r * ld, g = r / Q, tok = r - g * Q;
+    const int r = e / ld, c = e - r * ld, g = r / QM, tok = r - g * QM;
     float v = 0.f;
-    if (r < nrows && c < D) v = a.chunk[((long long)(i0 + g) * Q + (tok < R ? U + tok : tok - R)) * D + c];
+    if (r < nrows && tok < Q && c < D) v = a.chunk[((long long)(i0 + g) * Q + (tok < R ? U + tok : tok - R)) * D + c];
     X[e] = v; Y[e] = 0.f; Qb[e] = 0.f; ATT[e] = 0.f; R1[e] = 0.f;
   }
   for (int e = tid; e < par / 4; e += 256) reinterpret_cast<float4*>(PB)[e] = reinterpret_cast<const float4*>(a.layers[0].params)[e];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ef_barrier();
+  if (M > 0) {      // _EmformerImpl.infer: the first layer's memory input is the mean of the raw segment
+    for (int e = tid; e < G * D; e += 256) {
+      const int g = e / D, c = e - g * D;
+      float sm_ = 0.f;
+      for (int u = 0; u < U; ++u) sm_ += X[(g * QM + R + u) * ld + c];
+      MEMB[e] = sm_ / (float)U;
+    }
+    ef_barrier();
+  }
 
   for (int l = 0; l < a.L; ++l) {
     const EmfLayerW& w = a.layers[l];
@@ -265,6 +301,11 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
         if (soff[i] >= 0) { crk[i] = *reinterpret_cast<const float4*>(kbase + (unsigned)soff[i]); crv[i] = *reinterpret_cast<const float4*>(vbase + (unsigned)soff[i]); }
       }
     }
+    float4 cmk = make_float4(0.f, 0.f, 0.f, 0.f), cmv = cmk;         // this thread's bank row unit
+    if (msoff >= 0) {
+      cmk = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.bank_k[l]) + (unsigned)msoff);
+      cmv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.bank_v[l]) + (unsigned)msoff);
+    }
     float4 bqkv[TQ][KQD];
 #pragma unroll
     for (int i = 0; i < TQ; ++i) {
@@ -280,6 +321,16 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     // 1. layer_norm_input
     ef_layernorm<KQD>(X, Y, ld, pb + PB_LNIN, pb + PB_LNIN + D, tid);
     ef_barrier();
+    if (M > 0) {      // summary row = mean of the normalised segment (memory_op); memory-input row = the raw memory input
+      for (int e = tid; e < G * D; e += 256) {
+        const int g = e / D, c = e - g * D;
+        float sm_ = 0.f;
+        for (int u = 0; u < U; ++u) sm_ += Y[(g * QM + R + u) * ld + c];
+        Y[(g * QM + Q) * ld + c] = sm_ / (float)U;
+        Y[(g * QM + Q + 1) * ld + c] = MEMB[e];
+      }
+      ef_barrier();
+    }
     EF_STAMP(1);
     // 2. [q | k | v] = Y x [Wq | Wkv] + b : q (scaled) -> Qb, k / v -> key tables (+ ring append for utterance rows)
     {
@@ -303,11 +354,13 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
             const int c = isv ? ckv - D : ckv;
             float* tab = isv ? VB : KB;
             float* ring = isv ? a.vring[l] : a.kring[l];
+            float* bank = isv ? a.bank_v[l] : a.bank_k[l];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               const float v = accq[i][r4] + bias;
               if (tab_off[r4] >= 0) tab[tab_off[r4] + c] = v;
               if (ring_off[r4] >= 0) ring[ring_off[r4] + c] = v;
+              if (bank_off[r4] >= 0) bank[bank_off[r4] + c] = v;
             }
           }
         }
@@ -324,6 +377,14 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
         *reinterpret_cast<float2*>(dv) = make_float2(crv[i].x, crv[i].y);
         *reinterpret_cast<float2*>(dv + 2) = make_float2(crv[i].z, crv[i].w);
       }
+    if (msoff >= 0) {      // bank rows -> the head of the key tables
+      float* dk = KB + mdoff;
+      float* dv = VB + mdoff;
+      *reinterpret_cast<float2*>(dk) = make_float2(cmk.x, cmk.y);
+      *reinterpret_cast<float2*>(dk + 2) = make_float2(cmk.z, cmk.w);
+      *reinterpret_cast<float2*>(dv) = make_float2(cmv.x, cmv.y);
+      *reinterpret_cast<float2*>(dv + 2) = make_float2(cmv.z, cmv.w);
+    }
     float4 bo[TO][KQD];
 #pragma unroll
     for (int i = 0; i < TO; ++i) {
@@ -354,8 +415,10 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
           }
         }
       }
-      for (int qi = 0; qi < Q; ++qi) {
-        const float* qp = Qb + (pg * Q + qi) * ld + ph * DH;
+      const int nq = Q + (M > 0 ? 1 : 0);            // the summary token is the last query
+      for (int qi = 0; qi < nq; ++qi) {
+        const int klo = qi == Q ? pmq : 0;           // ... and does not see the memory columns (attention_mask[-1, :mems])
+        const float* qp = Qb + (pg * QM + qi) * ld + ph * DH;
         float2 q2[DH / 2];
 #pragma unroll
         for (int d = 0; d < DH / 2; ++d) q2[d] = *reinterpret_cast<const float2*>(qp + 2 * d);
@@ -367,14 +430,14 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
             float s0 = 0.f;
 #pragma unroll
             for (int d = 0; d < DH / 2; ++d) { s0 += q2[d].x * kreg[j][d].x; s0 += q2[d].y * kreg[j][d].y; }
-            sc[j] = (l16 + 16 * j) < nk ? s0 : -INFINITY;
+            sc[j] = ((l16 + 16 * j) < nk && (l16 + 16 * j) >= klo) ? s0 : -INFINITY;
             mx = fmaxf(mx, sc[j]);
           }
         }
         mx = ef_row_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < EF_MAXJ; ++j) { sc[j] = (j < jmax && (l16 + 16 * j) < nk) ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
+        for (int j = 0; j < EF_MAXJ; ++j) { sc[j] = (j < jmax && (l16 + 16 * j) < nk && (l16 + 16 * j) >= klo) ? expf(sc[j] - mx) : 0.f; sum += sc[j]; }
         const float inv = 1.0f / ef_row_sum(sum);
         float o[DH];
 #pragma unroll
@@ -388,7 +451,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
         float mine = 0.f;
 #pragma unroll
         for (int d = 0; d < DH; ++d) { const float t = ef_row_sum(o[d]); if (l16 == d) mine = t; }
-        if (pok && l16 < DH) ATT[(pg * Q + qi) * ld + ph * DH + l16] = mine * inv;
+        if (pok && l16 < DH) ATT[(pg * QM + qi) * ld + ph * DH + l16] = mine * inv;
       }
     }
     ef_barrier();
@@ -403,7 +466,17 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
         const int col = t * 16 + (lane & 15);
         const float bias = pb[PB_BO + col];
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) { const int r = (lane >> 4) * 4 + r4; R1[r * ld + col] = acc[r4] + bias + X[r * ld + col]; }
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int r = (lane >> 4) * 4 + r4;
+          float v = acc[r4] + bias + X[r * ld + col];
+          if (M > 0 && rtok[r4] >= Q) {
+            // the summary row's attention output (no residual) is the NEXT layer's memory input, clamped / tanh'd
+            // (_EmformerAttention._forward_impl); it and the memory-input row take no part in the rest of the layer
+            if (rtok[r4] == Q) { const float o = acc[r4] + bias; MEMB[(r / QM) * D + col] = a.tanh_on_mem ? tanhf(o) : fminf(fmaxf(o, -10.f), 10.f); }
+            v = 0.f;
+          }
+          R1[r * ld + col] = v;
+        }
       }
     }
     // 5. pos_ff: LN -> Linear(D, F) -> ReLU -> Linear(F, D); hidden in EF_HCHUNK-wide chunks, weights one phase ahead
@@ -535,6 +608,13 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     }
     ef_barrier();
     ef_layernorm<KQD>(ATT, X, ld, pb + PB_LNOUT, pb + PB_LNOUT + D, tid);
+    if (M > 0) {      // the summary / memory-input rows carry no layer input (their residual is zero): the row's own lanes clear them
+      const int r = tid >> 4, c0 = tid & 15;
+      if (r - (r / QM) * QM >= Q) {
+#pragma unroll
+        for (int i = 0; i < KQD; ++i) X[r * ld + c0 + 16 * i] = 0.f;
+      }
+    }
     if (l + 1 < a.L) {
       float4* dst = reinterpret_cast<float4*>(PB + ((l + 1) & 1) * par);
 #pragma unroll
@@ -550,7 +630,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
   if (a.out)
     for (int e = tid; e < ng * U * D; e += 256) {
       const int g = e / (U * D), rem = e - g * U * D, u = rem / D, c = rem - u * D;
-      a.out[((long long)(i0 + g) * U + u) * D + c] = X[(g * Q + R + u) * ld + c];
+      a.out[((long long)(i0 + g) * U + u) * D + c] = X[(g * QM + R + u) * ld + c];
     }
   if (a.logits || a.codes) {
     float* LG = Hb;                       // [16][K + 4]
@@ -577,7 +657,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     for (int ru = tid >> 4; ru < G * U; ru += 16) {
       const int g = ru / U, u = ru - g * U;
       const bool ok = g < ng;
-      const float* row = LG + (g * Q + R + u) * ldl;
+      const float* row = LG + (g * QM + R + u) * ldl;
       const long long orow = (long long)(i0 + g) * U + u;
       float best = -INFINITY; int bi = 0x7fffffff;
       for (int c = l16; c < a.K; c += 16) {
@@ -595,15 +675,16 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
 }
 
 size_t emformer_fused_smem(const EmfFusedArgs& a) {
-  const int D = a.D, Q = a.R + a.U, G = ef_streams_per_block(Q, a.H);
-  const int ld = D + 4, ldk = D + 2, nkmax = a.R + a.LC + a.U;
-  return (size_t)(EF_ROWS * ld * 5 + ef_scratch_floats(D, a.K) + 2 * (11 * D + a.F) + 2 * G * nkmax * ldk) * sizeof(float);
+  const int D = a.D, QM = a.R + a.U + (a.M > 0 ? 2 : 0), G = ef_streams_per_block(QM, a.H);
+  const int ld = D + 4, ldk = D + 2, nkmax = a.M + a.R + a.LC + a.U;
+  return (size_t)(EF_ROWS * ld * 5 + ef_scratch_floats(D, a.K) + 2 * (11 * D + a.F) + 2 * G * nkmax * ldk + G * D) * sizeof(float);
 }
 
 bool emformer_fused_supported(const EmfFusedArgs& a) {
-  const int Q = a.R + a.U;
-  if (Q < 1 || Q > EF_ROWS || a.H < 1 || a.H > 16) return false;
-  const int G = ef_streams_per_block(Q, a.H), nkmax = a.R + a.LC + a.U, dh = a.D / a.H;
+  const int Q = a.R + a.U + (a.M > 0 ? 2 : 0);      // rows per stream (with a memory bank: + summary + memory input)
+  if (Q < 1 || Q > EF_ROWS || a.H < 1 || a.H > 16 || a.M < 0) return false;
+  const int G = ef_streams_per_block(Q, a.H), nkmax = a.M + a.R + a.LC + a.U, dh = a.D / a.H;
+  if (a.M > 0 && (G < 1 || G * a.M * (a.D / 4) > 256 || a.MB <= a.M || (a.MB & (a.MB - 1)) || a.U < 1)) return false;
   return ((a.D == 80 && dh == 10) || (a.D == 64 && dh == 8)) && a.D % a.H == 0 && a.F % EF_HCHUNK == 0 && a.F >= EF_HCHUNK &&
          11 * a.D + a.F <= EF_PP * 256 * 4 && nkmax <= 16 * EF_MAXJ && G * a.LC * (a.D / 4) <= EF_CR * 256 && a.L >= 1 && a.L <= EMF_MAX_LAYERS &&
          (a.wp != nullptr || a.K == a.D) && emformer_fused_smem(a) <= 160 * 1024;
@@ -611,7 +692,7 @@ bool emformer_fused_supported(const EmfFusedArgs& a) {
 
 template <int KQD, int DH>
 static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
-  const int G = ef_streams_per_block(a.R + a.U, a.H);
+  const int G = ef_streams_per_block(a.R + a.U + (a.M > 0 ? 2 : 0), a.H);
   // the attribute is per device (the code object is loaded once per device): remember which devices have it
   static std::atomic<unsigned long long> attr_devs{0};
   int dev = 0;
@@ -627,7 +708,7 @@ static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH>), dim3(((a.n + G - 1) / G) * b.cs), dim3(256), emformer_fused_smem(a), st, b);
 }
 
-int emformer_fused_streams_per_block(const EmfFusedArgs& a) { return ef_streams_per_block(a.R + a.U, a.H); }
+int emformer_fused_streams_per_block(const EmfFusedArgs& a) { return ef_streams_per_block(a.R + a.U + (a.M > 0 ? 2 : 0), a.H); }
 
 // instantiated shapes: (input_dim, head_dim) = (80, 10) is modules/Emformer/emformer.py's only configuration
 void launch_emformer_fused(const EmfFusedArgs& a, hipStream_t st) {

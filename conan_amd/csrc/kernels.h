@@ -285,6 +285,11 @@ struct EmfFusedArgs {
   unsigned* xflag;        // [cluster][EMF_MAX_LAYERS][EMF_MAX_CLUSTER] "partial of this launch is written" (= epoch + 1)
   unsigned* xepoch;       // [cluster] launches this cluster has taken part in
   int fenced;             // 1: release / acquire fences around the exchange as well (CONAN_FENCED=1 cross-check)
+  // memory bank (max_memory_size = M > 0): per layer the PROJECTED key / value rows of the last memory inputs, rings of MB >= M + 1
+  // (power of two) entries per slot; entry of segment number j in row j % MB
+  int M, MB, tanh_on_mem;
+  float* bank_k[EMF_MAX_LAYERS]; float* bank_v[EMF_MAX_LAYERS];
+  long long bank_slot_stride;
 };
 constexpr int EMF_MAX_CLUSTER = 8;
 // floats of xch / words of xflag+xepoch for up to `max_groups` stream groups

@@ -552,6 +552,13 @@ void conan_streams::build_emformer() {
     a.slots = d_slots; a.past = pos_emf;
     a.L = c.emf_layers; a.R = c.emf_right_context; a.U = c.emf_segment; a.D = D; a.H = c.emf_heads; a.LC = c.emf_left_context;
     a.F = c.emf_ffn_dim; a.K = c.emf_output_dim; a.scaling = 1.0f / std::sqrt((float)(D / c.emf_heads));
+    if (M > 0) {      // the one-launch step keeps the bank as projected key / value rows (the per-op plan below keeps raw entries in e_bank)
+      a.M = M; a.MB = e_bank_rows; a.tanh_on_mem = c.emf_tanh_on_mem; a.bank_slot_stride = (long long)e_bank_rows * D;
+      for (int l = 0; l < c.emf_layers; ++l) {
+        a.bank_k[l] = alloc((size_t)max_slots * e_bank_rows * D); emf_state.push_back({a.bank_k[l], a.bank_slot_stride});
+        a.bank_v[l] = alloc((size_t)max_slots * e_bank_rows * D); emf_state.push_back({a.bank_v[l], a.bank_slot_stride});
+      }
+    }
     { const unsigned long long per_g = (unsigned long long)std::max(c.emf_left_context, 1) * (D / 4); a.magic_per_g = (unsigned)(((1ull << 32) + per_g - 1) / per_g); }
     {  // cluster mode workspace (zeroed once: flags and epochs count up from there)
       const size_t xf = cnk::emformer_cluster_xch_floats(max_slots, D), fw = cnk::emformer_cluster_flag_words(max_slots);
@@ -563,7 +570,7 @@ void conan_streams::build_emformer() {
       emf_cluster = e ? atoi(e) : 0;       // 0: chosen per launch from the stream count
     }
     const char* off = getenv("CONAN_EMF_UNFUSED");
-    emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1') && M == 0;   // the one-launch step has no memory tokens
+    emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1');
   }
 }
 
@@ -590,7 +597,7 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
     }
     // algorithmic FLOPs of the step: per stream and layer Q = R + U query rows against the four D x D projections, the
     // D x F x 2 feed-forward, and attention over R + LC + U keys; plus the output projection
-    const double Q = R + U, Dd = D, F = c.emf_ffn_dim, keys = R + c.emf_left_context + U;
+    const double Q = R + U + (c.emf_max_memory_size > 0 ? 1 : 0), Dd = D, F = c.emf_ffn_dim, keys = c.emf_max_memory_size + R + c.emf_left_context + U;
     const double fl = (double)n * (c.emf_layers * (2.0 * Q * Dd * (4.0 * Dd + 2.0 * F) + 4.0 * Q * keys * Dd) + 2.0 * U * Dd * c.emf_output_dim);
     profiled(D == 80 ? "cnk::emformer_fused_kernel<5, 10>" : "cnk::emformer_fused_kernel<4, 8>", fl, st, [&] { cnk::launch_emformer_fused(a, st); });
     return;

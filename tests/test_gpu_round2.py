@@ -79,15 +79,22 @@ def test_emformer_against_torchaudio(variant):
     st.close(); ctx.close()
 
 
+@pytest.mark.parametrize("plan", ["fused", "per-op"])
 @pytest.mark.parametrize("M,tanh", [(4, False), (2, True)])
-def test_emformer_memory_bank_vs_oracle(M, tanh):
+def test_emformer_memory_bank_vs_oracle(M, tanh, plan, monkeypatch):
     """The memory bank of torchaudio's Emformer (max_memory_size > 0: summary token, per-layer bank of the last M segment
     memories as extra attention keys, clamp / tanh on the produced memory) - BASELINE.json north_star "memory-bank
     update".  modules/Emformer/emformer.py:14-22 never enables it, so this is an extra, non-parity datapoint: the HIP
-    per-op step against the oracle restatement (itself checked against a whole-sequence formulation on the CPU) over
+    step (one launch, or the per-op plan) against the oracle restatement (itself checked against a whole-sequence formulation on the CPU) over
     20 chunks: bank ramp-up, saturation and roll-over, left-context wrap, a stream restarted half way."""
     from oracle import emformer as oemf
     from oracle.common import to_torch_sd
+    # plan "fused": the one-launch step (round 3: summary and memory-input rows in the 16-row tile, the bank as projected key /
+    # value rows at the head of the key tables); "per-op": the separate kernels (CONAN_EMF_UNFUSED=1, read at stream-set creation)
+    if plan == "per-op":
+        monkeypatch.setenv("CONAN_EMF_UNFUSED", "1")
+    else:
+        monkeypatch.delenv("CONAN_EMF_UNFUSED", raising=False)
     chp = dict(configs.conan_hparams(), emformer_max_memory_size=M, emformer_tanh_on_mem=tanh)
     ctx, chp, _ = _ctx(chp, conan=False, hifigan=False)
     assert ctx.cfg.emf_max_memory_size == M
@@ -112,6 +119,12 @@ def test_emformer_memory_bank_vs_oracle(M, tanh):
         top2 = lg_ref.topk(2, -1).values
         safe = (top2[..., 0] - top2[..., 1]) > 1e-3
         assert torch.equal(codes.cpu().long()[safe], codes_ref[safe])
+    # which kernels ran: the one-launch step, or the per-op plan's attention kernel
+    st.profile_begin()
+    st.emformer_step(slots, chunk.cuda())
+    st.profile_end()
+    names = [k[0] for k in st.profile_kernels()]
+    assert any("emformer_fused_kernel" in k for k in names) == (plan == "fused"), names
     st.close(); ctx.close()
 
 
