@@ -10,7 +10,7 @@ chp, vhp = configs.conan_hparams(tiny), configs.hifigan_hparams(tiny)
 ctx = Context(chp, vhp, 0, True, True, True)
 ctx.load_state_dict("emformer", synth.emformer_state_dict(chp, 0)); ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0)); ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
 ctx.finalize()
-S = 12
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 12          # (>= 16: the first vocoder stage runs the pair kernel)
 a, b = ctx.streams(S, 4, 64), ctx.streams(S, 4, 64)
 ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 300
