@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __re
   ro::RowTab& tab = *reinterpret_cast<ro::RowTab*>(lds_all);
   float* const lds = lds_all + ro::ROWTAB_FLOATS;
   const int b = (int)blockIdx.x;
+#ifdef MG_PRIO
+  __builtin_amdgcn_s_setprio(MG_PRIO);      // developer build
+#endif
   const int NG = (int)gridDim.x / GS, g = b / GS, sb = b - g * GS;      // groups, this workgroup's group and member index
   // developer stamps (CONAN_MEGA_STAMPS=1): workgroup 0 notes the 100 MHz clock at the start and behind every operator (+ barrier)
   if (dbg && b == 0 && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();

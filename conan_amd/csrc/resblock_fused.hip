@@ -374,6 +374,9 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(const RBArgs a) 
   }
 
   // ============================================================== matrix waves
+#ifdef RB_MATRIX_PRIO
+  __builtin_amdgcn_s_setprio(RB_MATRIX_PRIO);      // developer build: matrix waves above the default priority of co-resident kernels
+#endif
   // Barriers are raw s_barrier behind an LDS-only wait: global loads (next phase's weights, biases) stay in flight
   // across them.
   auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };

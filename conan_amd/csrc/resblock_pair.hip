@@ -369,6 +369,9 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_kernel(const RPArgs a) {
   }
 
   // ============================================================== matrix waves
+#ifdef RB_MATRIX_PRIO
+  __builtin_amdgcn_s_setprio(RB_MATRIX_PRIO);      // developer build: matrix waves above the default priority of co-resident kernels
+#endif
   auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   const int lr = lane & 15, lg = lane >> 4;
   float4 bw[16];
