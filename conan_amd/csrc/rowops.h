@@ -662,7 +662,7 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
     return s;
   };
   const int total = WR * C4;
-  constexpr int GB = 4;
+  constexpr int GB = 8;                                  // 16-byte loads per thread in flight: the whole 32-row window of a k = 5 layer in one round trip
   for (int e0 = 0; e0 < total; e0 += 256 * GB) {
     float4 v[GB];
 #pragma unroll
