@@ -162,7 +162,7 @@ __host__ __device__ inline int ef_scratch_floats(int D, int K) {
 
 }  // namespace
 
-template <int KQD, int DH>
+template <int KQD, int DH, bool MEM>
 __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   constexpr int D = 16 * KQD;
@@ -178,8 +178,9 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
   // the normalised segment; a query only) and the layer's memory INPUT of this step (raw; through the key / value projection
   // only, its K / V rows join the layer's bank for the following steps: the bank holds projected entries, which is the same
   // arithmetic as projecting the raw entries again every step) - and its key table begins with the bank's valid entries.
-  const int M = a.M;
-  const int R = a.R, U = a.U, Q = R + U, QM = Q + (M > 0 ? 2 : 0), H = a.H, G = ef_streams_per_block(QM, H);
+  // MEM = false compiles the bank out: the register budget of the M = 0 build (the headline configuration) is not shared with it
+  const int M = MEM ? a.M : 0;
+  const int R = a.R, U = a.U, Q = R + U, QM = MEM && M > 0 ? Q + 2 : Q, H = a.H, G = ef_streams_per_block(QM, H);
   const int nkmax = M + R + a.LC + U;
   const int par = PB_B1 + a.F;           // floats per layer parameter block (multiple of 4)
   float* X = sm;                         // [16][ld] layer input / residual
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       const int nseg = M > 0 ? (past + U - 1) / U : 0, pm = nseg < M ? nseg : M;      // valid bank entries (_unpack_state)
       if (tok < Q) tab_off[r4] = (g * nkmax + pm + (tok < R ? tok : R + Lc + (tok - R))) * ldk;
       if (tok >= R && tok < Q && member == 0) ring_off[r4] = (int)(slot * a.ring_slot_stride) + (int)((unsigned)(past + tok - R) & (unsigned)a.lmask) * D;
-      if (tok == Q + 1 && member == 0) bank_off[r4] = (int)(slot * a.bank_slot_stride) + (nseg & (a.MB - 1)) * D;      // _pack_state: this step's entry
+      if (MEM && tok == Q + 1 && member == 0) bank_off[r4] = (int)(slot * a.bank_slot_stride) + (nseg & (a.MB - 1)) * D;      // _pack_state: this step's entry
     }
   }
   // (b) attention: a 16-lane row per (stream, head)
@@ -354,13 +355,13 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
             const int c = isv ? ckv - D : ckv;
             float* tab = isv ? VB : KB;
             float* ring = isv ? a.vring[l] : a.kring[l];
-            float* bank = isv ? a.bank_v[l] : a.bank_k[l];
+            float* bank = !MEM ? nullptr : isv ? a.bank_v[l] : a.bank_k[l];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               const float v = accq[i][r4] + bias;
               if (tab_off[r4] >= 0) tab[tab_off[r4] + c] = v;
               if (ring_off[r4] >= 0) ring[ring_off[r4] + c] = v;
-              if (bank_off[r4] >= 0) bank[bank_off[r4] + c] = v;
+              if (MEM && bank_off[r4] >= 0) bank[bank_off[r4] + c] = v;
             }
           }
         }
@@ -415,9 +416,9 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
           }
         }
       }
-      const int nq = Q + (M > 0 ? 1 : 0);            // the summary token is the last query
+      const int nq = MEM && M > 0 ? Q + 1 : Q;            // the summary token is the last query
       for (int qi = 0; qi < nq; ++qi) {
-        const int klo = qi == Q ? pmq : 0;           // ... and does not see the memory columns (attention_mask[-1, :mems])
+        const int klo = (MEM && qi == Q) ? pmq : 0;           // ... and does not see the memory columns (attention_mask[-1, :mems])
         const float* qp = Qb + (pg * QM + qi) * ld + ph * DH;
         float2 q2[DH / 2];
 #pragma unroll
@@ -690,7 +691,7 @@ bool emformer_fused_supported(const EmfFusedArgs& a) {
          (a.wp != nullptr || a.K == a.D) && emformer_fused_smem(a) <= 160 * 1024;
 }
 
-template <int KQD, int DH>
+template <int KQD, int DH, bool MEM>
 static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
   const int G = ef_streams_per_block(a.R + a.U + (a.M > 0 ? 2 : 0), a.H);
   // the attribute is per device (the code object is loaded once per device): remember which devices have it
@@ -699,13 +700,13 @@ static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)emformer_fused_kernel<KQD, DH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)emformer_fused_kernel<KQD, DH, MEM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
   EmfFusedArgs b = a;
   const int chunks = a.F / EF_HCHUNK;
   if (b.cs < 1 || b.cs > EMF_MAX_CLUSTER || (b.cs & (b.cs - 1)) || chunks % b.cs || !b.xch || !b.xflag || !b.xepoch) b.cs = 1;
-  hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH>), dim3(((a.n + G - 1) / G) * b.cs), dim3(256), emformer_fused_smem(a), st, b);
+  hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH, MEM>), dim3(((a.n + G - 1) / G) * b.cs), dim3(256), emformer_fused_smem(a), st, b);
 }
 
 int emformer_fused_streams_per_block(const EmfFusedArgs& a) { return ef_streams_per_block(a.R + a.U + (a.M > 0 ? 2 : 0), a.H); }
@@ -713,8 +714,8 @@ int emformer_fused_streams_per_block(const EmfFusedArgs& a) { return ef_streams_
 // instantiated shapes: (input_dim, head_dim) = (80, 10) is modules/Emformer/emformer.py's only configuration
 void launch_emformer_fused(const EmfFusedArgs& a, hipStream_t st) {
   if (a.n <= 0) return;
-  if (a.D == 80 && a.D / a.H == 10) launch_ef<5, 10>(a, st);
-  else if (a.D == 64 && a.D / a.H == 8) launch_ef<4, 8>(a, st);
+  if (a.D == 80 && a.D / a.H == 10) a.M > 0 ? launch_ef<5, 10, true>(a, st) : launch_ef<5, 10, false>(a, st);
+  else if (a.D == 64 && a.D / a.H == 8) a.M > 0 ? launch_ef<4, 8, true>(a, st) : launch_ef<4, 8, false>(a, st);
 }
 
 }  // namespace cnk
