@@ -44,6 +44,11 @@ const PackedConv& conan_ctx::conv(const std::string& name) const {
   return it->second;
 }
 
+float* conan_ctx::vec_or_null(const std::string& name) const {
+  auto it = vecs.find(name);
+  return it == vecs.end() ? nullptr : it->second;
+}
+
 float* conan_ctx::vec(const std::string& name) const {
   auto it = vecs.find(name);
   if (it == vecs.end()) throw Error(CONAN_ERR_STATE, "device vector missing: " + name);
@@ -171,6 +176,31 @@ void conan_ctx::pack_fragments(const std::string& name, const std::string& prefi
           }
   vecs[name + ".w"] = upload(out);
   vecs[name + ".b"] = upload(b);
+  // The same weights as three bf16 limbs each, w = h + m + l (round-to-nearest-even; the subtractions are exact), for the
+  // bf16-MFMA form of the pass (resblock_limb.hip): [ct][k + 1 taps][C/32 K blocks][3 limbs][64 lanes][8 elements], lane =
+  // (output channel ct*16 + (lane & 15), input channels kb*32 + 8*(lane >> 4) + e).  Stored behind a float pointer (bits only).
+  if (C % 32 == 0 && cnk::resblock_limb_supported(C, k, 0)) {
+    auto rne = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+    auto val = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    const int KB = C / 32;
+    std::vector<uint16_t> lim((size_t)NCT * (k + 1) * KB * 3 * 512 + 4096, 0);      // + a block of slack: the ring prefetches past the last tap
+    for (int ct = 0; ct < NCT; ++ct)
+      for (int j = 0; j < k; ++j)
+        for (int q = 0; q < KB; ++q)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const int ci = q * 32 + 8 * (lane >> 4) + e, co = ct * 16 + (lane & 15);
+              const float w = W[((size_t)co * C + ci) * k + j];
+              const uint16_t h = rne(w); const float r1 = w - val(h);
+              const uint16_t m = rne(r1); const float r2 = r1 - val(m);
+              const uint16_t l = rne(r2);
+              const size_t base = ((((size_t)ct * (k + 1) + j) * KB + q) * 3) * 512 + lane * 8 + e;
+              lim[base] = h; lim[base + 512] = m; lim[base + 1024] = l;
+            }
+    std::vector<float> bits(lim.size() / 2);
+    memcpy(bits.data(), lim.data(), bits.size() * 4);
+    vecs[name + ".wl"] = upload(bits);
+  }
 }
 
 void conan_ctx::upload_vec(const std::string& name, const std::string& key) { vecs[name] = upload(get(key).data); }

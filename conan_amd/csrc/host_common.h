@@ -92,6 +92,7 @@ struct conan_ctx {
   bool has(const std::string& key) const { return raw.count(key) != 0; }
   const ch::PackedConv& conv(const std::string& name) const;
   float* vec(const std::string& name) const;
+  float* vec_or_null(const std::string& name) const;
   void pack_conv(const std::string& name, const std::vector<float>& W, const float* bias, int Cout, int Cin, int k,
                  int shuffle_r = 1);
   void add_rowconv_weights(const std::string& name, const std::vector<float>& W);   // second, fragment-major copy

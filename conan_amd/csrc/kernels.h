@@ -98,6 +98,8 @@ void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num
 struct RBProb {
   const float* w1; const float* w2;   // fragment-major: [C/16 column tiles][k + 1 taps (last zero)][C/16 K groups][64 lanes][4]
   const float* b1; const float* b2;   // [C]
+  const unsigned short* w1l; const unsigned short* w2l;   // the same weights as bf16 limbs (resblock_limb.hip):
+                                      // [C/16 column tiles][k + 1 taps (last zero)][C/32 K blocks][3 limbs][64 lanes][8]; null: not packed
   TRef x;                             // raw input (c1 operand after LeakyReLU, residual operand as it is)
   TRef y;                             // raw output
   int k, dil;
@@ -126,6 +128,14 @@ int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu);   
 bool launch_resblock_fused(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
 bool resblock_fused_can_merge(int C, int rows);   // a merged-branch build exists for this geometry
 const char* resblock_fused_name(int C, int rows, bool merge = false);
+const int* resblock_tiles(const RBArgs& a, int ro, int* total_out);      // the cached device tile list of a launch shape (resblock_fused.hip)
+// The same tile pass with every fp32 product as six bf16 limb products on the bf16 MFMA (resblock_limb.hip): same arguments
+// (RBProb::w1l / w2l), half as tall tiles.
+bool resblock_limb_supported(int C, int kmax, int span_max);
+int resblock_limb_rows(int C, int span_max);
+bool launch_resblock_limb(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
+bool resblock_limb_can_merge(int C, int rows);
+const char* resblock_limb_name(int C, int rows, bool merge = false);
 
 
 // One ResBlock1 unit per branch for the wide first stage (C = 256, <= 32 rows per stream and step), a PAIR of workgroups per

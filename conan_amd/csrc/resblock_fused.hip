@@ -535,7 +535,7 @@ int resblock_fused_rows(int C, int T, int n, int ksum, int kmax, int num_cu) {
 // Tile list of a launch shape: {branch, slot index, first row, 0} per tile, most expensive branch first (the blocks draw
 // from it in order: longest-processing-time-first list scheduling); cached per shape in device memory (a handful of
 // shapes per model and device, never freed).
-static const int* rb_tiles(const RBArgs& a, int ro, int* total_out) {
+const int* resblock_tiles(const RBArgs& a, int ro, int* total_out) {
   struct Key { int v[10]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
   static std::map<Key, std::pair<const int*, int>> cache;
   static std::mutex mu;
@@ -573,7 +573,7 @@ static bool launch_rb(const RBArgs& ain, int num_cu, hipStream_t st) {
   if (total <= 0) return true;
   if (!a.sched) return false;
   const int grid = std::min(a.merge ? total / a.nprob : total, num_cu);
-  a.tiles = rb_tiles(a, ro, &a.ntiles);
+  a.tiles = resblock_tiles(a, ro, &a.ntiles);
   if (!a.tiles) return false;
   hipLaunchKernelGGL((resblock_fused_kernel<C, NR2, MERGE>), dim3(grid), dim3(512), 0, st, a);
   return true;

@@ -1,0 +1,527 @@
+// resblock_limb: resblock_fused's tile pass (one ResBlock1 unit: xt = c1(lrelu(x)), y = c2(lrelu(xt)) + x, hifigan_causal.py:230-238)
+// with every fp32 product computed as SIX bf16 limb products on the bf16 MFMA instead of one product on the f32 MFMA.
+//
+// Why: the exact-f32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate and bounds the vocoder's ResBlock stages
+// (0.7 of its peak is what resblock_fused reaches).  An fp32 value is the exact sum of three bf16 limbs,
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)      (8 + 8 + 8 significant bits and two sign bits),
+// and a product of two bf16 values is exact in fp32, so
+//     x * w  =  hh + (hm + mh) + (hl + mm + lh)  +  O(2^-25 |x w|)
+// six products accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (smallest terms first) reproduce the fp32 product to the
+// rounding of the accumulation itself: tools/experiments/bf16x3_gemm.hip measures the error against a float64 sum of the same
+// fp32 inputs at 0.85 of the f32 MFMA's own (5.6e-7 against 6.7e-7 relative rms at K = 1408) and 1.8-2.0x its rate.  16 / 6 =
+// 2.7x the f32 matrix rate is the ceiling; operands are 6 instead of 4 bytes per element (LDS images and weight streams).
+//
+// What changes against resblock_fused (same roles, barriers, work queue, merge build - see that file's header):
+//   * LDS holds three bf16 PLANES (h, m, l) of the window and of xt, rows padded to C + 16 elements (conflict-free
+//     ds_read_b128: a lane's A operand for one 16x16x32 MFMA is 8 consecutive channels of its row, 16 bytes per limb);
+//     the helper waves split the window while staging it (LeakyReLU first), the matrix waves split xt in c1's epilogue;
+//   * weights are packed per limb at finalize (ctx.hip pack_fragments): [column tile][k + 1 taps][C/32 K blocks][3 limbs][64 lanes]
+//     x 16 bytes, streamed from L2 into registers as before, a ring of RING K blocks ahead;
+//   * c2's accumulators go to the helpers through an f32 image that overlays the xt planes (dead behind B4);
+//   * tiles are half as tall (6 bytes per element in LDS, and the block still has to share the CU with a decoder
+//     megakernel workgroup: tests/test_kernel_resources.py).
+#include <algorithm>
+#include <cstring>
+
+#include "kernels.h"
+
+#ifndef RL_STAMPS
+#define RL_STAMPS 0     // developer builds (tools/rb_bench -DRL_STAMPS=1): cycle stamps of the matrix waves per block
+#endif
+
+namespace cnk {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef const f32x4 __attribute__((address_space(1)))* gcf4;
+typedef f32x4 __attribute__((address_space(1)))* gf4;
+typedef const float __attribute__((address_space(1)))* gcf1;
+typedef const int __attribute__((address_space(1)))* gci;
+
+__device__ __forceinline__ f32x4 rl_gload(const void* p) { return *(gcf4)(p); }
+__device__ __forceinline__ float4 rl_gload4(const float* p) { const f32x4 v = *(gcf4)(p); return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ float rl_gload1(const float* p) { return *(gcf1)(p); }
+__device__ __forceinline__ void rl_gstore4(float* p, const float4 v) { *(gf4)(p) = (f32x4){v.x, v.y, v.z, v.w}; }
+
+// x = h + m + l (round-to-nearest-even at every step; the two subtractions are exact)
+__device__ __forceinline__ void rl_split(const float x, u16& h, u16& m, u16& l) {
+  const __bf16 hb = (__bf16)x;
+  const float r1 = x - (float)hb;
+  const __bf16 mb = (__bf16)r1;
+  const float r2 = r1 - (float)mb;
+  const __bf16 lb = (__bf16)r2;
+  h = __builtin_bit_cast(u16, hb); m = __builtin_bit_cast(u16, mb); l = __builtin_bit_cast(u16, lb);
+}
+
+template <int C_, int NR2_, int SPAN_>
+struct RLGeom {
+  static constexpr int C = C_, NR2 = NR2_;
+  static constexpr int NR1 = NR2 + 1;                 // c1 row tiles: 16*NR1 >= 16*NR2 + (k-1) for k <= 17
+  static constexpr int RO = 16 * NR2;                 // output rows per tile
+  static constexpr int XT_ROWS = 16 * NR1;
+  static constexpr int MAXSPAN = SPAN_;               // (k-1)*dil of c1
+  static constexpr int WR_MAX = XT_ROWS + MAXSPAN;    // window rows
+  // bf16 elements per LDS row: C + 16, i.e. a row stride of 2 (mod 4) 16-byte slots.  ds_read_b128 is serviced in the lane
+  // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS): with lane = (row & 15, 16-byte chunk
+  // lane >> 4) a group mixes rows 0-3 / 12-15 at chunk c with rows 4-11 at chunk c + 1, and only these strides keep its 16
+  // lanes on 16 distinct slots (C + 8 measured 2-way conflicts on most groups: the K loop ran LDS-bound at 0.65 of the MFMA rate)
+  static constexpr int LDB = C + 16;
+  static constexpr int PLW = WR_MAX * LDB;            // elements per window plane
+  static constexpr int PLX = XT_ROWS * LDB;           // elements per xt plane
+  static constexpr int LDA = C + 4;                   // floats per row of c2's accumulator image (overlays the xt planes)
+  static constexpr int LDS_U16 = 3 * (PLW + PLX);
+  static constexpr int NCT = C / 16;
+  static constexpr int RSPLIT = NCT >= 4 ? 1 : 4 / NCT;   // C = 32: two waves share a column strip and split the rows
+  static constexpr int NCW = NCT >= 4 ? NCT / 4 : 1;
+  static constexpr int NRW1 = (NR1 + RSPLIT - 1) / RSPLIT;
+  static constexpr int NRW2 = (NR2 + RSPLIT - 1) / RSPLIT;
+  static constexpr int KB = C / 32;                   // 32-deep K blocks per tap
+  static constexpr int RING = KB >= 2 ? 2 : 1;        // weight K blocks in flight
+  static constexpr int C4 = C / 4;
+  static constexpr int BLK = 3 * 512;                 // u16 per (K block, column tile): 3 limbs x 1 KiB
+  static_assert(C % 32 == 0 && KB % RING == 0, "channel count");
+  static_assert(RO * LDA * 4 <= 3 * PLX * 2, "accumulator image inside the xt planes");
+  static_assert(LDS_U16 * 2 + 16 <= 160 * 1024, "LDS budget");
+};
+
+template <int NCW, int RING>
+__device__ __forceinline__ void rl_prefetch_w(f32x4 (&bw)[RING][NCW][3], const u16* __restrict__ wl, const long long ct_stride) {
+#pragma unroll
+  for (int q = 0; q < RING; ++q) {
+#pragma unroll
+    for (int c = 0; c < NCW; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bw[q][c][p] = rl_gload(wl + c * ct_stride + q * 1536 + p * 512);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// One GEMM phase of a matrix wave: acc[r][c] += sum over (tap j, K block q) of A(rows of tile r shifted by j*tap_stride) x
+// W(j, q, column tile c), each as six limb products.  The MFMA is issued TRANSPOSED (weights as its first operand, rows as
+// its second - the register images are the same either way): acc[r][c][e] is output channel 16*c + 4*(lane>>4) + e of time
+// row 16*r + (lane&15), four consecutive channels of one row per lane, so the epilogues store 8 / 16 bytes per LDS write.  `src` is plane 0 of the LDS operand image (planes `plane` elements
+// apart, row stride LDB), `wl` the wave's first weight block (+ lane*8), column tiles ct_stride elements apart; bw holds the
+// first RING blocks on entry and those of (wl_next, ct_stride_next) on exit.
+template <int NRW, int NCW, int LDB, int KB, int RING>
+__device__ __forceinline__ void rl_gemm(const u16* __restrict__ src, const int plane, const int row0, const int tap_stride, const int k,
+                                        const u16* __restrict__ wl, const long long ct_stride, const u16* __restrict__ wl_next,
+                                        const long long ct_stride_next, f32x4 (&acc)[NRW][NCW], f32x4 (&bw)[RING][NCW][3], const int lane) {
+  const u16* abase = src + (row0 + (lane & 15)) * LDB + 8 * (lane >> 4);
+  f32x4 af[NRW][3];
+#pragma unroll
+  for (int r = 0; r < NRW; ++r)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[r][p] = *reinterpret_cast<const f32x4*>(abase + p * plane + r * 16 * LDB);
+  const int tstep = tap_stride * LDB;
+  for (int j = 0; j < k; ++j) {
+    const u16* arow = abase + j * tstep;
+    const bool last = j + 1 == k;
+    const u16* wnext = last ? wl_next : wl + (long long)(j + 1) * KB * 1536;
+    const long long cnext = last ? ct_stride_next : ct_stride;
+#pragma unroll
+    for (int q = 0; q < KB; ++q) {
+      const u16* anext = (q + 1 < KB) ? arow + (q + 1) * 32 : arow + tstep;
+      // limb products, smallest first: l*h, m*m, h*l, m*h, h*m, h*h.  ONE fragment set: a row tile's l limb of the next block is
+      // read right behind its last use (product 0), its m limb behind product 3, its h limb behind product 5 - needed again
+      // at products 0, 1 and 2 of the next block, so every read has at least two product rounds to land.
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+#pragma unroll
+          for (int c = 0; c < NCW; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[q % RING][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]),
+                                                                acc[r][c], 0, 0, 0);
+          if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + r * 16 * LDB);
+          if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + r * 16 * LDB);
+          if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + r * 16 * LDB);
+        }
+      if (q + RING < KB) {
+#pragma unroll
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bw[q % RING][c][p] = rl_gload(wl + ((long long)j * KB + q + RING) * 1536 + c * ct_stride + p * 512);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bw[q % RING][c][p] = rl_gload(wnext + (q + RING - KB) * 1536 + c * cnext + p * 512);
+      }
+      // pin that order
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        if (s == 0 || s == 3 || s == 5) {
+#pragma unroll
+          for (int r = 0; r < NRW; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NCW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NRW * NCW, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCW, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+}  // namespace
+
+#define RL_SEL(br_, f) ((br_) == 0 ? a.p[0].f : ((br_) == 1 ? a.p[1].f : a.p[2].f))
+
+template <int C, int NR2, int SPAN, bool MERGE>
+__global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
+  using G = RLGeom<C, NR2, SPAN>;
+  constexpr int LDB = G::LDB;
+  __shared__ __attribute__((aligned(16))) u16 lds[G::LDS_U16 + 8];      // + meta: {zero rows, next tile, its branch, draw generation}
+  u16* const win = lds;                                // [3][WR_MAX][LDB] limbs of leaky_relu(x)
+  u16* const xt = lds + 3 * G::PLW;                    // [3][XT_ROWS][LDB] limbs of leaky_relu(c1 + b1)
+  float* const accimg = reinterpret_cast<float*>(xt);  // [RO][LDA] c2's accumulators (behind B4)
+  int* const meta = reinterpret_cast<int*>(lds + G::LDS_U16);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto tile_word = [&](int idx, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(a.tiles + (long long)idx * 4 + w)); };
+  const int ntiles = a.ntiles;
+  const float slope = a.slope;
+  const int T = a.T;
+  constexpr bool merge = MERGE;
+  const int np = a.nprob;
+  const int first_tile = merge ? (int)blockIdx.x * np : (int)blockIdx.x;
+
+  if (wave >= 4) {
+    // ============================================================ helper waves: window loader + output writer
+    const int ht = tid - 256;
+    __builtin_amdgcn_s_setprio(3);
+    auto hbar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto slot_of = [&](int i) __attribute__((always_inline)) { return a.slots ? __builtin_amdgcn_readfirstlane(*(gci)(a.slots + i)) : i; };
+    auto pos_of = [&](int slot) __attribute__((always_inline)) { return a.pos ? __builtin_amdgcn_readfirstlane(*(gci)(a.pos + slot)) : 0; };
+    auto load_window = [&](const int p, const int i, const int t0, const int slot, const int pos) __attribute__((always_inline)) {
+      const int k = RL_SEL(p, k), d = RL_SEL(p, dil);
+      const int wr = G::XT_ROWS + (k - 1) * d;
+      const int tw0 = t0 - (k - 1) - (k - 1) * d;
+      const int xmode = a.p[0].x.mode, xrate = a.p[0].x.rate;
+      const float* xb = RL_SEL(p, x.base) + (long long)(xmode == 0 ? slot : i) * RL_SEL(p, x.slot_stride);
+      const unsigned rbase = (xmode == 0 ? (unsigned)pos * (unsigned)xrate : 0u) + (unsigned)(RL_SEL(p, x.off) + tw0);
+      const unsigned rmask = xmode == 0 ? (unsigned)RL_SEL(p, x.lmask) : 0xffffffffu;
+      constexpr int NIT = (G::WR_MAX * G::C4 + 255) / 256;
+      float4 v[NIT];
+      const int total = wr * G::C4;
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const int idx = ht + 256 * u;
+        const int w = idx / G::C4, c4 = idx - w * G::C4;
+        const unsigned row = (rbase + (unsigned)w) & rmask;
+        v[u] = idx < total ? rl_gload4(xb + (long long)row * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const int idx = ht + 256 * u;
+        const int w = idx / G::C4, c4 = idx - w * G::C4;
+        float q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        u16 h[4], m[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float s = q[e] > 0.f ? q[e] : q[e] * slope;
+          rl_split(s, h[e], m[e], l[e]);
+        }
+        if (idx < total) {
+          u16* dst = win + w * LDB + c4 * 4;
+          *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
+          *reinterpret_cast<uint2*>(dst + G::PLW) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
+          *reinterpret_cast<uint2*>(dst + 2 * G::PLW) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
+        }
+      }
+      const long long abs0 = (xmode == 0 ? (long long)pos * xrate : 0ll) + t0 - (k - 1);
+      if (ht == 0) meta[0] = abs0 >= 0 ? 0 : (abs0 < -(long long)G::XT_ROWS ? G::XT_ROWS : (int)-abs0);
+    };
+    constexpr int NOUT = (G::RO * G::C4) / 256;
+    static_assert((G::RO * G::C4) % 256 == 0 && 256 % G::C4 == 0, "output tile / helper threads");
+    constexpr int NOB = (NOUT + 1) / 2;
+    const int oc4 = ht % G::C4;
+    float4 oacc[NOUT], osum[MERGE ? NOUT : 1];
+    const float* oxb = nullptr; const float* ob2p = nullptr;
+    float* oyb = nullptr;
+    unsigned oyr0 = 0, oym = 0, oxr0 = 0, oxm = 0;
+    int ot0 = 0, op = 0, oyC = C;
+#pragma unroll
+    for (int u = 0; u < (MERGE ? NOUT : 1); ++u) osum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto out_fetch = [&](const int p, const int i, const int t0, const int slot, const int pos) __attribute__((always_inline)) {
+      const int xmode = a.p[0].x.mode, xrate = a.p[0].x.rate, ymode = a.p[0].y.mode, yrate = a.p[0].y.rate;
+      oxb = RL_SEL(p, x.base) + (long long)(xmode == 0 ? slot : i) * RL_SEL(p, x.slot_stride);
+      oxr0 = (xmode == 0 ? (unsigned)pos * (unsigned)xrate : 0u) + (unsigned)(RL_SEL(p, x.off) + t0);
+      oxm = xmode == 0 ? (unsigned)RL_SEL(p, x.lmask) : 0xffffffffu;
+      if (!merge) {
+        oyb = RL_SEL(p, y.base) + (long long)(ymode == 0 ? slot : i) * RL_SEL(p, y.slot_stride);
+        oyr0 = (ymode == 0 ? (unsigned)pos * (unsigned)yrate : 0u) + (unsigned)(RL_SEL(p, y.off) + t0);
+        oym = ymode == 0 ? (unsigned)RL_SEL(p, y.lmask) : 0xffffffffu;
+      } else {
+        const int mmode = a.ymean.mode;
+        oyb = a.ymean.base + (long long)(mmode == 0 ? slot : i) * a.ymean.slot_stride;
+        oyr0 = (mmode == 0 ? (unsigned)pos * (unsigned)a.ymean.rate : 0u) + (unsigned)(a.ymean.off + t0);
+        oym = mmode == 0 ? (unsigned)a.ymean.lmask : 0xffffffffu;
+        oyC = a.ymean.C;
+      }
+      ot0 = t0; op = p;
+      ob2p = RL_SEL(p, b2) + oc4 * 4;
+#pragma unroll
+      for (int u = 0; u < NOUT; ++u) oacc[u] = *reinterpret_cast<const float4*>(accimg + ((ht + 256 * u) / G::C4) * G::LDA + oc4 * 4);
+    };
+    auto out_store = [&]() __attribute__((always_inline)) {
+      const float4 ob2 = rl_gload4(ob2p);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 ores[NOB];
+#pragma unroll
+        for (int q = 0; q < NOB; ++q) {
+          const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
+          ores[q] = (u < NOUT && ot0 + r < T) ? rl_gload4(oxb + (long long)((oxr0 + (unsigned)r) & oxm) * C + oc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < NOB; ++q) {
+          const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
+          if (u < NOUT && ot0 + r < T) {
+            const float4 v = make_float4((oacc[u].x + ob2.x) + ores[q].x, (oacc[u].y + ob2.y) + ores[q].y, (oacc[u].z + ob2.z) + ores[q].z, (oacc[u].w + ob2.w) + ores[q].w);
+            if constexpr (!MERGE) rl_gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4, v);
+            else {
+              float4 sm = osum[MERGE ? u : 0];
+              if (op == 0) sm = v; else { sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w; }
+              osum[MERGE ? u : 0] = sm;
+              if (op == np - 1) {
+                const float dn = (float)np;
+                if (np > 1) { sm.x /= dn; sm.y /= dn; sm.z /= dn; sm.w /= dn; }
+                sm.x = sm.x > 0.f ? sm.x : sm.x * slope; sm.y = sm.y > 0.f ? sm.y : sm.y * slope;
+                sm.z = sm.z > 0.f ? sm.z : sm.z * slope; sm.w = sm.w > 0.f ? sm.w : sm.w * slope;
+                rl_gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * oyC + oc4 * 4, sm);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    int p = tile_word(first_tile, 0), i = tile_word(first_tile, 1), t0 = tile_word(first_tile, 2);
+    int slot = slot_of(i), pos = pos_of(slot);
+    int cur = first_tile;
+    if (ht == 0) meta[3] = 0;
+    load_window(p, i, t0, slot, pos);
+    hbar();                                              // B0: first window staged
+    bool pending = false;
+    int gen = 1;
+    for (;;) {
+      hbar();                                            // B3: the previous tile's accumulators are in registers (out_fetch)
+      hbar();                                            // B1: xt complete, window free
+      int nv = 0;
+      if (wave == 4 && lane == 0) {
+        if (merge && p != np - 1) nv = cur + 1;
+        else {
+          nv = (int)gridDim.x + __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (merge) nv *= np;
+        }
+      }
+      if (pending) out_store();
+      int nidx, pn;
+      if (wave == 4) {
+        int pv = -1;
+        if (lane == 0) pv = nv < ntiles ? *(gci)(a.tiles + (long long)nv * 4) : -1;
+        nidx = __builtin_amdgcn_readfirstlane(nv); pn = __builtin_amdgcn_readfirstlane(pv);
+        if (lane == 0) {
+          meta[1] = nidx; meta[2] = pn;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __hip_atomic_store(&meta[3], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        while (__hip_atomic_load(&meta[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen) __builtin_amdgcn_s_sleep(8);
+        nidx = __builtin_amdgcn_readfirstlane(meta[1]); pn = __builtin_amdgcn_readfirstlane(meta[2]);
+      }
+      ++gen;
+      int in = 0, t0n = 0, slotn = 0, posn = 0;
+      if (pn >= 0) { in = tile_word(nidx, 1); t0n = tile_word(nidx, 2); slotn = slot_of(in); posn = pos_of(slotn); }
+      if (pn >= 0) load_window(pn, in, t0n, slotn, posn);
+      hbar();                                            // B4
+      hbar();                                            // B2: c2 accumulators in LDS, next window staged
+      out_fetch(p, i, t0, slot, pos);
+      pending = true;
+      if (pn < 0) break;
+      p = pn; i = in; t0 = t0n; slot = slotn; pos = posn; cur = nidx;
+    }
+    if (pending) out_store();
+    if (ht == 0) {
+      const int d = __hip_atomic_fetch_add(a.sched + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d == (int)gridDim.x - 1) {
+        __hip_atomic_store(a.sched, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.sched + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+
+  // ============================================================== matrix waves
+  auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int wc = wave % (4 / G::RSPLIT);
+  const int wr = wave / (4 / G::RSPLIT);
+  const int ct0 = wc * G::NCW;
+  const int lr = lane & 15, lg = lane >> 4;
+#if RL_STAMPS
+  unsigned long long st_gemm = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_bar = 0, st_b3 = 0, st_b1 = 0, st_b4 = 0, st_b2 = 0;
+#define RL_T() __builtin_amdgcn_s_memtime()
+#define RL_BAR(acc_) do { const unsigned long long q0_ = RL_T(); bar(); const unsigned long long q1_ = RL_T(); acc_ += q1_ - q0_; st_bar += q1_ - q0_; } while (0)
+#define RL_GEMM(...) do { const unsigned long long s0_ = RL_T(); __VA_ARGS__; asm volatile("s_nop 0" ::"v"(acc[0][0][0])); st_gemm += RL_T() - s0_; } while (0)
+#else
+#define RL_BAR(acc_) bar()
+#define RL_GEMM(...) __VA_ARGS__
+#endif
+  f32x4 bw[G::RING][G::NCW][3];
+  int p = tile_word(first_tile, 0);
+  {
+    const long long cs = (long long)(RL_SEL(p, k) + 1) * G::KB * G::BLK;
+    rl_prefetch_w<G::NCW, G::RING>(bw, RL_SEL(p, w1l) + (long long)ct0 * cs + lane * 8, cs);
+  }
+  bar();                                                 // B0
+  while (p >= 0) {
+    const int k = RL_SEL(p, k), d = RL_SEL(p, dil);
+    const u16* const w1 = RL_SEL(p, w1l);
+    const u16* const w2 = RL_SEL(p, w2l);
+    const float* const b1 = RL_SEL(p, b1);
+    const long long ct_stride = (long long)(k + 1) * G::KB * G::BLK;
+    const int zrows = __builtin_amdgcn_readfirstlane(meta[0]);
+    f32x4 b1v[G::NCW];
+#pragma unroll
+    for (int c = 0; c < G::NCW; ++c) b1v[c] = rl_gload(b1 + (ct0 + c) * 16 + 4 * lg);
+    int pn;
+    // ---------------- c1 over the halo-extended rows
+    {
+      f32x4 acc[G::NRW1][G::NCW];
+#pragma unroll
+      for (int r = 0; r < G::NRW1; ++r)
+#pragma unroll
+        for (int c = 0; c < G::NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int rt0 = wr * G::NRW1;
+      RL_GEMM(rl_gemm<G::NRW1, G::NCW, LDB, G::KB, G::RING>(win, G::PLW, rt0 * 16, d, k, w1 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
+                                                           w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride, acc, bw, lane));
+      RL_BAR(st_b3);                                     // B3
+#pragma unroll
+      for (int c = 0; c < G::NCW; ++c) {
+        const int col = (ct0 + c) * 16 + 4 * lg;
+#pragma unroll
+        for (int r = 0; r < G::NRW1; ++r) {
+          if (rt0 + r < G::NR1) {
+            const int m = (rt0 + r) * 16 + lr;
+            u16 h[4], mm[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[r][c][e] + b1v[c][e];
+              v = v > 0.f ? v : v * slope;
+              v = m < zrows ? 0.f : v;
+              rl_split(v, h[e], mm[e], l[e]);
+            }
+            u16* dst = xt + m * LDB + col;
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
+            *reinterpret_cast<uint2*>(dst + G::PLX) = make_uint2((unsigned)mm[0] | (unsigned)mm[1] << 16, (unsigned)mm[2] | (unsigned)mm[3] << 16);
+            *reinterpret_cast<uint2*>(dst + 2 * G::PLX) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
+          }
+        }
+      }
+    }
+    RL_BAR(st_b1);                                       // B1: xt complete, window free
+    // ---------------- c2
+    {
+      f32x4 acc[G::NRW2][G::NCW];
+#pragma unroll
+      for (int r = 0; r < G::NRW2; ++r)
+#pragma unroll
+        for (int c = 0; c < G::NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int rt0 = wr * G::NRW2;
+      RL_GEMM(rl_gemm<G::NRW2, G::NCW, LDB, G::KB, G::RING>(xt, G::PLX, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
+                                                           w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride, acc, bw, lane));
+      RL_BAR(st_b4);                                     // B4: every matrix wave is done reading xt
+      pn = __builtin_amdgcn_readfirstlane(meta[2]);
+      if (pn >= 0) {
+        const long long csn = (long long)(RL_SEL(pn, k) + 1) * G::KB * G::BLK;
+        rl_prefetch_w<G::NCW, G::RING>(bw, RL_SEL(pn, w1l) + (long long)ct0 * csn + lane * 8, csn);
+      }
+#pragma unroll
+      for (int c = 0; c < G::NCW; ++c) {
+        const int col = (ct0 + c) * 16 + 4 * lg;
+#pragma unroll
+        for (int r = 0; r < G::NRW2; ++r) {
+          if (rt0 + r < NR2) *reinterpret_cast<f32x4*>(accimg + ((rt0 + r) * 16 + lr) * G::LDA + col) = acc[r][c];
+        }
+      }
+    }
+    RL_BAR(st_b2);                                       // B2
+    p = pn;
+  }
+#if RL_STAMPS
+  if (a.dbg && tid == 0) {
+    unsigned long long* o = a.dbg + blockIdx.x * 4;
+    if (blockIdx.x == 0) { unsigned long long* q = a.dbg + 256 * 4; q[0] = st_b3; q[1] = st_b1; q[2] = st_b4; q[3] = st_b2; }
+    o[0] = st_gemm; o[1] = __builtin_amdgcn_s_memtime() - st_t0; o[2] = __builtin_amdgcn_s_memrealtime() - st_r0; o[3] = st_bar;
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+namespace {
+struct RLCand { int C, NR2, span; };
+// tile heights that leave a decoder megakernel workgroup its 34 KB of LDS beside the block (6 bytes per element here)
+const RLCand kLimbCands[] = {{32, 10, 50}, {64, 5, 50}};
+}
+
+bool resblock_limb_supported(int C, int kmax, int span_max) {
+  for (const RLCand& c : kLimbCands)
+    if (c.C == C && span_max <= c.span) return kmax <= 16;
+  return false;
+}
+
+int resblock_limb_rows(int C, int span_max) {
+  int best = 0;
+  for (const RLCand& c : kLimbCands)
+    if (c.C == C && span_max <= c.span) best = std::max(best, 16 * c.NR2);
+  return best;
+}
+
+template <int C, int NR2, int SPAN, bool MERGE = false>
+static bool launch_rl(const RBArgs& ain, int num_cu, hipStream_t st) {
+  RBArgs a = ain;
+  const int ro = 16 * NR2;
+  a.tiles_per_slot = (a.T + ro - 1) / ro;
+  const int total = a.nprob * a.n * a.tiles_per_slot;
+  if (total <= 0) return true;
+  if (!a.sched) return false;
+  for (int p = 0; p < a.nprob; ++p) if (!a.p[p].w1l || !a.p[p].w2l) return false;
+  const int grid = std::min(a.merge ? total / a.nprob : total, num_cu);
+  a.tiles = resblock_tiles(a, ro, &a.ntiles);
+  if (!a.tiles) return false;
+  hipLaunchKernelGGL((resblock_limb_kernel<C, NR2, SPAN, MERGE>), dim3(grid), dim3(512), 0, st, a);
+  return true;
+}
+
+bool launch_resblock_limb(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st) {
+  const int nr2 = rows / 16;
+  if (a.merge) {
+    if (C == 32 && nr2 == 10) return launch_rl<32, 10, 50, true>(a, num_cu, st);
+    if (C == 64 && nr2 == 5) return launch_rl<64, 5, 50, true>(a, num_cu, st);
+    return false;
+  }
+  if (C == 32 && nr2 == 10) return launch_rl<32, 10, 50>(a, num_cu, st);
+  if (C == 64 && nr2 == 5) return launch_rl<64, 5, 50>(a, num_cu, st);
+  return false;
+}
+
+bool resblock_limb_can_merge(int C, int rows) { return (C == 32 && rows == 160) || (C == 64 && rows == 80); }
+
+const char* resblock_limb_name(int C, int rows, bool merge) {
+  static thread_local char buf[72];
+  const int span = 50;
+  snprintf(buf, sizeof(buf), "cnk::resblock_limb_kernel<%d, %d, %d, %s>", C, rows / 16, span, merge ? "true" : "false");
+  return buf;
+}
+
+}  // namespace cnk

@@ -172,15 +172,20 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   // blocks of this launch hold their CU for its whole duration, so without a few free CUs every one of the ~60
   // dependent front-end launches of the next chunk waits for a vocoder kernel boundary
   const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
-  const int rows = cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
+  // bf16-limb form (resblock_limb.hip) where the weights were packed for it and every branch's span fits its window
+  int span = 0;
+  bool limb = rb_limb;
+  for (int p = 0; p < a.nprob; ++p) { span = std::max(span, (a.p[p].k - 1) * a.p[p].dil); limb = limb && a.p[p].w1l && a.p[p].w2l; }
+  limb = limb && cnk::resblock_limb_supported(C, kmax, span);
+  const int rows = limb ? cnk::resblock_limb_rows(C, span) : cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
   // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
   // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.
   // With fewer groups than CUs (C = 128 at 64 streams: 128) the branches stay separate tiles.
   const long long groups = (long long)a.n * ((a.T + rows - 1) / rows);
-  a.merge = (ymean && rb_merge && a.nprob > 1 && groups >= cus && cnk::resblock_fused_can_merge(C, rows)) ? 1 : 0;
+  a.merge = (ymean && rb_merge && a.nprob > 1 && groups >= cus && (limb ? cnk::resblock_limb_can_merge(C, rows) : cnk::resblock_fused_can_merge(C, rows))) ? 1 : 0;
   if (a.merge) a.ymean = *ymean;
-  profiled(cnk::resblock_fused_name(C, rows, a.merge != 0), fl, st, [&] {
-    if (!cnk::launch_resblock_fused(a, C, rows, cus, st)) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
+  profiled(limb ? cnk::resblock_limb_name(C, rows, a.merge != 0) : cnk::resblock_fused_name(C, rows, a.merge != 0), fl, st, [&] {
+    if (!(limb ? cnk::launch_resblock_limb(a, C, rows, cus, st) : cnk::launch_resblock_fused(a, C, rows, cus, st))) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
   });
   return a.merge != 0;
 }
@@ -434,6 +439,8 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         cnk::RBProb& pr = ra.p[b];
         pr.w1 = ctx->vec(base + ".c1." + std::to_string(d) + ".w"); pr.b1 = ctx->vec(base + ".c1." + std::to_string(d) + ".b");
         pr.w2 = ctx->vec(base + ".c2." + std::to_string(d) + ".w"); pr.b2 = ctx->vec(base + ".c2." + std::to_string(d) + ".b");
+        pr.w1l = reinterpret_cast<const unsigned short*>(ctx->vec_or_null(base + ".c1." + std::to_string(d) + ".wl"));
+        pr.w2l = reinterpret_cast<const unsigned short*>(ctx->vec_or_null(base + ".c2." + std::to_string(d) + ".wl"));
         pr.x = d == 0 ? s.up.ref() : s.xo[b][d - 1].ref();
         pr.y = s.xo[b][d].ref();
         pr.k = c.voc_rb_kernels[b]; pr.dil = c.voc_rb_dilations[b][d];

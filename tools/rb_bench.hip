@@ -1,6 +1,6 @@
 // Developer tool: correctness (against a scalar CPU restatement on sampled outputs) and timing of
 // cnk::resblock_fused_kernel on the vocoder's stage shapes.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I conan_amd/csrc tools/rb_bench.hip conan_amd/csrc/resblock_fused.hip -o tools/bin/rb_bench
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I conan_amd/csrc tools/rb_bench.hip conan_amd/csrc/resblock_fused.hip conan_amd/csrc/resblock_limb.hip -o tools/bin/rb_bench
 //   tools/bin/rb_bench [B=64] [frames=4] [iters=20]
 #include <hip/hip_runtime.h>
 
@@ -27,6 +27,28 @@ static std::vector<float> pack_frag(const HostConv& c) {
           for (int s = 0; s < 4; ++s) {
             const int ci = q * 16 + 4 * (lane >> 4) + s, co = ct * 16 + (lane & 15);
             out[(((size_t)ct * (k + 1) + j) * KQ + q) * 256 + lane * 4 + s] = c.w[((size_t)co * C + ci) * k + j];
+          }
+  return out;
+}
+
+// bf16 limbs of the same weights (resblock_limb.hip): [ct][k + 1 taps][C/32 K blocks][3 limbs][64 lanes][8]
+static unsigned short bf16_rne(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); }
+static float bf16_f(unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static std::vector<unsigned short> pack_limb(const HostConv& c) {
+  const int C = c.C, k = c.k, KB = C / 32, NCT = C / 16;
+  std::vector<unsigned short> out((size_t)NCT * (k + 1) * KB * 3 * 512, 0);
+  for (int ct = 0; ct < NCT; ++ct)
+    for (int j = 0; j < k; ++j)
+      for (int q = 0; q < KB; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int ci = q * 32 + 8 * (lane >> 4) + e, co = ct * 16 + (lane & 15);
+            const float w = c.w[((size_t)co * C + ci) * k + j];
+            const unsigned short h = bf16_rne(w); const float r1 = w - bf16_f(h);
+            const unsigned short m = bf16_rne(r1); const float r2 = r1 - bf16_f(m);
+            const unsigned short l = bf16_rne(r2);
+            const size_t base = ((((size_t)ct * (k + 1) + j) * KB + q) * 3) * 512 + lane * 8 + e;
+            out[base] = h; out[base + 512] = m; out[base + 1024] = l;
           }
   return out;
 }
@@ -71,21 +93,25 @@ int main(int argc, char** argv) {
         }
         auto up = [&](const std::vector<float>& v) { float* p; CHECK(hipMalloc(&p, v.size() * 4)); CHECK(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice)); return p; };
         a.p[b].w1 = up(pack_frag(c1[b])); a.p[b].w2 = up(pack_frag(c2[b])); a.p[b].b1 = up(c1[b].b); a.p[b].b2 = up(c2[b].b);
+        auto up16 = [&](const std::vector<unsigned short>& v) { unsigned short* p; CHECK(hipMalloc(&p, v.size() * 2 + 65536)); CHECK(hipMemcpy(p, v.data(), v.size() * 2, hipMemcpyHostToDevice)); return p; };
+        a.p[b].w1l = up16(pack_limb(c1[b])); a.p[b].w2l = up16(pack_limb(c2[b]));
         cnk::TRef r; r.base = dx + (size_t)b * B * ss; r.slot_stride = ss; r.C = C; r.lmask = L - 1; r.rate = sg.rate; r.off = 0; r.mode = 0; r.pad_ = 0;
         a.p[b].x = r; r.base = dy + (size_t)b * B * ss; a.p[b].y = r;
         a.p[b].k = ks[b]; a.p[b].dil = d;
       }
       a.slots = dslots; a.pos = dpos; a.nprob = 3; a.n = B; a.T = T; a.slope = slope;
       // RB_MERGE=1: merged-branch build (the three branches of a (slot, row tile) in one workgroup, only leaky_relu(mean) stored)
-      const bool merge = getenv("RB_MERGE") != nullptr && cnk::resblock_fused_can_merge(C, cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu));
+      const bool limb = getenv("RB_LIMB") != nullptr && cnk::resblock_limb_supported(C, 11, 10 * d);
+      const bool merge = getenv("RB_MERGE") != nullptr && (limb ? cnk::resblock_limb_can_merge(C, cnk::resblock_limb_rows(C, 10 * d)) : cnk::resblock_fused_can_merge(C, cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu)));
       float* dmean = nullptr;
       if (merge) { CHECK(hipMalloc(&dmean, (size_t)B * ss * 4)); CHECK(hipMemset(dmean, 0, (size_t)B * ss * 4)); a.merge = 1; a.ymean = a.p[0].y; a.ymean.base = dmean; }
       unsigned long long* ddbg = nullptr;
       CHECK(hipMalloc(&ddbg, 260 * 4 * 8)); CHECK(hipMemset(ddbg, 0, 260 * 4 * 8));
       a.dbg = ddbg;
       int* dsched; CHECK(hipMalloc(&dsched, 8)); CHECK(hipMemset(dsched, 0, 8)); a.sched = dsched;
-      const int rows = getenv("RB_ROWS") && C == 64 ? atoi(getenv("RB_ROWS")) : cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu);
-      if (!cnk::launch_resblock_fused(a, C, rows, num_cu, 0)) { printf("launch failed\n"); return 1; }
+      const int rows = limb ? cnk::resblock_limb_rows(C, 10 * d) : getenv("RB_ROWS") && C == 64 ? atoi(getenv("RB_ROWS")) : cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu);
+      auto launch = [&] { return limb ? cnk::launch_resblock_limb(a, C, rows, num_cu, 0) : cnk::launch_resblock_fused(a, C, rows, num_cu, 0); };
+      if (!launch()) { printf("launch failed\n"); return 1; }
       CHECK(hipDeviceSynchronize());
       CHECK(hipMemcpy(hy.data(), dy, hy.size() * 4, hipMemcpyDeviceToHost));
       std::vector<float> hmean;
@@ -142,13 +168,13 @@ int main(int argc, char** argv) {
       }
       // ---- timing
       hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-      for (int w = 0; w < 3; ++w) cnk::launch_resblock_fused(a, C, rows, num_cu, 0);
+      for (int w = 0; w < 3; ++w) launch();
       CHECK(hipEventRecord(e0, 0));
-      for (int w = 0; w < iters; ++w) cnk::launch_resblock_fused(a, C, rows, num_cu, 0);
+      for (int w = 0; w < iters; ++w) launch();
       CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
       float ms = 0.f; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
       const double flops = 2.0 * 2.0 * 21.0 * C * C * (double)B * T;
-      printf("C=%3d T=%5d dil=%d rows/tile=%3d: max|err| %.2e (max|ref| %.2f) stray=%lld  %8.1f us  %6.1f TFLOP/s (%.1f%% of 157.3)\n", C, T, d, rows, worst, scale, stray,
+      printf("%s C=%3d T=%5d dil=%d rows/tile=%3d: max|err| %.2e (max|ref| %.2f) stray=%lld  %8.1f us  %6.1f TFLOP/s (%.1f%% of 157.3)\n", limb ? "limb" : "f32 ", C, T, d, rows, worst, scale, stray,
              ms * 1e3, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 157.3 * 100);
       {
         std::vector<unsigned long long> hd(260 * 4);
