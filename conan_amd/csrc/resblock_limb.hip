@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 namespace {
 struct RLCand { int C, NR2, span; };
 // tile heights that leave a decoder megakernel workgroup its 34 KB of LDS beside the block (6 bytes per element here)
-const RLCand kLimbCands[] = {{32, 10, 50}, {64, 5, 50}};
+const RLCand kLimbCands[] = {{32, 10, 50}, {64, 5, 50}, {128, 2, 50}};
 }
 
 bool resblock_limb_supported(int C, int kmax, int span_max) {
@@ -508,14 +508,16 @@ bool launch_resblock_limb(const RBArgs& a, int C, int rows, int num_cu, hipStrea
   if (a.merge) {
     if (C == 32 && nr2 == 10) return launch_rl<32, 10, 50, true>(a, num_cu, st);
     if (C == 64 && nr2 == 5) return launch_rl<64, 5, 50, true>(a, num_cu, st);
+    if (C == 128 && nr2 == 2) return launch_rl<128, 2, 50, true>(a, num_cu, st);
     return false;
   }
   if (C == 32 && nr2 == 10) return launch_rl<32, 10, 50>(a, num_cu, st);
   if (C == 64 && nr2 == 5) return launch_rl<64, 5, 50>(a, num_cu, st);
+  if (C == 128 && nr2 == 2) return launch_rl<128, 2, 50>(a, num_cu, st);
   return false;
 }
 
-bool resblock_limb_can_merge(int C, int rows) { return (C == 32 && rows == 160) || (C == 64 && rows == 80); }
+bool resblock_limb_can_merge(int C, int rows) { return (C == 32 && rows == 160) || (C == 64 && rows == 80) || (C == 128 && rows == 32); }
 
 const char* resblock_limb_name(int C, int rows, bool merge) {
   static thread_local char buf[72];
