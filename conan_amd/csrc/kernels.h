@@ -114,6 +114,7 @@ struct RBArgs {
                                       // one per stream that may have a fused launch in flight
   int nprob, n, T;                    // branches, slots in this batch, output rows per slot
   int tiles_per_slot;
+  int order[3];                       // the branches by descending k (stable): the order of the separate-branch tile list (filled by the launcher)
   float slope;
   // merge = 1 (last dilation of a stage, enough row tiles to fill the chip): a workgroup runs the nprob branches of one
   // (slot, row tile) one after the other and stores only leaky_relu(mean of the branch outputs) to `ymean` - the sum
@@ -131,7 +132,8 @@ const char* resblock_fused_name(int C, int rows, bool merge = false);
 const int* resblock_tiles(const RBArgs& a, int ro, int* total_out);      // the cached device tile list of a launch shape (resblock_fused.hip)
 // The same tile pass with every fp32 product as six bf16 limb products on the bf16 MFMA (resblock_limb.hip): same arguments
 // (RBProb::w1l / w2l), half as tall tiles.
-bool resblock_limb_supported(int C, int kmax, int span_max);
+bool resblock_limb_supported(int C, int kmax, int span_max);      // (and at most 256 slots per launch: launch_resblock_limb refuses more)
+constexpr int kResblockLimbMaxSlots = 256;
 int resblock_limb_rows(int C, int span_max);
 bool launch_resblock_limb(const RBArgs& a, int C, int rows, int num_cu, hipStream_t st);
 bool resblock_limb_can_merge(int C, int rows);

@@ -25,6 +25,8 @@
 
 #include "kernels.h"
 
+#define RL_MAX_SLOTS 256      // batch indices whose {slot, pos} the block keeps in LDS (launches with more take the f32 kernel)
+
 #ifndef RL_STAMPS
 #define RL_STAMPS 0     // developer builds (tools/rb_bench -DRL_STAMPS=1): cycle stamps of the matrix waves per block
 #endif
@@ -43,7 +45,6 @@ typedef const int __attribute__((address_space(1)))* gci;
 
 __device__ __forceinline__ f32x4 rl_gload(const void* p) { return *(gcf4)(p); }
 __device__ __forceinline__ float4 rl_gload4(const float* p) { const f32x4 v = *(gcf4)(p); return make_float4(v[0], v[1], v[2], v[3]); }
-__device__ __forceinline__ float rl_gload1(const float* p) { return *(gcf1)(p); }
 __device__ __forceinline__ void rl_gstore4(float* p, const float4 v) { *(gf4)(p) = (f32x4){v.x, v.y, v.z, v.w}; }
 
 // x = h + m + l (round-to-nearest-even at every step; the two subtractions are exact)
@@ -84,7 +85,7 @@ struct RLGeom {
   static constexpr int BLK = 3 * 512;                 // u16 per (K block, column tile): 3 limbs x 1 KiB
   static_assert(C % 32 == 0 && KB % RING == 0, "channel count");
   static_assert(RO * LDA * 4 <= 3 * PLX * 2, "accumulator image inside the xt planes");
-  static_assert(LDS_U16 * 2 + 16 <= 160 * 1024, "LDS budget");
+  static_assert(LDS_U16 * 2 + 32 + 8 * RL_MAX_SLOTS <= 160 * 1024, "LDS budget");
 };
 
 template <int NCW, int RING>
@@ -178,11 +179,12 @@ template <int C, int NR2, int SPAN, bool MERGE>
 __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
   using G = RLGeom<C, NR2, SPAN>;
   constexpr int LDB = G::LDB;
-  __shared__ __attribute__((aligned(16))) u16 lds[G::LDS_U16 + 8];      // + meta: {zero rows, next tile, its branch, draw generation}
+  __shared__ __attribute__((aligned(16))) u16 lds[G::LDS_U16 + 16 + 4 * RL_MAX_SLOTS];   // + meta: {zero rows, drawn tile, next tile's branch, draw generation} + {slot, pos} per batch index
   u16* const win = lds;                                // [3][WR_MAX][LDB] limbs of leaky_relu(x)
   u16* const xt = lds + 3 * G::PLW;                    // [3][XT_ROWS][LDB] limbs of leaky_relu(c1 + b1)
   float* const accimg = reinterpret_cast<float*>(xt);  // [RO][LDA] c2's accumulators (behind B4)
   int* const meta = reinterpret_cast<int*>(lds + G::LDS_U16);
+  int* const sptab = meta + 8;                          // [n][2]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,9 +201,13 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     const int ht = tid - 256;
     __builtin_amdgcn_s_setprio(3);
     auto hbar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto slot_of = [&](int i) __attribute__((always_inline)) { return a.slots ? __builtin_amdgcn_readfirstlane(*(gci)(a.slots + i)) : i; };
-    auto pos_of = [&](int slot) __attribute__((always_inline)) { return a.pos ? __builtin_amdgcn_readfirstlane(*(gci)(a.pos + slot)) : 0; };
-    auto load_window = [&](const int p, const int i, const int t0, const int slot, const int pos) __attribute__((always_inline)) {
+    // The next tile's window in two halves: win_issue() - behind B3, while the matrix waves are still in c1's epilogue - puts its
+    // global loads in flight (registers); win_write() - behind B1, when the window is dead - applies LeakyReLU, splits into limbs
+    // and stores the three planes.
+    constexpr int NIT = (G::WR_MAX * G::C4 + 255) / 256;
+    float4 wv[NIT];
+    int wtotal = 0, wzr = 0;
+    auto win_issue = [&](const int p, const int i, const int t0, const int slot, const int pos) __attribute__((always_inline)) {
       const int k = RL_SEL(p, k), d = RL_SEL(p, dil);
       const int wr = G::XT_ROWS + (k - 1) * d;
       const int tw0 = t0 - (k - 1) - (k - 1) * d;
@@ -209,42 +215,43 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       const float* xb = RL_SEL(p, x.base) + (long long)(xmode == 0 ? slot : i) * RL_SEL(p, x.slot_stride);
       const unsigned rbase = (xmode == 0 ? (unsigned)pos * (unsigned)xrate : 0u) + (unsigned)(RL_SEL(p, x.off) + tw0);
       const unsigned rmask = xmode == 0 ? (unsigned)RL_SEL(p, x.lmask) : 0xffffffffu;
-      constexpr int NIT = (G::WR_MAX * G::C4 + 255) / 256;
-      float4 v[NIT];
-      const int total = wr * G::C4;
+      wtotal = wr * G::C4;
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         const int idx = ht + 256 * u;
         const int w = idx / G::C4, c4 = idx - w * G::C4;
         const unsigned row = (rbase + (unsigned)w) & rmask;
-        v[u] = idx < total ? rl_gload4(xb + (long long)row * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wv[u] = idx < wtotal ? rl_gload4(xb + (long long)row * C + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      // xt row m is time t0 - (k-1) + m; rows before the start of the stream (absolute time < 0) are c2's zero left padding
+      const long long abs0 = (xmode == 0 ? (long long)pos * xrate : 0ll) + t0 - (k - 1);
+      wzr = abs0 >= 0 ? 0 : (abs0 < -(long long)G::XT_ROWS ? G::XT_ROWS : (int)-abs0);
+    };
+    auto win_write = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < NIT; ++u) {
         const int idx = ht + 256 * u;
         const int w = idx / G::C4, c4 = idx - w * G::C4;
-        float q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        float q[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
         u16 h[4], m[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float s = q[e] > 0.f ? q[e] : q[e] * slope;
           rl_split(s, h[e], m[e], l[e]);
         }
-        if (idx < total) {
+        if (idx < wtotal) {
           u16* dst = win + w * LDB + c4 * 4;
           *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
           *reinterpret_cast<uint2*>(dst + G::PLW) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
           *reinterpret_cast<uint2*>(dst + 2 * G::PLW) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
         }
       }
-      const long long abs0 = (xmode == 0 ? (long long)pos * xrate : 0ll) + t0 - (k - 1);
-      if (ht == 0) meta[0] = abs0 >= 0 ? 0 : (abs0 < -(long long)G::XT_ROWS ? G::XT_ROWS : (int)-abs0);
+      if (ht == 0) meta[0] = wzr;
     };
     constexpr int NOUT = (G::RO * G::C4) / 256;
     static_assert((G::RO * G::C4) % 256 == 0 && 256 % G::C4 == 0, "output tile / helper threads");
-    constexpr int NOB = (NOUT + 1) / 2;
     const int oc4 = ht % G::C4;
-    float4 oacc[NOUT], osum[MERGE ? NOUT : 1];
+    float4 oacc[NOUT], ores[NOUT], osum[MERGE ? NOUT : 1], ob2 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* oxb = nullptr; const float* ob2p = nullptr;
     float* oyb = nullptr;
     unsigned oyr0 = 0, oym = 0, oxr0 = 0, oxm = 0;
@@ -271,86 +278,143 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       ob2p = RL_SEL(p, b2) + oc4 * 4;
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) oacc[u] = *reinterpret_cast<const float4*>(accimg + ((ht + 256 * u) / G::C4) * G::LDA + oc4 * 4);
+      // the residual rows (and c2's bias): in flight through the next tile's c1, consumed by out_store() behind B3 - which must
+      // not wait for a load younger than the window loads issued just before it
+      ob2 = rl_gload4(ob2p);
+#pragma unroll
+      for (int u = 0; u < NOUT; ++u) {
+        const int r = (ht + 256 * u) / G::C4;
+        ores[u] = ot0 + r < T ? rl_gload4(oxb + (long long)((oxr0 + (unsigned)r) & oxm) * C + oc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     };
     auto out_store = [&]() __attribute__((always_inline)) {
-      const float4 ob2 = rl_gload4(ob2p);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float4 ores[NOB];
-#pragma unroll
-        for (int q = 0; q < NOB; ++q) {
-          const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
-          ores[q] = (u < NOUT && ot0 + r < T) ? rl_gload4(oxb + (long long)((oxr0 + (unsigned)r) & oxm) * C + oc4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < NOB; ++q) {
-          const int u = h * NOB + q, r = (ht + 256 * u) / G::C4;
-          if (u < NOUT && ot0 + r < T) {
-            const float4 v = make_float4((oacc[u].x + ob2.x) + ores[q].x, (oacc[u].y + ob2.y) + ores[q].y, (oacc[u].z + ob2.z) + ores[q].z, (oacc[u].w + ob2.w) + ores[q].w);
-            if constexpr (!MERGE) rl_gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4, v);
-            else {
-              float4 sm = osum[MERGE ? u : 0];
-              if (op == 0) sm = v; else { sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w; }
-              osum[MERGE ? u : 0] = sm;
-              if (op == np - 1) {
-                const float dn = (float)np;
-                if (np > 1) { sm.x /= dn; sm.y /= dn; sm.z /= dn; sm.w /= dn; }
-                sm.x = sm.x > 0.f ? sm.x : sm.x * slope; sm.y = sm.y > 0.f ? sm.y : sm.y * slope;
-                sm.z = sm.z > 0.f ? sm.z : sm.z * slope; sm.w = sm.w > 0.f ? sm.w : sm.w * slope;
-                rl_gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * oyC + oc4 * 4, sm);
-              }
+      for (int u = 0; u < NOUT; ++u) {
+        const int r = (ht + 256 * u) / G::C4;
+        if (ot0 + r < T) {
+          const float4 v = make_float4((oacc[u].x + ob2.x) + ores[u].x, (oacc[u].y + ob2.y) + ores[u].y, (oacc[u].z + ob2.z) + ores[u].z, (oacc[u].w + ob2.w) + ores[u].w);
+          if constexpr (!MERGE) rl_gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * C + oc4 * 4, v);
+          else {
+            // mean_act_kernel's arithmetic on the values the branch launches would have stored: (v0 + v1) + v2, / n, LeakyReLU
+            float4 sm = osum[MERGE ? u : 0];
+            if (op == 0) sm = v; else { sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w; }
+            osum[MERGE ? u : 0] = sm;
+            if (op == np - 1) {
+              const float dn = (float)np;
+              if (np > 1) { sm.x /= dn; sm.y /= dn; sm.z /= dn; sm.w /= dn; }
+              sm.x = sm.x > 0.f ? sm.x : sm.x * slope; sm.y = sm.y > 0.f ? sm.y : sm.y * slope;
+              sm.z = sm.z > 0.f ? sm.z : sm.z * slope; sm.w = sm.w > 0.f ? sm.w : sm.w * slope;
+              rl_gstore4(oyb + (long long)((oyr0 + (unsigned)r) & oym) * oyC + oc4 * 4, sm);
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    int p = tile_word(first_tile, 0), i = tile_word(first_tile, 1), t0 = tile_word(first_tile, 2);
-    int slot = slot_of(i), pos = pos_of(slot);
-    int cur = first_tile;
-    if (ht == 0) meta[3] = 0;
-    load_window(p, i, t0, slot, pos);
-    hbar();                                              // B0: first window staged
-    bool pending = false;
-    int gen = 1;
-    for (;;) {
-      hbar();                                            // B3: the previous tile's accumulators are in registers (out_fetch)
-      hbar();                                            // B1: xt complete, window free
-      int nv = 0;
-      if (wave == 4 && lane == 0) {
-        if (merge && p != np - 1) nv = cur + 1;
-        else {
-          nv = (int)gridDim.x + __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (merge) nv *= np;
-        }
+    // {slot, pos} of every batch index, once: a drawn tile is then decoded without a global load behind the draw itself
+    for (int e = ht; e < a.n; e += 256) {
+      const int sl = a.slots ? *(gci)(a.slots + e) : e;
+      sptab[2 * e] = sl; sptab[2 * e + 1] = a.pos ? *(gci)(a.pos + sl) : 0;
+    }
+    const int tps = a.tiles_per_slot, per_prob = a.n * tps;
+    // tile index -> {branch, batch index, first row} (the order of resblock_tiles(): separate branches by descending k, or
+    // (slot, row tile)-major groups with the branches adjacent)
+    auto decode = [&](const int e, int& p, int& i, int& t0) __attribute__((always_inline)) {
+      if constexpr (!MERGE) {
+        const int b = e / per_prob, rem = e - b * per_prob;
+        p = b == 0 ? a.order[0] : (b == 1 ? a.order[1] : a.order[2]);
+        i = rem / tps; t0 = (rem - i * tps) * G::RO;
+      } else {
+        const int g = e / np;
+        p = e - g * np; i = g / tps; t0 = (g - i * tps) * G::RO;
       }
-      if (pending) out_store();
-      int nidx, pn;
+    };
+    // The draw runs TWO tiles ahead of the matrix waves: `cur` is being computed, `nxt` (known since the previous tile) is
+    // the window staged during cur, and the tile after it is drawn while cur's c1 runs - the atomic's round trip (and nothing
+    // else: the decode is arithmetic + an LDS lookup) has that whole phase, so no barrier waits for it.  (One tile ahead, the
+    // chain draw -> tile words -> slot -> pos -> window loads sat between B3 and B1 of every tile: 14-20 % of a block's life in
+    // barrier waits at half the f32 pass's tile height.)
+    int cur = first_tile, p, i, t0;
+    decode(cur, p, i, t0);
+    if (ht == 0) meta[3] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // helper waves only see each other's table entries behind a barrier:
+    // (block-wide s_barrier: the matrix waves take part - their B(-1), see below)
+    int slot = __builtin_amdgcn_readfirstlane(sptab[2 * i]), pos = __builtin_amdgcn_readfirstlane(sptab[2 * i + 1]);
+    win_issue(p, i, t0, slot, pos);
+    int gen = 1;                                         // generation of the published draw (meta[3])
+    // draw(known_idx, known_p): issue; publish(): wave 4 lane 0 hands the index to the other helper waves through LDS
+    int dv = 0, dnext = -1;                              // wave 4 lane 0: the counter value, in flight (NOT touched before draw_take: a
+                                                         // use would put the atomic's round trip in front of B3), or the known successor
+    auto draw_issue = [&](const int have, const int idx_prev, const int p_prev) __attribute__((always_inline)) {
+      if (wave == 4 && lane == 0 && have) {
+        if (merge && p_prev != np - 1) dnext = idx_prev + 1;       // next branch of this group: no draw
+        else { dnext = -1; dv = __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+    };
+    auto draw_take = [&](const int have) __attribute__((always_inline)) {
+      int idx = -1;
+      if (!have) return idx;
       if (wave == 4) {
-        int pv = -1;
-        if (lane == 0) pv = nv < ntiles ? *(gci)(a.tiles + (long long)nv * 4) : -1;
-        nidx = __builtin_amdgcn_readfirstlane(nv); pn = __builtin_amdgcn_readfirstlane(pv);
+        const int drawn = ((int)gridDim.x + dv) * (merge ? np : 1);      // (merge: a drawn group's first tile)
+        idx = __builtin_amdgcn_readfirstlane(dnext >= 0 ? dnext : drawn);
+        if (idx >= ntiles) idx = -1;
         if (lane == 0) {
-          meta[1] = nidx; meta[2] = pn;
+          meta[1] = idx;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __hip_atomic_store(&meta[3], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       } else {
-        while (__hip_atomic_load(&meta[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen) __builtin_amdgcn_s_sleep(8);
-        nidx = __builtin_amdgcn_readfirstlane(meta[1]); pn = __builtin_amdgcn_readfirstlane(meta[2]);
+        while (__hip_atomic_load(&meta[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != gen) __builtin_amdgcn_s_sleep(4);
+        idx = __builtin_amdgcn_readfirstlane(meta[1]);
       }
       ++gen;
-      int in = 0, t0n = 0, slotn = 0, posn = 0;
-      if (pn >= 0) { in = tile_word(nidx, 1); t0n = tile_word(nidx, 2); slotn = slot_of(in); posn = pos_of(slotn); }
-      if (pn >= 0) load_window(pn, in, t0n, slotn, posn);
+      return idx;
+    };
+    // (with few tiles per block - the C = 128 stage: 3.75 - committing two tiles ahead costs more balance than the barrier wait it
+    // removes: 108 us against 97; such launches draw ONE tile ahead, the tile drawn during c1 is staged right behind B3)
+    const bool deep = ntiles >= 5 * (int)gridDim.x * (merge ? np : 1);
+    // (few scalars live across the loop: a tile is kept as its index and decoded where it is used)
+    auto stage = [&](const int e) __attribute__((always_inline)) {      // the window loads of tile e
+      int pe, ie, te;
+      decode(e, pe, ie, te);
+      win_issue(pe, ie, te, __builtin_amdgcn_readfirstlane(sptab[2 * ie]), __builtin_amdgcn_readfirstlane(sptab[2 * ie + 1]));
+      return pe;
+    };
+    int nxt = -1, pn = -1;
+    if (deep) {
+      draw_issue(1, cur, p);
+      nxt = draw_take(1);
+    }
+    win_write();
+    hbar();                                              // B0: first window staged
+    bool pending = false;                                // a fetched output tile waits for its stores
+    for (;;) {
+      // cur's c1 is running and the helpers have nothing else to do: everything up to the next window's loads happens here, so
+      // that B3 and B1 find the helper waves already waiting
+      const bool have = deep ? nxt >= 0 : true;
+      if (deep && nxt >= 0) pn = stage(nxt);
+      draw_issue(have, deep ? nxt : cur, deep ? pn : p);   // deep: the tile after nxt
+      if (pending) out_store();
+      int nn = draw_take(have);
+      if (!deep) {
+        nxt = nn; nn = -1; pn = -1;
+        if (nxt >= 0) pn = stage(nxt);
+      }
+      hbar();                                            // B3: the previous tile's accumulators are in registers (out_fetch)
+      hbar();                                            // B1: xt complete, window free
+      if (nxt >= 0) win_write();
+      if (ht == 0) meta[2] = nxt >= 0 ? pn : -1;         // the matrix waves read nxt's branch behind B4
       hbar();                                            // B4
       hbar();                                            // B2: c2 accumulators in LDS, next window staged
       out_fetch(p, i, t0, slot, pos);
       pending = true;
-      if (pn < 0) break;
-      p = pn; i = in; t0 = t0n; slot = slotn; pos = posn; cur = nidx;
+      if (nxt < 0) break;
+      cur = nxt;
+      decode(cur, p, i, t0);
+      slot = __builtin_amdgcn_readfirstlane(sptab[2 * i]); pos = __builtin_amdgcn_readfirstlane(sptab[2 * i + 1]);
+      nxt = nn;
     }
     if (pending) out_store();
+    // the last block to leave re-arms the queue for the next launch
     if (ht == 0) {
       const int d = __hip_atomic_fetch_add(a.sched + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d == (int)gridDim.x - 1) {
@@ -382,6 +446,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     const long long cs = (long long)(RL_SEL(p, k) + 1) * G::KB * G::BLK;
     rl_prefetch_w<G::NCW, G::RING>(bw, RL_SEL(p, w1l) + (long long)ct0 * cs + lane * 8, cs);
   }
+  bar();                                                 // (the helpers' {slot, pos} table is complete)
   bar();                                                 // B0
   while (p >= 0) {
     const int k = RL_SEL(p, k), d = RL_SEL(p, dil);
@@ -496,6 +561,9 @@ static bool launch_rl(const RBArgs& ain, int num_cu, hipStream_t st) {
   if (total <= 0) return true;
   if (!a.sched) return false;
   for (int p = 0; p < a.nprob; ++p) if (!a.p[p].w1l || !a.p[p].w2l) return false;
+  if (a.n > RL_MAX_SLOTS) return false;
+  for (int p = 0; p < 3; ++p) a.order[p] = p;
+  std::stable_sort(a.order, a.order + a.nprob, [&](int x, int y) { return a.p[x].k > a.p[y].k; });
   const int grid = std::min(a.merge ? total / a.nprob : total, num_cu);
   a.tiles = resblock_tiles(a, ro, &a.ntiles);
   if (!a.tiles) return false;

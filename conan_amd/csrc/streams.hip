@@ -176,13 +176,17 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   int span = 0;
   bool limb = rb_limb;
   for (int p = 0; p < a.nprob; ++p) { span = std::max(span, (a.p[p].k - 1) * a.p[p].dil); limb = limb && a.p[p].w1l && a.p[p].w2l; }
-  limb = limb && cnk::resblock_limb_supported(C, kmax, span);
+  limb = limb && a.n <= cnk::kResblockLimbMaxSlots && cnk::resblock_limb_supported(C, kmax, span);
   const int rows = limb ? cnk::resblock_limb_rows(C, span) : cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
   // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
   // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.
   // With fewer groups than CUs (C = 128 at 64 streams: 128) the branches stay separate tiles.
   const long long groups = (long long)a.n * ((a.T + rows - 1) / rows);
-  a.merge = (ymean && rb_merge && a.nprob > 1 && groups >= cus && (limb ? cnk::resblock_limb_can_merge(C, rows) : cnk::resblock_fused_can_merge(C, rows))) ? 1 : 0;
+  // (a group is the unit of work of a merged launch: the last round of groups must not leave most CUs idle - 320 groups on 256
+  // CUs, the limb build of the C = 128 stage at 64 streams, ran 137 us merged against 98 + 6 us as separate branches + mean_act)
+  const long long rounds = (groups + cus - 1) / cus;
+  const bool balanced = groups * 10 >= rounds * cus * 9;
+  a.merge = (ymean && rb_merge && a.nprob > 1 && groups >= cus && balanced && (limb ? cnk::resblock_limb_can_merge(C, rows) : cnk::resblock_fused_can_merge(C, rows))) ? 1 : 0;
   if (a.merge) a.ymean = *ymean;
   profiled(limb ? cnk::resblock_limb_name(C, rows, a.merge != 0) : cnk::resblock_fused_name(C, rows, a.merge != 0), fl, st, [&] {
     if (!(limb ? cnk::launch_resblock_limb(a, C, rows, cus, st) : cnk::launch_resblock_fused(a, C, rows, cus, st))) throw Error(CONAN_ERR_HIP, "fused resblock launch failed");
