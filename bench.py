@@ -37,6 +37,18 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32-input MFMA, dense
+# bf16 MFMA, dense: 16x the f32-input rate (MI355X_MICROARCH.md, Matrix cores: "F32 ... 1/16 of BF16"; ~2.5 PF spec).  The limb
+# kernels (resblock_limb.hip) compute every fp32 product as SIX bf16 products, so their ceiling in ALGORITHMIC fp32 FLOP/s is a
+# sixth of it; `achieved` stays algorithmic (2 * M * N * K of the fp32 convolution), never the 6x executed bf16 FLOPs.
+PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_F32_MFMA_TFLOPS
+PEAK_LIMB_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def kernel_peak(name):
+    """(peak in algorithmic TFLOP/s, what it is) of a matrix kernel by its name."""
+    if "resblock_limb" in name:
+        return PEAK_LIMB_TFLOPS, "bf16 MFMA dense / 6 limb products per fp32 product"
+    return PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 N_FRAMES, N_REF = 151, 151     # 3 s source + 3 s reference at 50 frames/s (SURVEY.md §8d)
 # SURVEY.md §8(d): algorithmic work per chunk per stream (stateful, seg = 4) and bytes per step
@@ -377,15 +389,17 @@ def main():
             step_bytes = pmc.get("bytes_per_step")
         flops_step = B * frames_per_step * GFLOP_PER_FRAME * 1e9
         bytes_alg = WEIGHT_BYTES_PER_STEP + B * STATE_BYTES_PER_STREAM * (frames_per_step / seg)
-        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+        k_peak, k_peak_basis = kernel_peak(name)
+        roof = {"bound": "mfma", "achieved": ach, "peak": k_peak, "unit": "TFLOP/s",
+                "frac": ach / k_peak, "peak_basis": k_peak_basis, "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
                 "traffic_stale": pmc_stale if traffic is not None else None, "lib_sha256": lib_sha256(),
                 "mfma_busy_frac_pmc": mfma_busy,
                 "kernel": name, "instantiations": insts, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
                 "largest_instantiation": {"kernel": kernels[0][0], "ms_per_step": kernels[0][1] / nprof, "tflops": kernels[0][2] / (kernels[0][1] * 1e-3) / 1e12},
                 "gflop_per_launch": k_fl / k_n / 1e9, "share_of_step_time": (k_ms / nprof) / ms_step,
                 "matrix_kernels": [{"kernel": kn, "launches_per_step": n_ / nprof, "us_per_launch": ms_ * 1e3 / n_, "ms_per_step": ms_ / nprof,
-                                    "tflops": fl_ / (ms_ * 1e-3) / 1e12, "frac": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS} for kn, ms_, fl_, n_ in kernels],
+                                    "tflops": fl_ / (ms_ * 1e-3) / 1e12, "peak": kernel_peak(kn)[0], "frac": fl_ / (ms_ * 1e-3) / 1e12 / kernel_peak(kn)[0],
+                                    "frac_of_f32_mfma_peak": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS} for kn, ms_, fl_, n_ in kernels],
                 "all_matrix_kernels": {"achieved": fam, "frac": fam / PEAK_F32_MFMA_TFLOPS, "launches_per_step": conv_launches / nprof,
                                        "ms_per_step": conv_ms / nprof, "gflop_per_frame_per_stream": conv_flops / nprof / B / frames_per_step / 1e9},
                 # the whole step against both rooflines (report both, the binding one is the larger fraction)
@@ -435,7 +449,9 @@ def main():
             "metric": "chunks/sec (%d ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it" % wl["chunk_ms"],
             "value": total_chunks / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # fp32 results throughout; the ResBlock stages that run resblock_limb.hip form each fp32 product from three bf16 limbs
+            # per operand (six bf16 MFMA products, error below the f32 MFMA's own: DESIGN.md) - CONAN_RB_NOLIMB=1 gives pure f32 MFMA
+            "dtype": "f32" if os.environ.get("CONAN_RB_NOLIMB") else "f32 (bf16x3 limbs on the bf16 MFMA in the ResBlock stages)", "data": "synthetic",
             "config": {"workload": wl["desc"] if not args.streams else f"batch={B} streams per GPU, {wl['chunk_ms']} ms chunk" + (", windowed" if window else ", stateful"),
                        "name": args.workload, "baseline_config": wl["config"],
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,

@@ -22,6 +22,7 @@
 //     megakernel workgroup: tests/test_kernel_resources.py).
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -29,6 +30,15 @@
 
 #ifndef RL_STAMPS
 #define RL_STAMPS 0     // developer builds (tools/rb_bench -DRL_STAMPS=1): cycle stamps of the matrix waves per block
+#endif
+
+// developer build -DRL_ABLATE_W: every weight fragment from the tap-0 blocks (L1 hits, wrong results): what the L2 round trips cost
+#ifdef RL_ABLATE_W
+#define RL_WOFF(x) 0
+#define RL_WOFF2(a_, b_) (b_)
+#else
+#define RL_WOFF(x) (x)
+#define RL_WOFF2(a_, b_) (a_)
 #endif
 
 namespace cnk {
@@ -75,15 +85,19 @@ struct RLGeom {
   static constexpr int LDA = C + 4;                   // floats per row of c2's accumulator image (overlays the xt planes)
   static constexpr int LDS_U16 = 3 * (PLW + PLX);
   static constexpr int NCT = C / 16;
-  static constexpr int RSPLIT = NCT >= 4 ? 1 : 4 / NCT;   // C = 32: two waves share a column strip and split the rows
-  static constexpr int NCW = NCT >= 4 ? NCT / 4 : 1;
+  // Column tiles per matrix wave.  C = 128: two (four column pairs).  C = 32: two - one pair, the rows split four ways: per K
+  // block a row tile's three A fragments then feed 12 MFMAs instead of 6 (the 16-cycle MFMAs leave the LDS reads little issue
+  // room: 60 us against 65).  C = 64 keeps one (four strips, every wave all rows): two pairs x two row halves measured 92 us
+  // against 86 - the row tiles of c2 (5) do not split evenly.
+  static constexpr int NCW = C == 64 ? 1 : 2;
+  static constexpr int RSPLIT = 4 / (NCT / NCW);
   static constexpr int NRW1 = (NR1 + RSPLIT - 1) / RSPLIT;
   static constexpr int NRW2 = (NR2 + RSPLIT - 1) / RSPLIT;
   static constexpr int KB = C / 32;                   // 32-deep K blocks per tap
-  static constexpr int RING = KB >= 2 ? 2 : 1;        // weight K blocks in flight
+  static constexpr int RING = 2;                      // weight K blocks in flight
   static constexpr int C4 = C / 4;
   static constexpr int BLK = 3 * 512;                 // u16 per (K block, column tile): 3 limbs x 1 KiB
-  static_assert(C % 32 == 0 && KB % RING == 0, "channel count");
+  static_assert(C % 32 == 0 && NCT % NCW == 0 && 4 % (NCT / NCW) == 0 && (KB == 1 || KB % RING == 0), "channel count");
   static_assert(RO * LDA * 4 <= 3 * PLX * 2, "accumulator image inside the xt planes");
   static_assert(LDS_U16 * 2 + 32 + 8 * RL_MAX_SLOTS <= 160 * 1024, "LDS budget");
 };
@@ -117,6 +131,61 @@ __device__ __forceinline__ void rl_gemm(const u16* __restrict__ src, const int p
 #pragma unroll
     for (int p = 0; p < 3; ++p) af[r][p] = *reinterpret_cast<const f32x4*>(abase + p * plane + r * 16 * LDB);
   const int tstep = tap_stride * LDB;
+  if constexpr (KB == 1) {
+    // one K block per tap (C = 32): the ring of two blocks spans two TAPS (one block ahead is 0.6 us of MFMAs, less than an L2
+    // round trip under load).  Taps in pairs; an odd tap count ends on slot 0 and the slots are swapped, so that the next
+    // phase again finds its first block in slot 0.
+    static_assert(RING == 2, "ring");
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    auto block = [&](const int j, auto slot_c) __attribute__((always_inline)) {
+      constexpr int SL = decltype(slot_c)::value;
+      const u16* anext = abase + (j + 1) * tstep;
+#pragma unroll
+      for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+#pragma unroll
+          for (int c = 0; c < NCW; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[SL][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]), acc[r][c], 0, 0, 0);
+          if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + r * 16 * LDB);
+          if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + r * 16 * LDB);
+          if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + r * 16 * LDB);
+        }
+      const bool own = j + 2 < k;
+      const u16* wsrc = own ? wl + (long long)(j + 2) * 1536 : wl_next + (long long)(j + 2 - k) * 1536;
+      const long long cs = own ? ct_stride : ct_stride_next;
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bw[SL][c][p] = rl_gload(wsrc + c * cs + p * 512);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        if (s == 0 || s == 3 || s == 5) {
+#pragma unroll
+          for (int r = 0; r < NRW; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NCW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NRW * NCW, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCW, 0);
+    };
+    int j = 0;
+    for (; j + 1 < k; j += 2) {
+      block(j, std::integral_constant<int, 0>{});
+      block(j + 1, std::integral_constant<int, 1>{});
+    }
+    if (j < k) {
+      block(j, std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { const f32x4 t = bw[0][c][p]; bw[0][c][p] = bw[1][c][p]; bw[1][c][p] = t; }
+    }
+    return;
+  }
   for (int j = 0; j < k; ++j) {
     const u16* arow = abase + j * tstep;
     const bool last = j + 1 == k;
@@ -145,12 +214,12 @@ __device__ __forceinline__ void rl_gemm(const u16* __restrict__ src, const int p
 #pragma unroll
         for (int c = 0; c < NCW; ++c)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bw[q % RING][c][p] = rl_gload(wl + ((long long)j * KB + q + RING) * 1536 + c * ct_stride + p * 512);
+          for (int p = 0; p < 3; ++p) bw[q % RING][c][p] = rl_gload(wl + RL_WOFF(((long long)j * KB + q + RING) * 1536) + c * ct_stride + p * 512);
       } else {
 #pragma unroll
         for (int c = 0; c < NCW; ++c)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bw[q % RING][c][p] = rl_gload(wnext + (q + RING - KB) * 1536 + c * cnext + p * 512);
+          for (int p = 0; p < 3; ++p) bw[q % RING][c][p] = rl_gload(RL_WOFF2(wnext, wl) + (q + RING - KB) * 1536 + c * cnext + p * 512);
       }
       // pin that order
 #pragma unroll
