@@ -1,0 +1,435 @@
+// conv_limb: causal / shifted 1-D convolution as an implicit GEMM with every fp32 product computed as SIX bf16 limb products on
+// the bf16 MFMA (see resblock_limb.hip for the arithmetic: x = h + m + l per operand, hh + hm + mh + hl + mm + lh accumulated in
+// fp32; error below the f32 MFMA's own) - the upsamplers and the wide first ResBlock stage of the vocoder, which conv_mfma /
+// resblock_pair run on the f32 MFMA at 0.54 - 0.72 of its peak.
+//
+//   y[i][t][co] = epilogue( sum_{j<ktaps} sum_{ci<Cin} W[j][ci][co] * f(x[i][t + j*dil - pad_left][ci]) )      (ConvArgs)
+//
+// A workgroup (4 matrix waves + 4 helper waves, like the fused ResBlock passes) owns a TM x TN output tile, TM = 16*NRW*RW rows
+// of one slot or of TM / T whole slots (T rows per slot and step), TN = 16*NCW*CW packed output columns:
+//   * K runs over 32-channel blocks; for each the helper waves stage the block's WINDOW - per slot the tile's rows plus the
+//     (ktaps-1)*dil rows of tap reach, LeakyReLU'd and split into three bf16 planes - into one of two LDS buffers while the
+//     matrix waves compute on the other: all taps of a channel block read the same window, row-shifted (one block barrier per
+//     channel block);
+//   * weights are packed per limb at finalize ([16-column tile][channel block][tap][limb][64 lanes] x 16 bytes) and streamed from
+//     L2 straight into registers, two blocks ahead, private per wave;
+//   * MFMAs are issued transposed (weights first): a lane's accumulator holds 4 consecutive packed columns of one row, and the
+//     epilogue (bias, activation, residual, pixel-shuffle row remap) stores 16 bytes per lane.
+// Launches are persistent over a host-balanced tile list (up to 3 problems of different tap counts per launch).
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "kernels.h"
+
+namespace cnk {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef const f32x4 __attribute__((address_space(1)))* gcf4;
+typedef f32x4 __attribute__((address_space(1)))* gf4;
+typedef const int __attribute__((address_space(1)))* gci;
+
+__device__ __forceinline__ f32x4 cl_gload(const void* p) { return *(gcf4)(p); }
+__device__ __forceinline__ void cl_gstore(float* p, const f32x4 v) { *(gf4)(p) = v; }
+
+__device__ __forceinline__ void cl_split(const float x, u16& h, u16& m, u16& l) {
+  const __bf16 hb = (__bf16)x;
+  const float r1 = x - (float)hb;
+  const __bf16 mb = (__bf16)r1;
+  const float r2 = r1 - (float)mb;
+  const __bf16 lb = (__bf16)r2;
+  h = __builtin_bit_cast(u16, hb); m = __builtin_bit_cast(u16, mb); l = __builtin_bit_cast(u16, lb);
+}
+
+constexpr int CL_LDB = 48;          // bf16 elements per window row: 32 channels + 16 (a stride of 2 mod 4 16-byte slots: conflict-free ds_read_b128)
+constexpr int CL_NIT = 12;          // float4 per helper thread and slice: windows of up to 384 rows
+
+}  // namespace
+
+#define CL_SEL(q_, f) ((q_) == 0 ? g.p[0].f : ((q_) == 1 ? g.p[1].f : g.p[2].f))
+
+template <int NRW, int NCW, int RW, int CW>
+__global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g) {
+  static_assert(RW * CW == 4, "four matrix waves");
+  constexpr int TM = 16 * NRW * RW, TN = 16 * NCW * CW;
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];      // [2 buffers][3 planes][wr_max][CL_LDB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int plane = g.wr_max * CL_LDB;                           // elements per plane
+  auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto tile_word = [&](int idx, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(g.tiles + (long long)idx * 4 + w)); };
+  // this block's tiles: assign[b * per + i] until -1 (host-balanced)
+  const int* mine = g.assign + (long long)blockIdx.x * g.assign_per;
+  int gslice = 0;                                                // slices staged / consumed so far (buffer = parity)
+
+  if (wave >= 4) {
+    // ============================================================ helper waves: window slices
+    const int ht = tid - 256;
+    __builtin_amdgcn_s_setprio(3);
+    for (int it = 0; it < g.assign_per; ++it) {
+      const int tile = __builtin_amdgcn_readfirstlane(*(gci)(mine + it));
+      if (tile < 0) break;
+      const int q = tile_word(tile, 0), mt = tile_word(tile, 1);
+      const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
+      const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil, S = TM / Tt, wr = S * wrs;
+      const int m0 = mt * TM, i0 = m0 / T, ta = m0 - i0 * T;
+      const bool ring = CL_SEL(q, x.mode) == 0;
+      const float* xb = CL_SEL(q, x.base);
+      const int xC = CL_SEL(q, x.C), xmask = ring ? CL_SEL(q, x.lmask) : -1, xrate = CL_SEL(q, x.rate), xoff = CL_SEL(q, x.off) - CL_SEL(q, pad_left);
+      const long long xss = CL_SEL(q, x.slot_stride);
+      const int* slots = CL_SEL(q, slots);
+      const int* pos = CL_SEL(q, pos);
+      const bool act = CL_SEL(q, in_act) == ACT_LRELU;
+      const float slope = CL_SEL(q, in_slope);
+      // per thread: the rows it stages (window row w = idx / 8, 4-channel group idx % 8), as float offsets from xb
+      int roff[CL_NIT], loff[CL_NIT];
+      const int total = wr * 8;
+#pragma unroll
+      for (int u = 0; u < CL_NIT; ++u) {
+        const int idx = ht + 256 * u;
+        roff[u] = -1; loff[u] = 0;
+        if (idx < total) {
+          const int w = idx >> 3, c4 = idx & 7, s = w / wrs, o = w - s * wrs;
+          const int i = i0 + s, slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
+          const int row = ((ring ? pv * xrate : 0) + xoff + ta + o) & xmask;
+          roff[u] = (int)((long long)(ring ? slot : i) * xss) + row * xC + c4 * 4;
+          loff[u] = w * CL_LDB + c4 * 4;
+        }
+      }
+      const int nblk = Cin / 32;
+      for (int cb = 0; cb < nblk; ++cb) {
+        u16* dstb = lds + (gslice & 1) * 3 * plane;
+        f32x4 v[CL_NIT];
+#pragma unroll
+        for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + cb * 32);
+#pragma unroll
+        for (int u = 0; u < CL_NIT; ++u) {
+          if (roff[u] >= 0) {
+            u16 h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float s = v[u][e];
+              if (act) s = s > 0.f ? s : s * slope;
+              cl_split(s, h[e], m[e], l[e]);
+            }
+            u16* d = dstb + loff[u];
+            *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
+            *reinterpret_cast<uint2*>(d + plane) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
+            *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
+          }
+        }
+        bar();                                                   // slice staged (and the matrix waves are done with the other buffer)
+        ++gslice;
+      }
+    }
+    return;
+  }
+
+  // ============================================================== matrix waves
+  const int wr_ = wave / CW, wc = wave % CW;
+  const int lr = lane & 15, lg = lane >> 4;
+  for (int it = 0; it < g.assign_per; ++it) {
+    const int tile = __builtin_amdgcn_readfirstlane(*(gci)(mine + it));
+    if (tile < 0) break;
+    const int q = tile_word(tile, 0), mt = tile_word(tile, 1), nt = tile_word(tile, 2);
+    const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
+    const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int nblk = Cin / 32, NB = nblk * k;
+    const int ct0 = n0 / 16 + wc * NCW;
+    const long long ct_stride = (long long)NB * 1536;            // elements per column tile
+    const u16* wl = CL_SEL(q, wl) + (long long)ct0 * ct_stride + lane * 8;
+    // this lane's row of each of the wave's row tiles: window row of tap 0
+    int abase[NRW];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) {
+      const int row = (wr_ * NRW + r) * 16 + lr, s = row / Tt, tl = row - s * Tt;
+      abase[r] = (s * wrs + tl) * CL_LDB + 8 * lg;
+    }
+    f32x4 acc[NRW][NCW];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r)
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bw[2][NCW][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bw[s][c][p] = cl_gload(wl + (s < NB ? s : 0) * 1536 + c * ct_stride + p * 512);
+    f32x4 af[NRW][3];
+    int j = 0;                                                   // tap of block gb
+    const u16* buf = lds;
+    const int dstep = dil * CL_LDB;
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+    auto step = [&](const int gb, auto slot_c) __attribute__((always_inline)) {
+      constexpr int SL = decltype(slot_c)::value;
+      if (j == 0) {                                              // first tap of a channel block: its window slice
+        bar();
+        buf = lds + (gslice & 1) * 3 * plane;
+        ++gslice;
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) af[r][p] = *reinterpret_cast<const f32x4*>(buf + p * plane + abase[r]);
+      }
+      const bool more = j + 1 < k;                               // the next tap reads the same slice, dil rows further
+      const u16* anext = buf + (more ? (j + 1) * dstep : 0);
+#pragma unroll
+      for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+#pragma unroll
+          for (int c = 0; c < NCW; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[SL][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]), acc[r][c], 0, 0, 0);
+          if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + abase[r]);
+          if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + abase[r]);
+          if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + abase[r]);
+        }
+      const int gn = gb + 2 < NB ? gb + 2 : 0;                   // (past the last block: block 0 again, unused)
+#pragma unroll
+      for (int c = 0; c < NCW; ++c)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bw[SL][c][p] = cl_gload(wl + (long long)gn * 1536 + c * ct_stride + p * 512);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        if (s == 0 || s == 3 || s == 5) {
+#pragma unroll
+          for (int r = 0; r < NRW; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NCW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NRW * NCW, 0);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCW, 0);
+      j = more ? j + 1 : 0;
+    };
+    int gb = 0;
+    for (; gb + 1 < NB; gb += 2) {
+      step(gb, std::integral_constant<int, 0>{});
+      step(gb + 1, std::integral_constant<int, 1>{});
+    }
+    if (gb < NB) step(gb, std::integral_constant<int, 0>{});
+    // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
+    {
+      const float* bias = CL_SEL(q, bias);
+      const int oact = CL_SEL(q, out_act);
+      const float oslope = CL_SEL(q, out_slope);
+      const int shuf = CL_SEL(q, shuffle_r), Cout = CL_SEL(q, Cout), Cq = Cout / shuf;
+      const bool yring = CL_SEL(q, y.mode) == 0;
+      float* yb = CL_SEL(q, y.base);
+      const int yC = CL_SEL(q, y.C), ymask = yring ? CL_SEL(q, y.lmask) : -1, yrate = CL_SEL(q, y.rate), yoff = CL_SEL(q, y.off);
+      const long long yss = CL_SEL(q, y.slot_stride);
+      const bool hres = CL_SEL(q, has_res) != 0;
+      const bool rring = CL_SEL(q, res.mode) == 0;
+      const float* rb = CL_SEL(q, res.base);
+      const int rC = CL_SEL(q, res.C), rmask = rring ? CL_SEL(q, res.lmask) : -1, rrate = CL_SEL(q, res.rate), roffs = CL_SEL(q, res.off);
+      const long long rss = CL_SEL(q, res.slot_stride);
+      float* y2b = CL_SEL(q, y2_base);
+      const float y2s = CL_SEL(q, y2_slope);
+      const int* slots = CL_SEL(q, slots);
+      const int* pos = CL_SEL(q, pos);
+#pragma unroll
+      for (int r = 0; r < NRW; ++r) {
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
+        const int slot = slots ? *(gci)(slots + i) : i, pv = pos ? *(gci)(pos + slot) : 0;
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) {
+          const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
+          if (cc < Cout) {
+            const f32x4 bq = bias ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 o = acc[r][c] + bq;
+            if (oact == ACT_LRELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * oslope;
+            }
+            if (hres) {
+              const int rrow = ((rring ? pv * rrate : 0) + roffs + t) & rmask;
+              o += cl_gload(rb + (long long)(rring ? slot : i) * rss + (long long)rrow * rC + cc);
+            }
+            int jj = 0, oc = cc;
+            if (shuf > 1) { jj = cc / Cq; oc = cc - jj * Cq; }
+            const int yrow = ((yring ? pv * yrate : 0) + yoff + t * shuf + jj) & ymask;
+            const long long yo = (long long)(yring ? slot : i) * yss + (long long)yrow * yC + oc;
+            cl_gstore(yb + yo, o);
+            if (y2b) {
+              f32x4 o2;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o2[e] = o[e] > 0.f ? o[e] : o[e] * y2s;
+              cl_gstore(y2b + yo, o2);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+namespace {
+
+struct CLShape { int NRW, NCW, RW, CW; };
+// tile shapes: 160 x 64 (ups.2 / ups.3: 256 tiles at 64 streams), 64 x 80 (ups.1: 256 tiles), 64 x 64 (the C = 256 ResBlock convs),
+// 32 x 64 / 64 x 32 for small launches
+const CLShape kShapes[] = {{5, 2, 2, 2}, {1, 5, 4, 1}, {2, 2, 2, 2}, {1, 2, 2, 2}};
+
+template <int NRW, int NCW, int RW, int CW>
+void launch_cl(const ConvLimbGroup& g, int grid, size_t lds_bytes, hipStream_t st) {
+  static std::atomic<unsigned long long> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)conv_limb_kernel<NRW, NCW, RW, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_devs.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((conv_limb_kernel<NRW, NCW, RW, CW>), dim3(grid), dim3(512), lds_bytes, st, g);
+}
+
+bool shape_fits(const CLShape& s, const ConvArgs& a) {
+  const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
+  const long long M = (long long)a.n * a.T;
+  if (M % TM) return false;
+  if (a.T < TM ? (TM % a.T) != 0 : (a.T % TM) != 0) return false;
+  const int cols = ((a.Cout + 15) / 16) * 16;
+  return cols % TN == 0;
+}
+
+}  // namespace
+
+// the arguments this kernel covers (the rest of ConvArgs stays with conv_mfma)
+bool conv_limb_supported(const ConvArgs& a) {
+  if (!a.wl || a.x.mode != 0 || a.Cin % 32 || a.Cout % 4 || a.has_m1 || a.has_m2 || a.bvec || a.lens || a.out_scale != 1.f) return false;
+  if (a.in_act != ACT_NONE && a.in_act != ACT_LRELU) return false;
+  if (a.out_act != ACT_NONE && a.out_act != ACT_LRELU) return false;
+  if (a.shuffle_r > 1 && ((a.Cout / a.shuffle_r) % 4 || a.Cout % a.shuffle_r)) return false;
+  if (a.x.C % 4 || a.y.C % 4 || (a.has_res && a.res.C % 4)) return false;
+  return true;
+}
+
+// tile shape index for a group of problems (same n, T and column count), or -1
+int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu) {
+  int best = -1; double best_cost = 1e30;
+  for (int si = 0; si < (int)(sizeof(kShapes) / sizeof(kShapes[0])); ++si) {
+    const CLShape& s = kShapes[si];
+    bool ok = true;
+    double units = 0, umax = 0;
+    long long tiles = 0;
+    for (int q = 0; q < nprob; ++q) {
+      ok = ok && shape_fits(s, p[q]);
+      if (!ok) break;
+      const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
+      const int Tt = std::min(p[q].T, TM), wr = (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil);
+      if (wr > 32 * CL_NIT || (size_t)2 * 3 * wr * CL_LDB * 2 > 126 * 1024) { ok = false; break; }
+      const long long t = ((long long)p[q].n * p[q].T / TM) * ((((p[q].Cout + 15) / 16) * 16) / TN);
+      const double u = (double)p[q].ktaps * p[q].Cin * TM * TN;
+      tiles += t; units += u * t; umax = std::max(umax, u);
+    }
+    if (!ok || tiles == 0) continue;
+    // makespan estimate: work per CU, at least one largest tile; small tiles re-read more weights
+    const double per_cu = std::max(units / std::max(1, num_cu), umax);
+    const double rounds = std::ceil((double)tiles / num_cu);
+    const double cost = std::max(per_cu, rounds * umax * (nprob == 1 ? 1.0 : 0.0)) * (1.0 + 24.0 / (16 * s.NRW * s.RW));
+    if (cost < best_cost) { best_cost = cost; best = si; }
+  }
+  return best;
+}
+
+size_t conv_limb_lds_bytes(const ConvArgs* p, int nprob, int shape, int* wr_max_out) {
+  const CLShape& s = kShapes[shape];
+  const int TM = 16 * s.NRW * s.RW;
+  int wr_max = 0;
+  for (int q = 0; q < nprob; ++q) {
+    const int Tt = std::min(p[q].T, TM);
+    wr_max = std::max(wr_max, (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil));
+  }
+  // (+ one row: the prefetch behind the last tap of a slice reads the plane's first row again, in bounds by construction)
+  *wr_max_out = wr_max;
+  return (size_t)2 * 3 * wr_max * CL_LDB * 2;
+}
+
+// Balanced tile lists per launch shape, cached in device memory (a handful per model and device, never freed).
+static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) {
+  struct Key { int v[16]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
+  struct Val { const int* tiles; const int* assign; int per, grid; };
+  static std::map<Key, Val> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Key key; memset(&key, 0, sizeof(key));
+  key.v[0] = shape; key.v[1] = num_cu; key.v[2] = dev; key.v[3] = g.nprob;
+  for (int q = 0; q < g.nprob; ++q) { key.v[4 + 4 * q] = g.p[q].n; key.v[5 + 4 * q] = g.p[q].T; key.v[6 + 4 * q] = g.p[q].Cout; key.v[7 + 4 * q] = g.p[q].ktaps * 4096 + g.p[q].Cin; }
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    const CLShape& s = kShapes[shape];
+    const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
+    struct Tl { int q, mt, nt; double cost; };
+    std::vector<Tl> tl;
+    for (int q = 0; q < g.nprob; ++q) {
+      const int mts = (int)((long long)g.p[q].n * g.p[q].T / TM), nts = (((g.p[q].Cout + 15) / 16) * 16) / TN;
+      // n-tile outermost: workgroups that run at the same time then share their weight columns' rows ... the m tiles of one
+      // n tile are adjacent in the list
+      for (int nt = 0; nt < nts; ++nt)
+        for (int mt = 0; mt < mts; ++mt) tl.push_back({q, mt, nt, (double)g.p[q].ktaps * g.p[q].Cin});
+    }
+    std::stable_sort(tl.begin(), tl.end(), [](const Tl& a, const Tl& b) { return a.cost > b.cost; });
+    const int grid = (int)std::min<size_t>(tl.size(), (size_t)num_cu);
+    std::vector<std::vector<int>> per(grid);
+    std::vector<double> load(grid, 0.0);
+    for (size_t e = 0; e < tl.size(); ++e) {      // longest first onto the least loaded block
+      int b = 0;
+      for (int c = 1; c < grid; ++c) if (load[c] < load[b]) b = c;
+      per[b].push_back((int)e); load[b] += tl[e].cost;
+    }
+    size_t mx = 0;
+    for (auto& v : per) mx = std::max(mx, v.size());
+    const int ap = (int)mx + 1;
+    std::vector<int> flat(tl.size() * 4), asg((size_t)grid * ap, -1);
+    for (size_t e = 0; e < tl.size(); ++e) { flat[e * 4] = tl[e].q; flat[e * 4 + 1] = tl[e].mt; flat[e * 4 + 2] = tl[e].nt; flat[e * 4 + 3] = 0; }
+    for (int b = 0; b < grid; ++b) for (size_t i2 = 0; i2 < per[b].size(); ++i2) asg[(size_t)b * ap + i2] = per[b][i2];
+    int *dt = nullptr, *da = nullptr;
+    if (hipMalloc(&dt, flat.size() * sizeof(int)) != hipSuccess || hipMalloc(&da, asg.size() * sizeof(int)) != hipSuccess) return false;
+    (void)hipMemcpy(dt, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMemcpy(da, asg.data(), asg.size() * sizeof(int), hipMemcpyHostToDevice);
+    it = cache.emplace(key, Val{dt, da, ap, grid}).first;
+  }
+  g.tiles = it->second.tiles; g.assign = it->second.assign; g.assign_per = it->second.per;
+  *grid_out = it->second.grid;
+  return true;
+}
+
+bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream_t st) {
+  ConvLimbGroup g = gin;
+  if (shape < 0 || shape >= (int)(sizeof(kShapes) / sizeof(kShapes[0])) || g.nprob < 1 || g.nprob > 3) return false;
+  const size_t lds = conv_limb_lds_bytes(g.p, g.nprob, shape, &g.wr_max);
+  int grid = 0;
+  if (!cl_schedule(g, shape, num_cu, &grid) || grid <= 0) return false;
+  switch (shape) {
+    case 0: launch_cl<5, 2, 2, 2>(g, grid, lds, st); break;
+    case 1: launch_cl<1, 5, 4, 1>(g, grid, lds, st); break;
+    case 2: launch_cl<2, 2, 2, 2>(g, grid, lds, st); break;
+    case 3: launch_cl<1, 2, 2, 2>(g, grid, lds, st); break;
+    default: return false;
+  }
+  return true;
+}
+
+const char* conv_limb_name(int shape) {
+  static const char* names[] = {"cnk::conv_limb_kernel<5, 2, 2, 2>", "cnk::conv_limb_kernel<1, 5, 4, 1>", "cnk::conv_limb_kernel<2, 2, 2, 2>", "cnk::conv_limb_kernel<1, 2, 2, 2>"};
+  return shape >= 0 && shape < 4 ? names[shape] : "cnk::conv_limb_kernel<?>";
+}
+
+}  // namespace cnk

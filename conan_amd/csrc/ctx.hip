@@ -80,6 +80,34 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
   }
   pc.w = upload(P);
   pc.bias = upload(B);
+  // bf16 limbs of the same (column-permuted) weights for conv_limb.hip: the vocoder's upsamplers and ResBlock convs
+  if (name.rfind("voc.ups.", 0) == 0 || name.rfind("voc.rb.", 0) == 0) {
+    if (Cin % 32 == 0) {
+      auto rne = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); };
+      auto val = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+      const int NCT = ch::round_up(Cout, 16) / 16, NCB = Cin / 32;
+      std::vector<uint16_t> lim((size_t)NCT * NCB * k * 3 * 512 + 4096, 0);
+      for (int co = 0; co < Cout; ++co) {
+        int col = co;
+        if (shuffle_r > 1) { int c = co / shuffle_r, j = co % shuffle_r; col = j * Cq + c; }
+        const int ct = col / 16, ln = col % 16;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const int cb = ci / 32, lane = ln + 16 * ((ci % 32) / 8), e = ci % 8;
+          for (int j = 0; j < k; ++j) {
+            const float w = W[((size_t)co * Cin + ci) * k + j];
+            const uint16_t h = rne(w); const float r1 = w - val(h);
+            const uint16_t m = rne(r1); const float r2 = r1 - val(m);
+            const uint16_t l = rne(r2);
+            const size_t base = ((((size_t)ct * NCB + cb) * k + j) * 3) * 512 + (size_t)lane * 8 + e;
+            lim[base] = h; lim[base + 512] = m; lim[base + 1024] = l;
+          }
+        }
+      }
+      std::vector<float> bits(lim.size() / 2);
+      memcpy(bits.data(), lim.data(), bits.size() * 4);
+      pc.wl = upload(bits);
+    }
+  }
   convs[name] = pc;
 }
 

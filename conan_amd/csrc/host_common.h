@@ -37,6 +37,7 @@ struct PackedConv {
   float* bias = nullptr;   // [Cout_pad] (zeros when the layer has no bias)
   int Cin = 0, Cin_pad = 0, Cin_alloc = 0, Cout = 0, Cout_pad = 0, k = 1;
   int shuffle_r = 1;
+  float* wl = nullptr;     // bf16 limbs for conv_limb.hip (vocoder upsamplers / wide ResBlock convs; bits behind a float pointer)
   float* wf = nullptr;     // fragment-major copy for rowconv.hip (decoder-step layers only), Cout padded to wf_cout_pad
   int wf_cout_pad = 0;
 };

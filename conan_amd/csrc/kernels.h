@@ -54,6 +54,9 @@ struct ConvArgs {
   // base differs).  The consumer then reads pre-activated rows and its K loop needs no input transform.
   float* y2_base;
   float y2_slope;
+  // the weights as bf16 limbs for conv_limb.hip (null: not packed): [Cout_pad16/16 column tiles][Cin/32 channel blocks][ktaps]
+  // [3 limbs][64 lanes][8], lane = (packed column ct*16 + (lane & 15), channels cb*32 + 8*(lane >> 4) + e)
+  const unsigned short* wl;
 #ifdef CK_STAMPS
   unsigned long long* dbg;   // developer build only (tools/conv_bench -DCK_STAMPS): s_memtime stamps of block 1
 #endif
@@ -92,6 +95,21 @@ const char* conv_cfg_name(int cfg);  // the kernel's name as rocprofv3 prints it
 int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);
 void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num_cu = 256);
+
+// The same convolution with every fp32 product as six bf16 limb products on the bf16 MFMA (conv_limb.hip); covers the
+// subset of ConvArgs that conv_limb_supported() accepts.
+struct ConvLimbGroup {
+  ConvArgs p[3];        // problems with the same n, T and column count (different taps / dilations / tensors)
+  int nprob;
+  const int* tiles;     // filled by launch_conv_limb: [ntiles] {problem, m tile, n tile, 0}
+  const int* assign;    // [grid][assign_per] tile indices per block, -1 terminated
+  int assign_per;
+  int wr_max;           // window rows of the largest problem's tile
+};
+bool conv_limb_supported(const ConvArgs& a);
+int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu);      // tile shape for these problems, -1: none fits
+bool launch_conv_limb(const ConvLimbGroup& g, int shape, int num_cu, hipStream_t st);
+const char* conv_limb_name(int shape);
 
 // One ResBlock1 unit (hifigan_causal.py:230-238) as ONE tile pass (resblock_fused.hip):
 //   y = c2(leaky_relu(c1(leaky_relu(x)))) + x,  c1: k taps, dilation dil;  c2: k taps, dilation 1, both causal.

@@ -14,6 +14,7 @@ ConvArgs conan_streams::mk(const PackedConv& pc, const TRef& x, const TRef& y, i
   a.ktaps = pc.k; a.dil = dil; a.pad_left = pad_left < 0 ? (pc.k - 1) * dil : pad_left;
   a.T = T; a.n = n; a.in_act = cnk::ACT_NONE; a.in_slope = 0.f; a.out_act = cnk::ACT_NONE; a.out_scale = 1.f; a.out_slope = 0.f;
   a.shuffle_r = pc.shuffle_r;
+  a.wl = reinterpret_cast<const unsigned short*>(pc.wl);
   if (x.C != pc.Cin && !(x.C > pc.Cin)) throw Error(CONAN_ERR_SHAPE, "conv input width mismatch");
   return a;
 }
@@ -49,6 +50,24 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
 
 void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipStream_t st) {
   if (mega_rec) { mega_rec_ok = false; return; }      // (a conv_mfma layer is not a megakernel operator: that step keeps its separate launches)
+  // the bf16-limb form (conv_limb.hip) where the weights were packed for it and a tile shape fits all problems of the group
+  if (rb_limb && nprob >= 1 && nprob <= 3) {
+    bool ok = true;
+    for (int p = 0; p < nprob; ++p) ok = ok && cnk::conv_limb_supported(gin.p[p]) && gin.p[p].n == gin.p[0].n && gin.p[p].T == gin.p[0].T && gin.p[p].Cout == gin.p[0].Cout;
+    const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
+    const int shape = ok ? cnk::conv_limb_shape(gin.p, nprob, cus) : -1;
+    if (shape >= 0) {
+      cnk::ConvLimbGroup lg; memset(&lg, 0, sizeof(lg));
+      for (int p = 0; p < nprob; ++p) lg.p[p] = gin.p[p];
+      lg.nprob = nprob;
+      double fl = 0.0;
+      for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)lg.p[p].n * lg.p[p].T * lg.p[p].Cout * lg.p[p].ktaps * lg.p[p].Cin;
+      profiled(cnk::conv_limb_name(shape), fl, st, [&] {
+        if (!cnk::launch_conv_limb(lg, shape, cus, st)) throw Error(CONAN_ERR_HIP, "conv_limb launch failed");
+      });
+      return;
+    }
+  }
   ConvGroup g = gin;
   for (int p = 0; p < nprob; ++p) {
     // layers that touch no per-slot ring need neither the slot table nor the position counters: dropping them
