@@ -105,11 +105,15 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         }
       }
       const int nblk = Cin / 32;
+      // Software-pipelined: the loads of slice cb + 1 are issued BEFORE the barrier that publishes slice cb and land while the
+      // matrix waves compute; behind the barrier the helper only converts and stores registers.  (Loading, converting and
+      // storing a slice between two barriers put a global round trip - 2 us - on every channel block: 3-tap tiles ran as
+      // long as 11-tap ones.)
+      f32x4 v[CL_NIT];
+#pragma unroll
+      for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u]);
       for (int cb = 0; cb < nblk; ++cb) {
         u16* dstb = lds + (gslice & 1) * 3 * plane;
-        f32x4 v[CL_NIT];
-#pragma unroll
-        for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + cb * 32);
 #pragma unroll
         for (int u = 0; u < CL_NIT; ++u) {
           if (roff[u] >= 0) {
@@ -125,6 +129,10 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
             *reinterpret_cast<uint2*>(d + plane) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
             *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
           }
+        }
+        if (cb + 1 < nblk) {
+#pragma unroll
+          for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + (cb + 1) * 32);
         }
         bar();                                                   // slice staged (and the matrix waves are done with the other buffer)
         ++gslice;
@@ -159,9 +167,12 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     for (int r = 0; r < NRW; ++r)
 #pragma unroll
       for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 bw[2][NCW][3];
+    // weight blocks in flight: four with one column tile per wave (a block is 6 * NRW MFMAs = 0.2 us of work there - two blocks
+    // ahead is less than an L2 round trip under load), two with two
+    constexpr int RING = NCW == 1 ? 4 : 2;
+    f32x4 bw[RING][NCW][3];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < RING; ++s)
 #pragma unroll
       for (int c = 0; c < NCW; ++c)
 #pragma unroll
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
           if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + abase[r]);
           if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + abase[r]);
         }
-      const int gn = gb + 2 < NB ? gb + 2 : 0;                   // (past the last block: block 0 again, unused)
+      const int gn = gb + RING < NB ? gb + RING : 0;             // (past the last block: block 0 again, unused)
 #pragma unroll
       for (int c = 0; c < NCW; ++c)
 #pragma unroll
@@ -216,11 +227,19 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       j = more ? j + 1 : 0;
     };
     int gb = 0;
-    for (; gb + 1 < NB; gb += 2) {
+    for (; gb + RING <= NB; gb += RING) {
       step(gb, std::integral_constant<int, 0>{});
       step(gb + 1, std::integral_constant<int, 1>{});
+      if constexpr (RING == 4) {
+        step(gb + 2, std::integral_constant<int, 2>{});
+        step(gb + 3, std::integral_constant<int, 3>{});
+      }
     }
     if (gb < NB) step(gb, std::integral_constant<int, 0>{});
+    if constexpr (RING == 4) {
+      if (gb + 1 < NB) step(gb + 1, std::integral_constant<int, 1>{});
+      if (gb + 2 < NB) step(gb + 2, std::integral_constant<int, 2>{});
+    }
     // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
     {
       const float* bias = CL_SEL(q, bias);
@@ -281,9 +300,22 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 namespace {
 
 struct CLShape { int NRW, NCW, RW, CW; };
-// tile shapes: 160 x 64 (ups.2 / ups.3: 256 tiles at 64 streams), 64 x 80 (ups.1: 256 tiles), 64 x 64 (the C = 256 ResBlock convs),
-// 32 x 64 / 64 x 32 for small launches
-const CLShape kShapes[] = {{5, 2, 2, 2}, {1, 5, 4, 1}, {2, 2, 2, 2}, {1, 2, 2, 2}};
+// Tile shapes.  The weights come through the CU's vector memory path (64 bytes per clock) from L2: per 32-channel block a
+// TM x TN tile needs 6 * TN * 32 bytes of them against 1.5 * TM * TN / 16 clocks of MFMA per SIMD - MFMA time / load time = TM / 32
+// with every weight loaded once per workgroup, and chip-wide the L2 has to deliver tiles * K * TN * 6 bytes.  So: tall tiles,
+// and the four matrix waves on DISJOINT column tiles (CW = 4; the A fragments, which every wave then reads, come from LDS).
+// What this kernel is used for follows from that (measured at 64 streams, rocprofv3 kernel times):
+//   * ups.2 / ups.3 (160 / 640 rows per slot, 80- and 160-row tiles): 33 us each against 57 / 28 us of conv_mfma's f32 passes;
+//   * ups.1 (32 rows per slot, 2048 x 640 outputs) only tiles into 320 tiles of 64 x 64 - two rounds, 78 us against 72 - or
+//     into 64 x 80 tiles with all four waves on the same five column tiles (4x the loads, 62 us): it stays with conv_mfma,
+//     whose split-K tail evens out the 1.25 tiles per CU;
+//   * ups.0 (4 rows per slot; K = 8192, 100 MB of limb weights) and the C = 256 ResBlock convs (32 rows per slot; 64-row
+//     tiles because a 4-slot window of the dilation-5 conv does not fit in LDS twice) are bound by the L2 -> CU weight
+//     traffic at M <= 64: 118 us against conv_mfma's 84, and 6 x 48 us against resblock_pair's 3 x 98.  They keep the f32
+//     kernels (CONAN_RB_NOPAIR=1 runs the ResBlock convs through this kernel: the group path and its tile balancing are tested
+//     that way).
+const CLShape kShapes[] = {{4, 1, 1, 4}, {5, 1, 1, 4}, {5, 2, 2, 2}};
+constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
 template <int NRW, int NCW, int RW, int CW>
 void launch_cl(const ConvLimbGroup& g, int grid, size_t lds_bytes, hipStream_t st) {
@@ -319,29 +351,35 @@ bool conv_limb_supported(const ConvArgs& a) {
   return true;
 }
 
-// tile shape index for a group of problems (same n, T and column count), or -1
+// tile shape index for a group of problems (same n, T and column count), or -1: the shape with the smallest estimated
+// makespan among those that fit and give every CU a tile
 int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu) {
+  static const int forced = (getenv("CONAN_CL_SHAPE") && *getenv("CONAN_CL_SHAPE")) ? atoi(getenv("CONAN_CL_SHAPE")) : -1;      // developer switch
   int best = -1; double best_cost = 1e30;
-  for (int si = 0; si < (int)(sizeof(kShapes) / sizeof(kShapes[0])); ++si) {
+  for (int si = 0; si < kNumShapes; ++si) {
     const CLShape& s = kShapes[si];
+    const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
     bool ok = true;
     double units = 0, umax = 0;
     long long tiles = 0;
-    for (int q = 0; q < nprob; ++q) {
-      ok = ok && shape_fits(s, p[q]);
+    for (int q = 0; q < nprob && ok; ++q) {
+      ok = shape_fits(s, p[q]);
       if (!ok) break;
-      const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
       const int Tt = std::min(p[q].T, TM), wr = (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil);
       if (wr > 32 * CL_NIT || (size_t)2 * 3 * wr * CL_LDB * 2 > 126 * 1024) { ok = false; break; }
       const long long t = ((long long)p[q].n * p[q].T / TM) * ((((p[q].Cout + 15) / 16) * 16) / TN);
       const double u = (double)p[q].ktaps * p[q].Cin * TM * TN;
       tiles += t; units += u * t; umax = std::max(umax, u);
     }
-    if (!ok || tiles == 0) continue;
-    // makespan estimate: work per CU, at least one largest tile; small tiles re-read more weights
-    const double per_cu = std::max(units / std::max(1, num_cu), umax);
+    if (!ok || tiles < num_cu) continue;
+    // (a single problem in 64-row tiles - ups.1: 320 tiles, two rounds - measured slower than conv_mfma's f32 pass with its
+    // split-K tail, 78 against 72 us; groups of problems are list-scheduled and take them)
+    if (nprob == 1 && TM < 80 && forced < 0) continue;
+    if (forced >= 0) { if (si == forced) return si; continue; }
+    // equal tiles run in rounds; tiles of several costs are list-scheduled (at least the largest one, at least the average)
     const double rounds = std::ceil((double)tiles / num_cu);
-    const double cost = std::max(per_cu, rounds * umax * (nprob == 1 ? 1.0 : 0.0)) * (1.0 + 24.0 / (16 * s.NRW * s.RW));
+    const double makespan = nprob == 1 ? rounds * umax : std::max(units / num_cu, umax);
+    const double cost = makespan * (s.CW == 4 ? 1.0 : 1.05);     // shared column tiles: redundant weight loads
     if (cost < best_cost) { best_cost = cost; best = si; }
   }
   return best;
@@ -389,9 +427,17 @@ static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) 
     const int grid = (int)std::min<size_t>(tl.size(), (size_t)num_cu);
     std::vector<std::vector<int>> per(grid);
     std::vector<double> load(grid, 0.0);
-    for (size_t e = 0; e < tl.size(); ++e) {      // longest first onto the least loaded block
-      int b = 0;
-      for (int c = 1; c < grid; ++c) if (load[c] < load[b]) b = c;
+    // Longest first onto the least loaded block - among the blocks of ONE XCD (workgroups are dealt to the 8 XCDs round-robin:
+    // block b runs on XCD b % 8): the tiles of an n tile, which stream the same weight columns, then share one L2 instead
+    // of pulling those columns into all eight.  With fewer than 8 n tiles an n tile's m tiles are spread over 8 / nts XCDs.
+    for (size_t e = 0; e < tl.size(); ++e) {
+      const int nts = (((g.p[tl[e].q].Cout + 15) / 16) * 16) / TN;
+      int x = tl[e].nt % 8;
+      if (nts < 8) { const int share = 8 / nts; x = (tl[e].nt + nts * (tl[e].mt % share)) % 8; }
+      if (grid < 8) x = 0;
+      int b = -1;
+      for (int c = x; c < grid; c += (grid < 8 ? 1 : 8)) if (b < 0 || load[c] < load[b]) b = c;
+      if (b < 0) b = 0;
       per[b].push_back((int)e); load[b] += tl[e].cost;
     }
     size_t mx = 0;
@@ -413,23 +459,22 @@ static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) 
 
 bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream_t st) {
   ConvLimbGroup g = gin;
-  if (shape < 0 || shape >= (int)(sizeof(kShapes) / sizeof(kShapes[0])) || g.nprob < 1 || g.nprob > 3) return false;
+  if (shape < 0 || shape >= kNumShapes || g.nprob < 1 || g.nprob > 3) return false;
   const size_t lds = conv_limb_lds_bytes(g.p, g.nprob, shape, &g.wr_max);
   int grid = 0;
   if (!cl_schedule(g, shape, num_cu, &grid) || grid <= 0) return false;
   switch (shape) {
-    case 0: launch_cl<5, 2, 2, 2>(g, grid, lds, st); break;
-    case 1: launch_cl<1, 5, 4, 1>(g, grid, lds, st); break;
-    case 2: launch_cl<2, 2, 2, 2>(g, grid, lds, st); break;
-    case 3: launch_cl<1, 2, 2, 2>(g, grid, lds, st); break;
+    case 0: launch_cl<4, 1, 1, 4>(g, grid, lds, st); break;
+    case 1: launch_cl<5, 1, 1, 4>(g, grid, lds, st); break;
+    case 2: launch_cl<5, 2, 2, 2>(g, grid, lds, st); break;
     default: return false;
   }
   return true;
 }
 
 const char* conv_limb_name(int shape) {
-  static const char* names[] = {"cnk::conv_limb_kernel<5, 2, 2, 2>", "cnk::conv_limb_kernel<1, 5, 4, 1>", "cnk::conv_limb_kernel<2, 2, 2, 2>", "cnk::conv_limb_kernel<1, 2, 2, 2>"};
-  return shape >= 0 && shape < 4 ? names[shape] : "cnk::conv_limb_kernel<?>";
+  static const char* names[] = {"cnk::conv_limb_kernel<4, 1, 1, 4>", "cnk::conv_limb_kernel<5, 1, 1, 4>", "cnk::conv_limb_kernel<5, 2, 2, 2>"};
+  return shape >= 0 && shape < kNumShapes ? names[shape] : "cnk::conv_limb_kernel<?>";
 }
 
 }  // namespace cnk

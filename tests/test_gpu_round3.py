@@ -251,3 +251,64 @@ def test_decoder_widths_come_from_the_checkpoint(streams):
         ctx2.finalize()
     assert ei.value.code == _lib.ERR_SHAPE
     ctx2.close()
+
+
+def _two_stream_sets(ctx, S, env):
+    """A default stream-set and one created with the environment switches in `env` (they are read at creation)."""
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k in env:
+            os.environ.pop(k, None)
+        a = ctx.streams(S, max_frames=4, max_ref_frames=16)
+        os.environ.update(env)
+        b = ctx.streams(S, max_frames=4, max_ref_frames=16)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return a, b
+
+
+def _kernel_names(st, ids, mel):
+    st.profile_begin()
+    st.hifigan_step(ids, mel)
+    st.profile_end()
+    return {r[0]: r[3] for r in st.profile_kernels()}       # kernel name -> launches
+
+
+@pytest.mark.parametrize("env,limb_expected", [({"CONAN_RB_NOLIMB": "1"}, False), ({"CONAN_RB_NOPAIR": "1"}, True)])
+def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, limb_expected):
+    """resblock_limb.hip / conv_limb.hip form every fp32 product from three bf16 limbs per operand (six bf16 MFMA products,
+    accumulated in fp32).  64 streams through a default stream-set (limb kernels in the C = 128 / 64 / 32 ResBlock stages and
+    in ups.2 / ups.3) and through one created with CONAN_RB_NOLIMB=1 (exact-f32 MFMA everywhere): per-stage tensors,
+    pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch cross-check uses.  Second case:
+    CONAN_RB_NOPAIR=1 routes the first stage's ResBlock convs through conv_limb's grouped launches (three problems of 3 / 7 / 11
+    taps per launch, list-scheduled tiles) instead of resblock_pair."""
+    vhp = configs.hifigan_hparams()
+    ctx = _voc_ctx(vhp)
+    S = 64
+    a, b = _two_stream_sets(ctx, S, env)
+    ids = list(range(S))
+    mel = torch.from_numpy(synth.mel(16, 9, S)).cuda()
+    for st in (a, b):
+        st.reset(ids)
+    for i in range(0, 16, 4):
+        wa, pa, ca, ua = a.hifigan_step_taps(ids, mel[:, i:i + 4].contiguous())
+        wb, pb, cb, ub = b.hifigan_step_taps(ids, mel[:, i:i + 4].contiguous())
+        for x, y in zip(ua, ub):
+            s = max(1.0, float(y.abs().max()))
+            assert float((x - y).abs().max()) <= 2e-5 * s
+        assert float((pa - pb).abs().max()) <= 2e-5 * max(1.0, float(pb.abs().max()))
+        assert float((wa - wb).abs().max()) <= 2e-5
+    # the kernels that ran (a silent fall-back to the f32 kernels would pass the comparison above)
+    na, nb = _kernel_names(a, ids, mel[:, :4].contiguous()), _kernel_names(b, ids, mel[:, :4].contiguous())
+    assert any("resblock_limb_kernel<128" in k for k in na) and any("resblock_limb_kernel<64" in k for k in na) and any("resblock_limb_kernel<32" in k for k in na)
+    assert any("conv_limb_kernel" in k for k in na) and any("resblock_pair_kernel" in k for k in na)
+    if limb_expected:
+        # two upsamplers + 3 dilations x (c1, c2) grouped launches
+        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k) == 8 and not any("resblock_pair_kernel" in k for k in nb)
+    else:
+        assert not any("limb" in k for k in nb)
+    a.close(); b.close(); ctx.close()
