@@ -78,6 +78,13 @@ def test_co_residency_budgets(tmp_path):
         # (the merged builds' helper waves keep three scalars in scratch: the two-deep tile draw's state on top of the merge
         # state; read once per tile, outside the matrix waves' loops)
         assert f["spill"] == 0 and f["scratch"] <= (16 if key[2] else 0), (key, f)
+    # conv_limb.hip (dynamic LDS: two window slices of <= 384 rows x 96 bytes x 3 planes; 96 KB for the 160-row tiles of ups.2 /
+    # ups.3): the register budget is what the code object shows
+    convl = [v for k, v in ks.items() if "conv_limb_kernel" in k]
+    assert len(convl) >= 3
+    for f in convl:
+        assert f["spill"] == 0 and f["scratch"] == 0 and f["lds"] == 0, f
+        assert 2 * gran(f["vgpr"] + f["agpr"]) + 80 <= 512, f
     for key, f in list(fused.items()) + [("pair", pair)] + list(limb.items()):
         assert 2 * gran(f["vgpr"] + f["agpr"]) + 80 <= 512, (key, f)
         assert f["lds"] + mega_lds <= 160 * 1024, (key, f)

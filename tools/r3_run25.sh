@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp
+cd /root/repo
+for sk in 0 1 2 3; do
+CONAN_SKIP_STAGE=$sk python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-b1 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('skip $sk', d['ms_per_step'], d.get('p50_latency_ms'))"
+done
