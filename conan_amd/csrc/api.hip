@@ -398,6 +398,9 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     int* codes_seg = s->codes_hand[p];
     // developer timing switch (results are then meaningless): CONAN_SKIP_STAGE bit 0 skips the Emformer launch, bit 1 the decoder's
     static const int skip = getenv("CONAN_SKIP_STAGE") ? atoi(getenv("CONAN_SKIP_STAGE")) : 0;
+    // (the Emformer's workgroups need whole CUs for ~0.15 ms; they are kept away from the pair kernel's launches: see ev_wide)
+    static const bool hold = getenv("CONAN_EMF_NOHOLD") == nullptr;
+    if (hold && t >= 2 && s->ev_wide[(t + NP - 2) % NP] && s->wide_marked[(t + NP - 2) % NP]) HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_wide[(t + NP - 2) % NP], 0));
     if (tl) HIP_CHECK(hipEventRecord(te[0], s->st_emf));
     if (!(skip & 1)) s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_emf);
     if (tl) HIP_CHECK(hipEventRecord(te[1], s->st_emf));
@@ -427,7 +430,11 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
       s->fence_set = false;
     }
     if (tl) HIP_CHECK(hipEventRecord(te[4], s->st_voc));
+    if (!s->ev_wide[p]) HIP_CHECK(hipEventCreateWithFlags(&s->ev_wide[p], hipEventDisableTiming));
+    s->mark_wide = s->ev_wide[p];
+    s->wide_marked[p] = false;
     s->hifigan_step(n, emit, mel, wav_out_dev, nullptr, s->st_voc);
+    s->mark_wide = nullptr;
     if (tl) { HIP_CHECK(hipEventRecord(te[5], s->st_voc)); s->tl_n++; }
     HIP_CHECK(hipEventRecord(s->ev_voc[p], s->st_voc));
     if (s->clock_on && s->clock_n < (int)s->clock_ev.size()) HIP_CHECK(hipEventRecord(s->clock_ev[s->clock_n++], s->st_voc));   // step completion stamp

@@ -257,13 +257,11 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  auto tile_word = [&](int idx, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(a.tiles + (long long)idx * 4 + w)); };
   const int ntiles = a.ntiles;
   const float slope = a.slope;
   const int T = a.T;
   constexpr bool merge = MERGE;
   const int np = a.nprob;
-  const int first_tile = merge ? (int)blockIdx.x * np : (int)blockIdx.x;
 
   if (wave >= 4) {
     // ============================================================ helper waves: window loader + output writer
@@ -379,6 +377,12 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
         }
       }
     };
+    // EVERY tile is drawn from the queue, the first one too (issued here, its round trip hidden behind the table fill below): a
+    // block that is dispatched late - its CU held by another stream's kernel for 100-200 us: the Emformer's workgroups need whole
+    // CUs - then finds the queue empty and leaves, instead of starting a statically assigned first tile when everyone else is done
+    // (pipelined steps: the launches' maxima were 60-80 us above their means).
+    int dv0 = 0;
+    if (wave == 4 && lane == 0) dv0 = __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // {slot, pos} of every batch index, once: a drawn tile is then decoded without a global load behind the draw itself
     for (int e = ht; e < a.n; e += 256) {
       const int sl = a.slots ? *(gci)(a.slots + e) : e;
@@ -402,11 +406,19 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     // else: the decode is arithmetic + an LDS lookup) has that whole phase, so no barrier waits for it.  (One tile ahead, the
     // chain draw -> tile words -> slot -> pos -> window loads sat between B3 and B1 of every tile: 14-20 % of a block's life in
     // barrier waits at half the f32 pass's tile height.)
-    int cur = first_tile, p, i, t0;
-    decode(cur, p, i, t0);
-    if (ht == 0) meta[3] = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // helper waves only see each other's table entries behind a barrier:
-    // (block-wide s_barrier: the matrix waves take part - their B(-1), see below)
+    int cur = -1, p = -1, i = 0, t0 = 0;
+    if (wave == 4) {
+      cur = __builtin_amdgcn_readfirstlane(dv0) * (merge ? np : 1);
+      if (cur >= ntiles) cur = -1;
+      if (cur >= 0) decode(cur, p, i, t0);
+      if (lane == 0) { meta[1] = cur; meta[2] = p; meta[3] = 0; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B(-1), block-wide: the table and the first tile are published
+    if (wave != 4) {
+      cur = __builtin_amdgcn_readfirstlane(meta[1]);
+      if (cur >= 0) decode(cur, p, i, t0);
+    }
+    if (cur >= 0) {
     int slot = __builtin_amdgcn_readfirstlane(sptab[2 * i]), pos = __builtin_amdgcn_readfirstlane(sptab[2 * i + 1]);
     win_issue(p, i, t0, slot, pos);
     int gen = 1;                                         // generation of the published draw (meta[3])
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       int idx = -1;
       if (!have) return idx;
       if (wave == 4) {
-        const int drawn = ((int)gridDim.x + dv) * (merge ? np : 1);      // (merge: a drawn group's first tile)
+        const int drawn = dv * (merge ? np : 1);                         // (merge: a drawn group's first tile)
         idx = __builtin_amdgcn_readfirstlane(dnext >= 0 ? dnext : drawn);
         if (idx >= ntiles) idx = -1;
         if (lane == 0) {
@@ -483,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       nxt = nn;
     }
     if (pending) out_store();
+    }      // (cur >= 0)
     // the last block to leave re-arms the queue for the next launch
     if (ht == 0) {
       const int d = __hip_atomic_fetch_add(a.sched + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -510,12 +523,13 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 #define RL_GEMM(...) __VA_ARGS__
 #endif
   f32x4 bw[G::RING][G::NCW][3];
-  int p = tile_word(first_tile, 0);
+  bar();                                                 // B(-1): the helpers have drawn the block's first tile
+  int p = __builtin_amdgcn_readfirstlane(meta[2]);
+  if (p < 0) return;                                     // (dispatched after the queue ran empty)
   {
     const long long cs = (long long)(RL_SEL(p, k) + 1) * G::KB * G::BLK;
     rl_prefetch_w<G::NCW, G::RING>(bw, RL_SEL(p, w1l) + (long long)ct0 * cs + lane * 8, cs);
   }
-  bar();                                                 // (the helpers' {slot, pos} table is complete)
   bar();                                                 // B0
   while (p >= 0) {
     const int k = RL_SEL(p, k), d = RL_SEL(p, dil);
@@ -634,8 +648,7 @@ static bool launch_rl(const RBArgs& ain, int num_cu, hipStream_t st) {
   for (int p = 0; p < 3; ++p) a.order[p] = p;
   std::stable_sort(a.order, a.order + a.nprob, [&](int x, int y) { return a.p[x].k > a.p[y].k; });
   const int grid = std::min(a.merge ? total / a.nprob : total, num_cu);
-  a.tiles = resblock_tiles(a, ro, &a.ntiles);
-  if (!a.tiles) return false;
+  a.tiles = nullptr; a.ntiles = total;      // (tile index -> {branch, batch index, row} is arithmetic in this kernel: no list)
   hipLaunchKernelGGL((resblock_limb_kernel<C, NR2, SPAN, MERGE>), dim3(grid), dim3(512), 0, st, a);
   return true;
 }

@@ -144,6 +144,12 @@ struct conan_streams {
   }
   // --- pipelined stepping (conan_step_async): front-end (Emformer + decoder) and vocoder on two internal streams
   hipStream_t st_emf = nullptr, st_front = nullptr, st_voc = nullptr;
+  // pipelined steps: recorded on the vocoder stream behind the wide first stage's ResBlock launches (the pair kernel's
+  // workgroups wait for their partners: a CU that an Emformer workgroup holds stalls a whole pair) - the Emformer of step t is
+  // held back until the vocoder of step t-2 has passed that point (CONAN_EMF_NOHOLD=1: not)
+  hipEvent_t ev_wide[4] = {};
+  hipEvent_t mark_wide = nullptr;            // set around hifigan_step by conan_step_async
+  bool wide_marked[4] = {false, false, false, false};   // the step at this ring position recorded its ev_wide (it has a pair stage)
   static constexpr int NP = 4;                 // depth of the hand-off rings: a stage may run up to NP steps ahead of its consumer
   hipEvent_t ev_in[NP] = {}, ev_emf[NP] = {}, ev_front[NP] = {}, ev_voc[NP] = {};   // (one input event per ring position: a single
                                                // event re-recorded while its previous record is still pending stalls the pipeline)
@@ -168,7 +174,7 @@ struct conan_streams {
     if (st_front) (void)hipStreamDestroy(st_front);
     if (st_voc) (void)hipStreamDestroy(st_voc);
     for (int i = 0; i < NP; ++i) { if (ev_in[i]) (void)hipEventDestroy(ev_in[i]); if (ev_fence[i]) (void)hipEventDestroy(ev_fence[i]); }
-    for (int i = 0; i < NP; ++i) { if (ev_emf[i]) (void)hipEventDestroy(ev_emf[i]); if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
+    for (int i = 0; i < NP; ++i) { if (ev_wide[i]) (void)hipEventDestroy(ev_wide[i]); if (ev_emf[i]) (void)hipEventDestroy(ev_emf[i]); if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
     for (void* p : allocs) (void)hipFree(p);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : clock_ev) (void)hipEventDestroy(e);

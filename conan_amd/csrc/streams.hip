@@ -454,6 +454,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       }
       ra.slots = d_slots; ra.pos = pos; ra.nprob = NB; ra.n = n; ra.T = T; ra.slope = LR;
       launch_rp(ra, st);
+      if (d + 1 == ND && mark_wide) { HIP_CHECK(hipEventRecord(mark_wide, st)); for (int q = 0; q < 4; ++q) if (ev_wide[q] == mark_wide) wide_marked[q] = true; }
     }
     for (int d = 0; d < ND && s.fused && !s.pair; ++d) {   // ResBlock1 (hifigan_causal.py:230-238): c1 -> lrelu -> c2 -> + x in one tile pass per branch
       cnk::RBArgs ra; memset(&ra, 0, sizeof(ra));
