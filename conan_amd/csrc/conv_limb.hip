@@ -393,7 +393,6 @@ size_t conv_limb_lds_bytes(const ConvArgs* p, int nprob, int shape, int* wr_max_
     const int Tt = std::min(p[q].T, TM);
     wr_max = std::max(wr_max, (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil));
   }
-  // (+ one row: the prefetch behind the last tap of a slice reads the plane's first row again, in bounds by construction)
   *wr_max_out = wr_max;
   return (size_t)2 * 3 * wr_max * CL_LDB * 2;
 }

@@ -19,7 +19,13 @@
 //     x 16 bytes, streamed from L2 into registers as before, a ring of RING K blocks ahead;
 //   * c2's accumulators go to the helpers through an f32 image that overlays the xt planes (dead behind B4);
 //   * tiles are half as tall (6 bytes per element in LDS, and the block still has to share the CU with a decoder
-//     megakernel workgroup: tests/test_kernel_resources.py).
+//     megakernel workgroup: tests/test_kernel_resources.py);
+//   * the MFMAs are issued transposed (weights as the first operand): a lane's accumulator holds 4 consecutive channels of one
+//     row, so the epilogues store 8 / 16 bytes per LDS write;
+//   * the helpers do everything for the NEXT tile while the matrix waves are in c1, the tile draw runs up to two tiles ahead,
+//     every tile - the first one too - comes from the queue and is decoded arithmetically (no tile list, a {slot, pos} table
+//     in LDS): at half the tile height the per-tile fixed costs are what decides (16-22 % of a block's life in barrier
+//     waits before, 2-5 % now).
 #include <algorithm>
 #include <cstring>
 #include <type_traits>
