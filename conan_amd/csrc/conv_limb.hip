@@ -18,6 +18,7 @@
 // Launches are persistent over a host-balanced tile list (up to 3 problems of different tap counts per launch).
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -53,6 +54,10 @@ constexpr int CL_LDB = 48;          // bf16 elements per window row: 32 channels
 constexpr int CL_NIT = 12;          // float4 per helper thread and slice: windows of up to 384 rows
 
 }  // namespace
+
+#ifdef CL_STAMPS
+__device__ unsigned long long cl_dbg[256 * 4];      // developer build: per block {K-loop cycles, barrier-wait cycles, life cycles, life in 10 ns}
+#endif
 
 #define CL_SEL(q_, f) ((q_) == 0 ? g.p[0].f : ((q_) == 1 ? g.p[1].f : g.p[2].f))
 
@@ -142,6 +147,9 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
   }
 
   // ============================================================== matrix waves
+#ifdef CL_STAMPS
+  unsigned long long st_bar = 0, st_loop = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wr_ = wave / CW, wc = wave % CW;
   const int lr = lane & 15, lg = lane >> 4;
   for (int it = 0; it < g.assign_per; ++it) {
@@ -185,7 +193,11 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     auto step = [&](const int gb, auto slot_c) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_c)::value;
       if (j == 0) {                                              // first tap of a channel block: its window slice
+#ifdef CL_STAMPS
+        { const unsigned long long q0 = __builtin_amdgcn_s_memtime(); bar(); st_bar += __builtin_amdgcn_s_memtime() - q0; }
+#else
         bar();
+#endif
         buf = lds + (gslice & 1) * 3 * plane;
         ++gslice;
 #pragma unroll
@@ -226,6 +238,9 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCW, 0);
       j = more ? j + 1 : 0;
     };
+#ifdef CL_STAMPS
+    const unsigned long long st_l0 = __builtin_amdgcn_s_memtime();
+#endif
     int gb = 0;
     for (; gb + RING <= NB; gb += RING) {
       step(gb, std::integral_constant<int, 0>{});
@@ -240,6 +255,10 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       if (gb + 1 < NB) step(gb + 1, std::integral_constant<int, 1>{});
       if (gb + 2 < NB) step(gb + 2, std::integral_constant<int, 2>{});
     }
+#ifdef CL_STAMPS
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+    st_loop += __builtin_amdgcn_s_memtime() - st_l0;
+#endif
     // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
     {
       const float* bias = CL_SEL(q, bias);
@@ -293,6 +312,12 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       }
     }
   }
+#ifdef CL_STAMPS
+  if (tid == 0 && blockIdx.x < 256) {
+    cl_dbg[blockIdx.x * 4] = st_loop; cl_dbg[blockIdx.x * 4 + 1] = st_bar;
+    cl_dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - st_t0; cl_dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -311,9 +336,12 @@ struct CLShape { int NRW, NCW, RW, CW; };
 //     whose split-K tail evens out the 1.25 tiles per CU;
 //   * ups.0 (4 rows per slot; K = 8192, 100 MB of limb weights) and the C = 256 ResBlock convs (32 rows per slot; 64-row
 //     tiles because a 4-slot window of the dilation-5 conv does not fit in LDS twice) are bound by the L2 -> CU weight
-//     traffic at M <= 64: 118 us against conv_mfma's 84, and 6 x 48 us against resblock_pair's 3 x 98.  They keep the f32
-//     kernels (CONAN_RB_NOPAIR=1 runs the ResBlock convs through this kernel: the group path and its tile balancing are tested
-//     that way).
+//     traffic at M <= 64: 118 us against conv_mfma's 84, and 6 x 48 us against resblock_pair's 3 x 98.  (-DCL_STAMPS: the K
+//     loops of the ResBlock convs run at 0.37 of the MFMA rate, 2.2 GHz - not power-limited -, about 1000 cycles per block of
+//     24 MFMAs: 12 bytes per clock and CU of weights = 7 TB/s chip-wide, which is also what resblock_pair's f32 weights come to
+//     - 705 MB per launch in 98 us; 128 x 32 tiles with two row waves per column tile reload the weights per wave and
+//     measured 55 us.)  They keep the f32 kernels (CONAN_RB_NOPAIR=1 runs the ResBlock convs through this kernel: the group
+//     path and its tile balancing are tested that way).
 const CLShape kShapes[] = {{4, 1, 1, 4}, {5, 1, 1, 4}, {5, 2, 2, 2}};
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));
 
@@ -468,6 +496,17 @@ bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream
     case 2: launch_cl<5, 2, 2, 2>(g, grid, lds, st); break;
     default: return false;
   }
+#ifdef CL_STAMPS
+  {
+    (void)hipStreamSynchronize(st);
+    unsigned long long h[256 * 4];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cl_dbg), sizeof(h));
+    double lp = 0, br = 0, lf = 0, rt = 0, lfmax = 0; int nb = 0;
+    for (int b = 0; b < grid && b < 256; ++b) { lp += h[b * 4]; br += h[b * 4 + 1]; lf += h[b * 4 + 2]; rt += h[b * 4 + 3]; lfmax = std::max(lfmax, (double)h[b * 4 + 3]); ++nb; }
+    fprintf(stderr, "[conv_limb %s nprob %d k %d Cin %d T %d] K loops %.0f cyc = %.0f%% of life (barrier waits in them %.0f%%), life %.0f cyc = %.1f us avg / %.1f us max, clock %.2f GHz\n",
+            conv_limb_name(shape), g.nprob, g.p[0].ktaps, g.p[0].Cin, g.p[0].T, lp / nb, 100 * lp / lf, 100 * br / lf, lf / nb, rt / nb / 100.0, lfmax / 100.0, (lf / nb) / (rt / nb / 100.0) / 1e3);
+  }
+#endif
   return true;
 }
 
