@@ -225,3 +225,45 @@ def test_state_dicts_from_checkpoints_like_the_reference_constructor(tmp_path):
         state_dicts_from_checkpoints(dict(hp, emformer_ckpt=str(tmp_path / "missing")))
     with pytest.raises(ValueError):
         state_dicts_from_checkpoints(dict(hp, vocoder="NoSuchVocoder"))
+
+
+def _bf16_rne(x):
+    """float32 array -> the float32 value of its bf16 rounding (round-to-nearest-even on the bit pattern, as ctx.hip packs the
+    weights and v_cvt_pk_bf16_f32 rounds on the device)."""
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
+def test_three_bf16_limbs_carry_an_fp32_value_and_six_products_its_product():
+    """The arithmetic resblock_limb.hip / conv_limb.hip rest on: x = h + m + l with h = bf16(x), m = bf16(x - h),
+    l = bf16(x - h - m) reproduces an fp32 x to <= 2^-24 |x| (exactly, for most values), both subtractions are exact in fp32,
+    and the six limb products hh + hm + mh + hl + mm + lh - each exact in fp32 - miss x * w by <= 2^-22 |x w| before any
+    accumulation rounding, i.e. the sum is an fp32-grade product."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-12, 8, 200000))).astype(np.float32)
+    w = (rng.standard_normal(200000) * np.exp(rng.uniform(-12, 2, 200000))).astype(np.float32)
+
+    def limbs(v):
+        h = _bf16_rne(v)
+        r1 = (v - h).astype(np.float32)
+        assert np.array_equal(r1.astype(np.float64), v.astype(np.float64) - h.astype(np.float64))       # exact subtraction
+        m = _bf16_rne(r1)
+        r2 = (r1 - m).astype(np.float32)
+        assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - m.astype(np.float64))
+        return h, m, _bf16_rne(r2)
+
+    xh, xm, xl = limbs(x)
+    wh, wm, wl = limbs(w)
+    rec = xh.astype(np.float64) + xm.astype(np.float64) + xl.astype(np.float64)
+    assert np.max(np.abs(rec - x.astype(np.float64)) / np.abs(x.astype(np.float64))) <= 2.0 ** -24
+    assert np.mean(rec == x.astype(np.float64)) > 0.9
+    # each limb product has <= 16 significant bits: exact in fp32
+    for a, b in ((xh, wh), (xh, wm), (xm, wh), (xh, wl), (xm, wm), (xl, wh)):
+        p32 = (a * b).astype(np.float32)
+        assert np.array_equal(p32.astype(np.float64), a.astype(np.float64) * b.astype(np.float64))
+    six = sum(a.astype(np.float64) * b.astype(np.float64) for a, b in ((xl, wh), (xm, wm), (xh, wl), (xm, wh), (xh, wm), (xh, wh)))
+    exact = x.astype(np.float64) * w.astype(np.float64)
+    assert np.max(np.abs(six - exact) / np.abs(exact)) <= 2.0 ** -22
+    # ... against which the fp32 product itself is off by up to 2^-24
+    assert np.max(np.abs((x * w).astype(np.float64) - exact) / np.abs(exact)) <= 2.0 ** -24
