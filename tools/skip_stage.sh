@@ -1,3 +1,5 @@
+# What each front-end stage costs the pipelined step: bench.py with CONAN_SKIP_STAGE 0 / 1 (no Emformer) / 2 (no decoder) / 3 (vocoder only).
+# Timing only - the skipped stages leave their outputs unwritten.  Run through gpurun.
 cd /tmp && export TMPDIR=/tmp
 cd /root/repo
 for sk in 0 1 2 3; do
