@@ -1,4 +1,4 @@
-# A/B of two builds of the library on ONE box, alternating: bash tools/r3_ab.sh <alt .so>
+# A/B of two builds of the library on ONE box, alternating: bash tools/ab_bench.sh <alt .so>
 cd /tmp && export TMPDIR=/tmp
 cd /root/repo
 ALT=$1
