@@ -391,7 +391,10 @@ def main():
         bytes_alg = WEIGHT_BYTES_PER_STEP + B * STATE_BYTES_PER_STREAM * (frames_per_step / seg)
         k_peak, k_peak_basis = kernel_peak(name)
         roof = {"bound": "mfma", "achieved": ach, "peak": k_peak, "unit": "TFLOP/s",
-                "frac": ach / k_peak, "peak_basis": k_peak_basis, "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
+                "frac": ach / k_peak, "peak_basis": k_peak_basis, "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                # limb kernels: the bf16 FLOP/s the MFMAs execute (6 per algorithmic FLOP) against the bf16 dense peak - the same fraction
+                "executed_bf16_tflops": (6.0 * ach) if k_peak == PEAK_LIMB_TFLOPS else None, "bf16_dense_peak": PEAK_BF16_MFMA_TFLOPS,
+                "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
                 "traffic_stale": pmc_stale if traffic is not None else None, "lib_sha256": lib_sha256(),
                 "mfma_busy_frac_pmc": mfma_busy,
                 "kernel": name, "instantiations": insts, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
