@@ -348,7 +348,13 @@ void conan_streams::build_vocoder() {
     // tile (resblock_pair.hip).  A tile is all rows of a stream's step, so the stream-set must not take more than 32 rows per
     // step in this stage (windowed / whole-utterance stream-sets keep the two-launch plan), and it needs enough streams to
     // give the chip tiles.
-    if (!s.fused && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
+    // ... unless the stream-set is large enough for conv_limb's grouped launches (three problems of 3 / 7 / 11 taps, 64-row tiles:
+    // 6 tiles per stream, so >= 43 streams give every CU one): alone the two forms take the same time (6 x 48 against 3 x 98 us at
+    // 64 streams), but in the pipelined step the limb convs - LDS-bound, a third of the MFMA rate - leave the decoder and the
+    // Emformer more of the CUs they share than the f32-MFMA-dense pair kernel does: 1.408 against 1.427 ms per step, three
+    // alternating runs on one box (p95 of the step intervals 1.53 against 1.57).  CONAN_RB_PAIR=1 keeps the pair kernel.
+    const bool limb_groups = rb_limb && max_slots >= 48 && getenv("CONAN_RB_PAIR") == nullptr;
+    if (!s.fused && !limb_groups && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
         c.voc_num_resblocks <= kMaxBranches && max_slots >= (getenv("CONAN_RP_MIN_SLOTS") ? atoi(getenv("CONAN_RP_MIN_SLOTS")) : 16) && max_frames * rate <= 32) {
       s.pair = true;
       for (int b = 0; b < c.voc_num_resblocks; ++b)

@@ -278,14 +278,15 @@ def _kernel_names(st, ids, mel):
     return {r[0]: r[3] for r in st.profile_kernels()}       # kernel name -> launches
 
 
-@pytest.mark.parametrize("env,limb_expected", [({"CONAN_RB_NOLIMB": "1"}, False), ({"CONAN_RB_NOPAIR": "1"}, True)])
-def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, limb_expected):
+@pytest.mark.parametrize("env,other", [({"CONAN_RB_NOLIMB": "1"}, "f32"), ({"CONAN_RB_PAIR": "1"}, "pair")])
+def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, other):
     """resblock_limb.hip / conv_limb.hip form every fp32 product from three bf16 limbs per operand (six bf16 MFMA products,
-    accumulated in fp32).  64 streams through a default stream-set (limb kernels in the C = 128 / 64 / 32 ResBlock stages and
-    in ups.2 / ups.3) and through one created with CONAN_RB_NOLIMB=1 (exact-f32 MFMA everywhere): per-stage tensors,
-    pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch cross-check uses.  Second case:
-    CONAN_RB_NOPAIR=1 routes the first stage's ResBlock convs through conv_limb's grouped launches (three problems of 3 / 7 / 11
-    taps per launch, list-scheduled tiles) instead of resblock_pair."""
+    accumulated in fp32).  64 streams through a default stream-set - limb kernels in the C = 128 / 64 / 32 ResBlock stages, in
+    ups.2 / ups.3 and, for stream-sets of >= 48 slots, conv_limb's grouped launches (three problems of 3 / 7 / 11 taps per launch,
+    list-scheduled tiles) for the ResBlock convs of the C = 256 stage - and through one created with CONAN_RB_NOLIMB=1 (exact-f32
+    MFMA everywhere, pair kernel in the first stage) or with CONAN_RB_PAIR=1 (limb kernels, but the f32 pair kernel in the
+    first stage): per-stage tensors, pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch
+    cross-check uses."""
     vhp = configs.hifigan_hparams()
     ctx = _voc_ctx(vhp)
     S = 64
@@ -305,10 +306,11 @@ def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, limb_expected):
     # the kernels that ran (a silent fall-back to the f32 kernels would pass the comparison above)
     na, nb = _kernel_names(a, ids, mel[:, :4].contiguous()), _kernel_names(b, ids, mel[:, :4].contiguous())
     assert any("resblock_limb_kernel<128" in k for k in na) and any("resblock_limb_kernel<64" in k for k in na) and any("resblock_limb_kernel<32" in k for k in na)
-    assert any("conv_limb_kernel" in k for k in na) and any("resblock_pair_kernel" in k for k in na)
-    if limb_expected:
-        # two upsamplers + 3 dilations x (c1, c2) grouped launches
-        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k) == 8 and not any("resblock_pair_kernel" in k for k in nb)
+    # two upsamplers + 3 dilations x (c1, c2) grouped launches, no pair kernel
+    assert sum(n for k, n in na.items() if "conv_limb_kernel" in k) == 8 and not any("resblock_pair_kernel" in k for k in na)
+    if other == "pair":
+        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k) == 2 and any("resblock_pair_kernel" in k for k in nb)
+        assert any("resblock_limb_kernel<128" in k for k in nb)
     else:
-        assert not any("limb" in k for k in nb)
+        assert not any("limb" in k for k in nb) and any("resblock_pair_kernel" in k for k in nb)
     a.close(); b.close(); ctx.close()
