@@ -56,7 +56,8 @@ constexpr int CL_NIT = 12;          // float4 per helper thread and slice: windo
 }  // namespace
 
 #ifdef CL_STAMPS
-__device__ unsigned long long cl_dbg[256 * 4];      // developer build: per block {K-loop cycles, barrier-wait cycles, life cycles, life in 10 ns}
+__device__ unsigned long long cl_dbg[256 * 4];
+__device__ unsigned long long cl_dbg2[256 * 4];      // {cycles before the first K loop, epilogue cycles, first barrier wait of tile 1, tiles}      // developer build: per block {K-loop cycles, barrier-wait cycles, life cycles, life in 10 ns}
 #endif
 
 #define CL_SEL(q_, f) ((q_) == 0 ? g.p[0].f : ((q_) == 1 ? g.p[1].f : g.p[2].f))
@@ -115,6 +116,10 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       // storing a slice between two barriers put a global round trip - 2 us - on every channel block: 3-tap tiles ran as
       // long as 11-tap ones.)
       f32x4 v[CL_NIT];
+#ifdef CL_ABL_STAGE      // developer ablation: the helpers only keep the barriers
+      for (int cb = 0; cb < nblk; ++cb) { bar(); ++gslice; }
+      continue;
+#endif
 #pragma unroll
       for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u]);
       for (int cb = 0; cb < nblk; ++cb) {
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 
   // ============================================================== matrix waves
 #ifdef CL_STAMPS
-  unsigned long long st_bar = 0, st_loop = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_bar = 0, st_loop = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_pro = 0, st_epi = 0, st_fb = 0, st_tiles = 0;
 #endif
   const int wr_ = wave / CW, wc = wave % CW;
   const int lr = lane & 15, lg = lane >> 4;
@@ -175,6 +180,20 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     for (int r = 0; r < NRW; ++r)
 #pragma unroll
       for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the epilogue's rows: slot and frame counter of this lane's row of every row tile - two dependent loads, issued now so that
+    // they are long back when the K loop ends (in the epilogue they were 2 us per tile with nothing to overlap them)
+    int eslot[NRW], epos[NRW];
+    {
+      const int* slots = CL_SEL(q, slots);
+      const int* pos = CL_SEL(q, pos);
+#pragma unroll
+      for (int r = 0; r < NRW; ++r) {
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T;
+        eslot[r] = slots ? *(gci)(slots + i) : i;
+      }
+#pragma unroll
+      for (int r = 0; r < NRW; ++r) epos[r] = pos ? *(gci)(pos + eslot[r]) : 0;
+    }
     // weight blocks in flight: four with one column tile per wave (a block is 6 * NRW MFMAs = 0.2 us of work there - two blocks
     // ahead is less than an L2 round trip under load), two with two
     constexpr int RING = NCW == 1 ? 4 : 2;
@@ -214,11 +233,17 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 #pragma unroll
           for (int c = 0; c < NCW; ++c)
             acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[SL][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]), acc[r][c], 0, 0, 0);
+#ifndef CL_ABL_A      // (developer ablation: no A re-reads)
           if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + abase[r]);
           if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + abase[r]);
           if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + abase[r]);
+#endif
         }
+#ifdef CL_ABL_W
+      const int gn = 0;                                          // developer ablation: every weight block from the stream's start (L1 hits)
+#else
       const int gn = gb + RING < NB ? gb + RING : 0;             // (past the last block: block 0 again, unused)
+#endif
 #pragma unroll
       for (int c = 0; c < NCW; ++c)
 #pragma unroll
@@ -240,6 +265,9 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     };
 #ifdef CL_STAMPS
     const unsigned long long st_l0 = __builtin_amdgcn_s_memtime();
+    if (st_tiles == 0) st_pro = st_l0 - st_t0;
+    const unsigned long long st_bar0 = st_bar;
+    ++st_tiles;
 #endif
     int gb = 0;
     for (; gb + RING <= NB; gb += RING) {
@@ -258,6 +286,8 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 #ifdef CL_STAMPS
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
     st_loop += __builtin_amdgcn_s_memtime() - st_l0;
+    (void)st_bar0;
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
     // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
     {
@@ -276,12 +306,10 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const long long rss = CL_SEL(q, res.slot_stride);
       float* y2b = CL_SEL(q, y2_base);
       const float y2s = CL_SEL(q, y2_slope);
-      const int* slots = CL_SEL(q, slots);
-      const int* pos = CL_SEL(q, pos);
 #pragma unroll
       for (int r = 0; r < NRW; ++r) {
         const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
-        const int slot = slots ? *(gci)(slots + i) : i, pv = pos ? *(gci)(pos + slot) : 0;
+        const int slot = eslot[r], pv = epos[r];
 #pragma unroll
         for (int c = 0; c < NCW; ++c) {
           const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
@@ -311,8 +339,13 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         }
       }
     }
+#ifdef CL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_epi += __builtin_amdgcn_s_memtime() - st_e0;
+#endif
   }
 #ifdef CL_STAMPS
+  if (tid == 0 && blockIdx.x < 256) { cl_dbg2[blockIdx.x * 4] = st_pro; cl_dbg2[blockIdx.x * 4 + 1] = st_epi; cl_dbg2[blockIdx.x * 4 + 2] = st_fb; cl_dbg2[blockIdx.x * 4 + 3] = st_tiles; }
   if (tid == 0 && blockIdx.x < 256) {
     cl_dbg[blockIdx.x * 4] = st_loop; cl_dbg[blockIdx.x * 4 + 1] = st_bar;
     cl_dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - st_t0; cl_dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime() - st_r0;
@@ -503,6 +536,14 @@ bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(cl_dbg), sizeof(h));
     double lp = 0, br = 0, lf = 0, rt = 0, lfmax = 0; int nb = 0;
     for (int b = 0; b < grid && b < 256; ++b) { lp += h[b * 4]; br += h[b * 4 + 1]; lf += h[b * 4 + 2]; rt += h[b * 4 + 3]; lfmax = std::max(lfmax, (double)h[b * 4 + 3]); ++nb; }
+    {
+      unsigned long long h2[256 * 4];
+      (void)hipMemcpyFromSymbol(h2, HIP_SYMBOL(cl_dbg2), sizeof(h2));
+      double pro = 0, epi = 0, tl = 0; int nb2 = 0;
+      for (int b2 = 0; b2 < grid && b2 < 256; ++b2) { pro += h2[b2 * 4]; epi += h2[b2 * 4 + 1]; tl += h2[b2 * 4 + 3]; ++nb2; }
+      fprintf(stderr, "   before the first K loop %.0f cyc, epilogues %.0f cyc (%.2f tiles per block); block 0: %llu / %llu, block %d: %llu / %llu\n", pro / nb2, epi / nb2, tl / nb2,
+              h2[0], h2[1], nb2 - 1, h2[(nb2 - 1) * 4], h2[(nb2 - 1) * 4 + 1]);
+    }
     fprintf(stderr, "[conv_limb %s nprob %d k %d Cin %d T %d] K loops %.0f cyc = %.0f%% of life (barrier waits in them %.0f%%), life %.0f cyc = %.1f us avg / %.1f us max, clock %.2f GHz\n",
             conv_limb_name(shape), g.nprob, g.p[0].ktaps, g.p[0].Cin, g.p[0].T, lp / nb, 100 * lp / lf, 100 * br / lf, lf / nb, rt / nb / 100.0, lfmax / 100.0, (lf / nb) / (rt / nb / 100.0) / 1e3);
   }
