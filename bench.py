@@ -61,6 +61,12 @@ STATE_BYTES_PER_STREAM = 1.2e6  # state read+write + I/O per stream per step
 WORKLOADS = {
     "b64": dict(streams=64, chunk_ms=80, window=0, config="BASELINE.json configs[2] (x8 GPUs = configs[3])",
                 desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
+    # the same workload with the vocoder's fp32 products formed from three bf16 limbs per operand on the bf16 MFMA (resblock_limb.hip,
+    # conv_limb.hip: fp32 results, every parity test at its unchanged tolerance) - a separate datapoint with its own roofline;
+    # every other workload runs the exact-f32 MFMA kernels (CONAN_RB_NOLIMB=1 is set for them below)
+    "b64_bf16x3": dict(streams=64, chunk_ms=80, window=0, limb=True, config="BASELINE.json configs[2] (x8 GPUs = configs[3]), fp32 products as bf16 limb products",
+                       desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline; "
+                            "vocoder fp32 products as six bf16 limb products"),
     "b1": dict(streams=1, chunk_ms=80, window=0, config="BASELINE.json configs[1], stateful mode",
                desc="batch=1 stream, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
     "b1win": dict(streams=1, chunk_ms=80, window=8, config="BASELINE.json configs[1], 160 ms context window",
@@ -206,6 +212,26 @@ def pmc_summary(tag):
     return None, None, None
 
 
+def limb_datapoint(steps, warmup):
+    """`bench.py --workload b64_bf16x3` in a child process, reduced to the fields of a datapoint."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "b64_bf16x3", "--steps", str(steps), "--warmup", str(warmup),
+                            "--no-cpu-baseline", "--no-b1"], capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        rf = d["roofline"]
+        return {"workload": "b64_bf16x3", "dtype": d["dtype"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "p50_latency_ms": d["p50_latency_ms"], "step_time_stats": d.get("step_time_stats"),
+                "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "peak_basis", "frac_of_f32_mfma_peak",
+                                                    "executed_bf16_tflops", "bf16_dense_peak", "traffic", "traffic_stale", "avg_launch_us", "launches_per_step")},
+                "matrix_kernels": rf.get("matrix_kernels"),
+                "note": "same workload, the vocoder's fp32 products as six bf16 limb products each (fp32 results: every parity test and golden at its "
+                        "unchanged tolerance; error against float64 below the f32 MFMA's own - DESIGN.md); not the headline"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +257,13 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.streams or wl["streams"]
     window = wl["window"]
+    # arithmetic of the vocoder's matrix kernels: exact-f32 MFMA unless the workload is the bf16-limb datapoint (the switch is read
+    # when a stream-set is created)
+    limb = bool(wl.get("limb"))
+    if limb:
+        os.environ.pop("CONAN_RB_NOLIMB", None)
+    else:
+        os.environ["CONAN_RB_NOLIMB"] = "1"
 
     ctx, chp, vhp = build_context(local, wl["chunk_ms"], wl.get("memory", 0))
     eng, chunks = make_engine(ctx, B, first_stream=rank * B, window=window)
@@ -452,9 +485,7 @@ def main():
             "metric": "chunks/sec (%d ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it" % wl["chunk_ms"],
             "value": total_chunks / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # fp32 results throughout; the ResBlock stages that run resblock_limb.hip form each fp32 product from three bf16 limbs
-            # per operand (six bf16 MFMA products, error below the f32 MFMA's own: DESIGN.md) - CONAN_RB_NOLIMB=1 gives pure f32 MFMA
-            "dtype": "f32" if os.environ.get("CONAN_RB_NOLIMB") else "f32 (bf16x3 limbs on the bf16 MFMA in the ResBlock stages)", "data": "synthetic",
+            "dtype": "f32 via 3xbf16 limbs, f32 accumulate" if limb else "f32", "data": "synthetic",
             "config": {"workload": wl["desc"] if not args.streams else f"batch={B} streams per GPU, {wl['chunk_ms']} ms chunk" + (", windowed" if window else ", stateful"),
                        "name": args.workload, "baseline_config": wl["config"],
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
@@ -466,6 +497,10 @@ def main():
             "realtime_streams_supported": (total_chunks / dt) / (1000.0 / wl["chunk_ms"]),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        # the default line is the exact-f32 one; the bf16-limb datapoint of the same workload rides along (a child process: the
+        # arithmetic switch is per stream-set, and its own roofline needs its own profiling pass)
+        if args.workload == "b64" and world == 1 and not args.streams and not args.no_b1 and not args.marks:
+            out["bf16x3_datapoint"] = limb_datapoint(args.steps, args.warmup)
         if b1 is not None:
             out["latency_b1"] = b1
         if fe is not None:

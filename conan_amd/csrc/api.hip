@@ -399,7 +399,7 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     // developer timing switch (results are then meaningless): CONAN_SKIP_STAGE bit 0 skips the Emformer launch, bit 1 the decoder's
     static const int skip = getenv("CONAN_SKIP_STAGE") ? atoi(getenv("CONAN_SKIP_STAGE")) : 0;
     // (the Emformer's workgroups need whole CUs for ~0.15 ms; they are kept away from the pair kernel's launches: see ev_wide)
-    static const bool hold = getenv("CONAN_EMF_NOHOLD") == nullptr;
+    static const bool hold = getenv("CONAN_EMF_HOLD") != nullptr;      // (off by default: see streams.h, ev_wide)
     if (hold && t >= 2 && s->ev_wide[(t + NP - 2) % NP] && s->wide_marked[(t + NP - 2) % NP]) HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_wide[(t + NP - 2) % NP], 0));
     if (tl) HIP_CHECK(hipEventRecord(te[0], s->st_emf));
     if (!(skip & 1)) s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_emf);
