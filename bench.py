@@ -63,7 +63,7 @@ WORKLOADS = {
                 desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
     # the same workload with the vocoder's fp32 products formed from three bf16 limbs per operand on the bf16 MFMA (resblock_limb.hip,
     # conv_limb.hip: fp32 results, every parity test at its unchanged tolerance) - a separate datapoint with its own roofline;
-    # every other workload runs the exact-f32 MFMA kernels (CONAN_RB_NOLIMB=1 is set for them below)
+    # every other workload runs the library's default, the exact-f32 MFMA kernels
     "b64_bf16x3": dict(streams=64, chunk_ms=80, window=0, limb=True, config="BASELINE.json configs[2] (x8 GPUs = configs[3]), fp32 products as bf16 limb products",
                        desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline; "
                             "vocoder fp32 products as six bf16 limb products"),
@@ -262,8 +262,9 @@ def main():
     limb = bool(wl.get("limb"))
     if limb:
         os.environ.pop("CONAN_RB_NOLIMB", None)
+        os.environ["CONAN_RB_LIMB"] = "1"
     else:
-        os.environ["CONAN_RB_NOLIMB"] = "1"
+        os.environ.pop("CONAN_RB_LIMB", None)
 
     ctx, chp, vhp = build_context(local, wl["chunk_ms"], wl.get("memory", 0))
     eng, chunks = make_engine(ctx, B, first_stream=rank * B, window=window)

@@ -130,7 +130,9 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
       s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
-      s->rb_limb = getenv("CONAN_RB_NOLIMB") == nullptr;
+      // fp32 products of the vocoder's matrix kernels as six bf16 limb products (resblock_limb.hip, conv_limb.hip): opt-in - the
+      // default is the exact-f32 MFMA everywhere (CONAN_RB_NOLIMB=1 wins over CONAN_RB_LIMB=1)
+      s->rb_limb = getenv("CONAN_RB_LIMB") != nullptr && getenv("CONAN_RB_NOLIMB") == nullptr;
       { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
       { const char* e = getenv("CONAN_DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
       { const char* e = getenv("CONAN_MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }

@@ -74,7 +74,7 @@ struct conan_streams {
   int* sk_counters[3] = {nullptr, nullptr, nullptr};
   int reserve_cus = 0;                     // CUs the pipelined vocoder's persistent launches leave to the front-end stream (CONAN_RESERVE_CUS)
   bool fenced = false;          // CONAN_FENCED=1 at creation: release / acquire fences around the inter-workgroup hand-offs too
-  bool rb_limb = true;          // bf16-limb form of the fused ResBlock pass where it exists (CONAN_RB_NOLIMB=1 at creation: exact-f32 MFMA everywhere)
+  bool rb_limb = false;         // bf16-limb form of the vocoder's matrix kernels where it exists (CONAN_RB_LIMB=1 at creation; default: exact-f32 MFMA everywhere)
   bool rb_merge = true;         // merged-branch last-dilation launches (CONAN_RB_NOMERGE=1 at creation: separate branches + mean_act)
   int* cp_ticket[3] = {nullptr, nullptr, nullptr};   // conv_post's last-workgroup ticket, per internal stream
   int* rb_sched[2] = {nullptr, nullptr};   // work-queue counters of the fused resblock launches, per stream like the split-K workspaces

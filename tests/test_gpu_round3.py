@@ -253,22 +253,24 @@ def test_decoder_widths_come_from_the_checkpoint(streams):
     ctx2.close()
 
 
-def _two_stream_sets(ctx, S, env):
-    """A default stream-set and one created with the environment switches in `env` (they are read at creation)."""
-    old = {k: os.environ.get(k) for k in env}
+def _two_stream_sets(ctx, S, env_a, env_b):
+    """Two stream-sets created under the environment switches env_a / env_b (they are read at creation)."""
+    keys = set(env_a) | set(env_b)
+    old = {k: os.environ.get(k) for k in keys}
     try:
-        for k in env:
-            os.environ.pop(k, None)
-        a = ctx.streams(S, max_frames=4, max_ref_frames=16)
-        os.environ.update(env)
-        b = ctx.streams(S, max_frames=4, max_ref_frames=16)
+        sets = []
+        for env in (env_a, env_b):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            sets.append(ctx.streams(S, max_frames=4, max_ref_frames=16))
     finally:
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    return a, b
+    return sets
 
 
 def _kernel_names(st, ids, mel):
@@ -278,19 +280,19 @@ def _kernel_names(st, ids, mel):
     return {r[0]: r[3] for r in st.profile_kernels()}       # kernel name -> launches
 
 
-@pytest.mark.parametrize("env,other", [({"CONAN_RB_NOLIMB": "1"}, "f32"), ({"CONAN_RB_PAIR": "1"}, "pair")])
+@pytest.mark.parametrize("env,other", [({}, "f32"), ({"CONAN_RB_LIMB": "1", "CONAN_RB_PAIR": "1"}, "pair")])
 def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, other):
     """resblock_limb.hip / conv_limb.hip form every fp32 product from three bf16 limbs per operand (six bf16 MFMA products,
-    accumulated in fp32).  64 streams through a default stream-set - limb kernels in the C = 128 / 64 / 32 ResBlock stages, in
-    ups.2 / ups.3 and, for stream-sets of >= 48 slots, conv_limb's grouped launches (three problems of 3 / 7 / 11 taps per launch,
-    list-scheduled tiles) for the ResBlock convs of the C = 256 stage - and through one created with CONAN_RB_NOLIMB=1 (exact-f32
-    MFMA everywhere, pair kernel in the first stage) or with CONAN_RB_PAIR=1 (limb kernels, but the f32 pair kernel in the
-    first stage): per-stage tensors, pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch
-    cross-check uses."""
+    accumulated in fp32); CONAN_RB_LIMB=1 at stream-set creation switches them on (the default is the exact-f32 MFMA everywhere).
+    64 streams through a limb stream-set - limb kernels in the C = 128 / 64 / 32 ResBlock stages, in ups.2 / ups.3 and, for
+    stream-sets of >= 48 slots, conv_limb's grouped launches (three problems of 3 / 7 / 11 taps per launch, list-scheduled tiles)
+    for the ResBlock convs of the C = 256 stage - and through a default one (exact-f32 MFMA, pair kernel in the first stage) or
+    one with CONAN_RB_LIMB=1 CONAN_RB_PAIR=1 (limb kernels, but the f32 pair kernel in the first stage): per-stage tensors,
+    pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch cross-check uses."""
     vhp = configs.hifigan_hparams()
     ctx = _voc_ctx(vhp)
     S = 64
-    a, b = _two_stream_sets(ctx, S, env)
+    a, b = _two_stream_sets(ctx, S, {"CONAN_RB_LIMB": "1"}, env)
     ids = list(range(S))
     mel = torch.from_numpy(synth.mel(16, 9, S)).cuda()
     for st in (a, b):

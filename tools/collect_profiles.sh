@@ -14,9 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- pytho
 # between two profile marks (tools/blocking_trace.py: 6 timed steps; tools/marked_stats.py) - the per-utterance style pass runs
 # the same conv_mfma instantiations as the upsamplers and must not be averaged into them
 # (the arithmetic switch of the workload: bench.py sets it itself; the blocking trace takes it from the environment)
-if [ "$W" = "b64_bf16x3" ]; then unset CONAN_RB_NOLIMB; else export CONAN_RB_NOLIMB=1; fi
+if [ "$W" = "b64_bf16x3" ]; then export CONAN_RB_LIMB=1; else unset CONAN_RB_LIMB; fi
 rocprofv3 --kernel-trace --output-format csv -d $O/stats_blocking -o run -- python3 tools/blocking_trace.py 64 > $O/stats_blocking.log 2>&1
-unset CONAN_RB_NOLIMB
+unset CONAN_RB_LIMB
 python3 tools/marked_stats.py $O/stats_blocking/run_kernel_trace.csv 6 > $O/stats_blocking/run_kernel_stats.csv
 CMD="python3 bench.py --workload $W --steps $STEPS --warmup 3 --marks"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do

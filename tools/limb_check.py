@@ -7,11 +7,10 @@ from conan_amd.runtime import Context
 vhp = configs.hifigan_hparams()
 ctx = Context(None, vhp, 0, False, False, True); ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0)); ctx.finalize()
 for S in (100, 40, 130):
-    os.environ.pop("CONAN_RB_NOLIMB", None)
+    os.environ["CONAN_RB_LIMB"] = "1"
     a = ctx.streams(S, max_frames=4, max_ref_frames=16)
-    os.environ["CONAN_RB_NOLIMB"] = "1"
+    os.environ.pop("CONAN_RB_LIMB", None)
     b = ctx.streams(S, max_frames=4, max_ref_frames=16)
-    os.environ.pop("CONAN_RB_NOLIMB", None)
     ids = list(range(S)); mel = torch.from_numpy(synth.mel(12, 3, S)).cuda()
     for st in (a, b): st.reset(ids)
     worst = 0.0
