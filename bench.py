@@ -486,7 +486,7 @@ def main():
             "metric": "chunks/sec (%d ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it" % wl["chunk_ms"],
             "value": total_chunks / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 via 3xbf16 limbs, f32 accumulate" if limb else "f32", "data": "synthetic",
+            "dtype": "f32 via 3\u00d7bf16 limbs, f32 accumulate" if limb else "f32", "data": "synthetic",
             "config": {"workload": wl["desc"] if not args.streams else f"batch={B} streams per GPU, {wl['chunk_ms']} ms chunk" + (", windowed" if window else ", stateful"),
                        "name": args.workload, "baseline_config": wl["config"],
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
