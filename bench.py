@@ -61,12 +61,6 @@ STATE_BYTES_PER_STREAM = 1.2e6  # state read+write + I/O per stream per step
 WORKLOADS = {
     "b64": dict(streams=64, chunk_ms=80, window=0, config="BASELINE.json configs[2] (x8 GPUs = configs[3])",
                 desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
-    # the same workload with the vocoder's fp32 products formed from three bf16 limbs per operand on the bf16 MFMA (resblock_limb.hip,
-    # conv_limb.hip: fp32 results, every parity test at its unchanged tolerance) - a separate datapoint with its own roofline;
-    # every other workload runs the library's default, the exact-f32 MFMA kernels
-    "b64_bf16x3": dict(streams=64, chunk_ms=80, window=0, limb=True, config="BASELINE.json configs[2] (x8 GPUs = configs[3]), fp32 products as bf16 limb products",
-                       desc="batch=64 concurrent streams per GPU, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline; "
-                            "vocoder fp32 products as six bf16 limb products"),
     "b1": dict(streams=1, chunk_ms=80, window=0, config="BASELINE.json configs[1], stateful mode",
                desc="batch=1 stream, 80 ms chunk (seg 4 + rc 2 frames), stateful full Emformer->Conan->HiFi-GAN pipeline"),
     "b1win": dict(streams=1, chunk_ms=80, window=8, config="BASELINE.json configs[1], 160 ms context window",
@@ -94,11 +88,11 @@ def build_context(device, chunk_ms=80, memory=0):
     return ctx, chp, vhp
 
 
-def make_engine(ctx, B, first_stream, window=0):
+def make_engine(ctx, B, first_stream, window=0, arith="auto"):
     """B streams with their reference set and every full chunk of the 3 s utterance staged in HBM."""
     from conan_amd import synth
     from conan_amd.engine import StreamingVoiceConversionEngine
-    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1, max_frames=window + ctx.cfg.emf_segment if window else None)
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1, max_frames=window + ctx.cfg.emf_segment if window else None, arith=arith)
     src = np.concatenate([synth.mel(N_FRAMES, 1234 + first_stream + s) for s in range(B)])
     ref = np.concatenate([synth.mel(N_REF, 4321 + first_stream + s) for s in range(B)])
     src = torch.from_numpy(src).cuda()
@@ -202,7 +196,7 @@ def pmc_summary(tag):
     from inside the benchmark): profiles/r<round>_<tag>_pmc.json, made by tools/collect_profiles.sh + tools/summarize_pmc.py
     (newest round first).  The summary records the sha256 of the library it was collected with; `stale` says whether that
     differs from the library loaded now (a summary without a hash counts as stale)."""
-    for rnd in ("r3", "r2"):
+    for rnd in ("r4",):
         path = os.path.join(REPO, "profiles", f"{rnd}_{tag}_pmc.json")
         try:
             d = json.load(open(path))
@@ -212,24 +206,138 @@ def pmc_summary(tag):
     return None, None, None
 
 
-def limb_datapoint(steps, warmup):
-    """`bench.py --workload b64_bf16x3` in a child process, reduced to the fields of a datapoint."""
-    import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "b64_bf16x3", "--steps", str(steps), "--warmup", str(warmup),
-                            "--no-cpu-baseline", "--no-b1"], capture_output=True, text=True, timeout=600)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        d = json.loads(line)
-        rf = d["roofline"]
-        return {"workload": "b64_bf16x3", "dtype": d["dtype"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                "p50_latency_ms": d["p50_latency_ms"], "step_time_stats": d.get("step_time_stats"),
-                "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "peak_basis", "frac_of_f32_mfma_peak",
-                                                    "executed_bf16_tflops", "bf16_dense_peak", "traffic", "traffic_stale", "avg_launch_us", "launches_per_step")},
-                "matrix_kernels": rf.get("matrix_kernels"),
-                "note": "same workload, the vocoder's fp32 products as six bf16 limb products each (fp32 results: every parity test and golden at its "
-                        "unchanged tolerance; error against float64 below the f32 MFMA's own - DESIGN.md); not the headline"}
-    except Exception as e:  # noqa: BLE001
-        return {"error": f"{type(e).__name__}: {e}"}
+DTYPE = {"f32": "f32", "limb": "f32 (3×bf16-limb products, f32 accumulate)"}
+
+
+class Runner:
+    """One stream-set (engine) of the workload with its output buffers: pipelined / windowed steps, blocking steps, the
+    throughput timing, the latency leg and the per-kernel profile.  The headline and the other arithmetic form's datapoint are
+    two Runners over the same context, timed by the same code."""
+
+    def __init__(self, ctx, wl, B, rank, world, arith, comm=False):
+        from conan_amd.engine import AudioGatherRing
+        self.wl, self.B, self.world, self.rank, self.window = wl, B, world, rank, wl["window"]
+        self.eng, self.chunks = make_engine(ctx, B, first_stream=rank * B, window=self.window, arith=arith)
+        self.arith = self.eng.st.arith                  # 'auto' resolved by the library
+        self.hop, self.seg = ctx.hop, self.eng.seg
+        self.codes = torch.empty(B, self.seg, dtype=torch.int32, device="cuda")
+        self.mel_out = torch.empty(B, self.seg, 80, device="cuda")
+        self.wav = torch.empty(B, self.seg * self.hop, device="cuda")
+        # Throughput leg, stateful workloads: pipelined steps (conan_step_async) - the stages of consecutive chunks overlap on
+        # the library's internal HIP streams.  Audio goes to a small ring of buffers; with more than one rank the RCCL gather
+        # runs on its own stream (conan_amd.engine.AudioGatherRing; CONAN_BENCH_COMM=1 exercises that choreography on one rank).
+        # Windowed workloads: one blocking windowed step (Emformer step, reset, decoder + vocoder over window + chunk frames).
+        self.ring = AudioGatherRing(lambda: torch.empty_like(self.wav), world, rank, nb=4, always=comm,
+                                    every=int(os.environ.get("CONAN_BENCH_GATHER_EVERY", "4")))
+        self.hist = [torch.randint(0, 100, (B, self.window), dtype=torch.int32, device="cuda")] if self.window else None
+        self.j = 0
+
+    def step(self):
+        j, eng, seg = self.j, self.eng, self.seg
+        self.j += 1
+        chunk = self.chunks[j % len(self.chunks)]
+        if not self.window:      # only the vocoder stage of the step waits for the gather that last read this buffer
+            buf, fence = self.ring.acquire(j, fence=True)
+            eng.st.step_async(eng.slots, chunk, buf, emit=seg, codes=self.codes, mel_out=self.mel_out, out_fence=fence)
+            self.ring.submit(j, join=eng.st.join)
+            return
+        buf = self.ring.acquire(j)
+        c, w = eng.windowed_step(chunk, self.hist[0])
+        self.hist[0] = torch.cat([self.hist[0][:, seg:], c], 1)
+        buf.copy_(w)
+        self.ring.submit(j, wait_current=True)
+
+    def blocking_step(self):
+        eng, seg = self.eng, self.seg
+        chunk = self.chunks[self.j % len(self.chunks)]
+        self.j += 1
+        if self.window:
+            cc, _ = eng.windowed_step(chunk, self.hist[0])
+            self.hist[0] = torch.cat([self.hist[0][:, seg:], cc], 1)
+        else:
+            eng.st.step(eng.slots, chunk, emit=seg, codes=self.codes, mel_out=self.mel_out, wav_out=self.wav)
+
+    def barrier(self):
+        if not self.window:
+            self.eng.st.join()
+        self.ring.flush(self.j - 1)
+        self.ring.drain()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, marks=False):
+        """W untimed + exactly K timed steps between barrier + synchronize on both sides -> seconds (this rank's clock)."""
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        if marks:
+            self.eng.st.profile_mark()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if marks:
+            self.eng.st.profile_mark()
+            torch.cuda.synchronize()
+        return dt
+
+    def step_intervals(self, n):
+        """Distribution of the step time (outside the timed region, same schedule): the library stamps the completion of every
+        pipelined step with a timing event on its own vocoder stream (conan_step_clock) - no extra stream, no extra wait."""
+        st = self.eng.st
+        st.step_clock(n + 1)
+        for _ in range(n + 1):
+            self.step()
+        self.barrier()
+        iv = sorted(st.step_clock_read())
+        st.step_clock(0)
+        if not iv:
+            return None
+        return {"n": len(iv), "mean_ms": statistics.fmean(iv), "sigma_ms": statistics.pstdev(iv), "p50_ms": statistics.median(iv),
+                "p95_ms": iv[min(len(iv) - 1, int(round(0.95 * (len(iv) - 1))))], "min_ms": iv[0], "max_ms": iv[-1],
+                "how": "intervals between consecutive step completions (timing events on the library's vocoder stream), a separate run of pipelined steps after the timed region"}
+
+    def latencies(self, n):
+        """per-chunk latency: one blocking step for all B streams, host submit -> audio complete on device"""
+        lats = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            self.blocking_step()
+            torch.cuda.synchronize()
+            lats.append((time.perf_counter() - a) * 1e3)
+        return {"n": len(lats), "p50_ms": statistics.median(lats), "p95_ms": sorted(lats)[min(len(lats) - 1, int(round(0.95 * (len(lats) - 1))))],
+                "sigma_ms": statistics.pstdev(lats), "min_ms": min(lats), "max_ms": max(lats)}
+
+    def kernel_profile(self, nprof=5):
+        """HIP events around every launch of the matrix kernels on their launch stream (blocking steps): per kernel template
+        ('family') and per instantiation the summed time, algorithmic FLOPs and launches."""
+        st = self.eng.st
+        torch.cuda.synchronize()
+        st.profile_begin()
+        for _ in range(nprof):
+            self.blocking_step()
+        conv_ms, conv_flops, conv_launches = st.profile_end()
+        kernels = sorted(st.profile_kernels(), key=lambda r: -r[1])
+        fams = {}
+        for kn, ms_, fl_, n_ in kernels:
+            f = fams.setdefault(kn.split("<")[0], [0.0, 0.0, 0, []])
+            f[0] += ms_; f[1] += fl_; f[2] += n_; f[3].append(kn)
+        return {"nprof": nprof, "kernels": kernels, "families": fams, "conv_ms": conv_ms, "conv_flops": conv_flops, "conv_launches": conv_launches}
+
+    def close(self):
+        self.eng.st.close()
+
+
+def dominant(prof):
+    """The dominant kernel = the kernel template with the largest summed time: (name, achieved algorithmic TFLOP/s, peak, basis,
+    ms per step, launches per step, average launch us, instantiations)."""
+    name, (k_ms, k_fl, k_n, insts) = max(prof["families"].items(), key=lambda kv: kv[1][0])
+    peak, basis = kernel_peak(name)
+    return {"kernel": name, "achieved": k_fl / (k_ms * 1e-3) / 1e12, "peak": peak, "peak_basis": basis, "ms_per_step": k_ms / prof["nprof"],
+            "launches_per_step": k_n / prof["nprof"], "avg_launch_us": k_ms * 1e3 / k_n, "gflop_per_launch": k_fl / k_n / 1e9, "instantiations": insts}
 
 
 def main():
@@ -238,10 +346,13 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="b64", choices=sorted(WORKLOADS))
+    ap.add_argument("--arith", default="auto", choices=["auto", "f32", "limb"],
+                    help="arithmetic of the vocoder's matrix kernels (conan_streams_opts.arith); auto = the library's default, which `value` measures")
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-steps", type=int, default=40)
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency leg (keeps profiler summaries to one workload)")
+    ap.add_argument("--no-other", action="store_true", help="skip the datapoint of the other arithmetic form")
     ap.add_argument("--marks", action="store_true", help="bracket the timed steps with cnk::profile_mark_kernel dispatches and skip "
                                                          "every other leg (rocprofv3 --pmc passes: tools/summarize_pmc.py keeps the dispatches between the marks)")
     args = ap.parse_args()
@@ -257,77 +368,23 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.streams or wl["streams"]
     window = wl["window"]
-    # arithmetic of the vocoder's matrix kernels: exact-f32 MFMA unless the workload is the bf16-limb datapoint (the switch is read
-    # when a stream-set is created)
-    limb = bool(wl.get("limb"))
-    if limb:
-        os.environ.pop("CONAN_RB_NOLIMB", None)
-        os.environ["CONAN_RB_LIMB"] = "1"
-    else:
-        os.environ.pop("CONAN_RB_LIMB", None)
 
     ctx, chp, vhp = build_context(local, wl["chunk_ms"], wl.get("memory", 0))
-    eng, chunks = make_engine(ctx, B, first_stream=rank * B, window=window)
-    hop, seg = ctx.hop, eng.seg
-    codes = torch.empty(B, seg, dtype=torch.int32, device="cuda")
-    mel_out = torch.empty(B, seg, 80, device="cuda")
-    wav = torch.empty(B, seg * hop, device="cuda")
+    run = Runner(ctx, wl, B, rank, world, args.arith, comm=os.environ.get("CONAN_BENCH_COMM", "0") == "1")
+    arith = run.arith                     # what the library resolved `auto` to: the form `value` is measured in
+    hop, seg = run.hop, run.seg
 
-    # Throughput leg, stateful workloads: pipelined steps (conan_step_async) - the front-end of chunk t+1 overlaps the
-    # vocoder of chunk t on the library's two internal HIP streams.  Audio goes to a small ring of buffers; with more
-    # than one rank the RCCL gather of chunk t runs on its own stream so that it does not serialise the pipeline either
-    # (conan_amd.engine.AudioGatherRing; CONAN_BENCH_COMM=1 exercises that choreography on a single rank).
-    # Windowed workloads: one blocking windowed step (Emformer step, reset, decoder + vocoder over window + chunk frames).
-    from conan_amd.engine import AudioGatherRing
-    ring = AudioGatherRing(lambda: torch.empty_like(wav), world, rank, nb=4, always=os.environ.get("CONAN_BENCH_COMM", "0") == "1")
-    hist = [torch.randint(0, 100, (B, window), dtype=torch.int32, device="cuda")] if window else None
-
-    def step(j):
-        if not window:      # only the vocoder stage of the step waits for the gather that last read this buffer
-            buf, fence = ring.acquire(j, fence=True)
-            eng.st.step_async(eng.slots, chunks[j % len(chunks)], buf, emit=seg, codes=codes, mel_out=mel_out, out_fence=fence)
-            ring.submit(j, join=eng.st.join)
-            return
-        buf = ring.acquire(j)
-        if window:
-            c, w = eng.windowed_step(chunks[j % len(chunks)], hist[0])
-            hist[0] = torch.cat([hist[0][:, seg:], c], 1)
-            buf.copy_(w)
-            ring.submit(j, wait_current=True)
-        else:
-            eng.st.step_async(eng.slots, chunks[j % len(chunks)], buf, emit=seg, codes=codes, mel_out=mel_out)
-            ring.submit(j, join=eng.st.join)
-
-    def barrier():
-        if not window:
-            eng.st.join()
-        ring.drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    j = 0
-    for _ in range(args.warmup):
-        step(j); j += 1
-    barrier()
-    if args.marks:
-        eng.st.profile_mark()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(j); j += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if args.marks:
-        eng.st.profile_mark()
-        torch.cuda.synchronize()
-    # Every rank's own clock, its device, and a check of the exchange: the audio rank 0 gathered for the LAST timed step must
+    dt = run.timed(args.steps, args.warmup, marks=args.marks)
+    j = run.j
+    # Every rank's own clock, its device, and a check of the exchange: the audio rank 0 gathered for the LAST gathered step must
     # be, bit for bit, what each rank produced for it (one all_gather of integer checksums, outside the timed region).
-    dt_local = dt
+    ring = run.ring
     ranks = None
-    last = ring.bufs[(j - 1) % ring.nb]
+    gj = ring.last_gathered if ring.last_gathered is not None else j - 1
+    last = ring.last_sent if ring.last_sent is not None else ring.bufs[gj % ring.nb]      # what this rank handed to the last gather
     csum = last.view(torch.int32).to(torch.int64).sum().reshape(1)            # order-independent, exact
     if world > 1:
-        mine = torch.tensor([dt_local, float(torch.cuda.current_device())], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([dt, float(torch.cuda.current_device())], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         sums = [torch.zeros_like(csum) for _ in range(world)]
@@ -341,77 +398,38 @@ def main():
                      "ms_per_step_per_rank": [float(r[0].item()) / args.steps * 1e3 for r in allr],
                      "ms_per_step_min": min(float(r[0].item()) for r in allr) / args.steps * 1e3,
                      "ms_per_step_max": max(float(r[0].item()) for r in allr) / args.steps * 1e3,
-                     "gather_check": {"step": j - 1, "ok": got == want, "checksums_rank0_gathered": got, "checksums_ranks_own": want}}
+                     "gathers": ring.submitted, "gather_every": ring.every,
+                     "gather_check": {"step": gj, "ok": got == want, "checksums_rank0_gathered": got, "checksums_ranks_own": want}}
             if got != want:
                 raise SystemExit("bench.py: the audio gathered on rank 0 differs from what the ranks produced: %r vs %r" % (got, want))
     else:
         ranks = {"rccl_world": 1, "backend": None, "devices": [torch.cuda.current_device()], "device_name": torch.cuda.get_device_name(),
                  "ms_per_step_per_rank": [dt / args.steps * 1e3], "ms_per_step_min": dt / args.steps * 1e3, "ms_per_step_max": dt / args.steps * 1e3,
-                 "gather_check": ({"step": j - 1, "ok": True, "note": "single rank: the gather path (CONAN_BENCH_COMM=1) hands rank 0 its own buffer",
+                 "gathers": ring.submitted, "gather_every": ring.every,
+                 "gather_check": ({"step": gj, "ok": True, "note": "single rank: the gather path (CONAN_BENCH_COMM=1) hands rank 0 its own buffer",
                                    "checksums_ranks_own": [int(csum.item())]} if ring.active else None)}
     ms_step = dt / args.steps * 1e3
 
-    # Distribution of the step time (outside the timed region, same schedule): the library stamps the completion of every
-    # pipelined step with a timing event on its own vocoder stream (conan_step_clock) - no extra stream, no extra wait;
-    # windowed workloads run blocking steps, whose host-timed latencies are the distribution (latency_stats).
     step_stats = None
     if not args.marks and not window:
-        ns = min(max(args.steps, 2), 60)
-        eng.st.step_clock(ns + 1)
-        for _ in range(ns + 1):
-            step(j); j += 1
-        barrier()
-        iv = sorted(eng.st.step_clock_read())
-        eng.st.step_clock(0)
-        if iv:
-            step_stats = {"n": len(iv), "mean_ms": statistics.fmean(iv), "sigma_ms": statistics.pstdev(iv), "p50_ms": statistics.median(iv),
-                          "p95_ms": iv[min(len(iv) - 1, int(round(0.95 * (len(iv) - 1))))], "min_ms": iv[0], "max_ms": iv[-1],
-                          "how": "intervals between consecutive step completions (timing events on the library's vocoder stream), a separate run of pipelined steps after the timed region"}
+        step_stats = run.step_intervals(min(max(args.steps, 2), 60))
     frames_per_step = (window + seg) if window else seg           # decoder / vocoder frames computed per stream per step
-
-    def one_blocking_step(e, ch, c_, m_, w_, h_):
-        if window:
-            cc, ww = e.windowed_step(ch, h_[0])
-            h_[0] = torch.cat([h_[0][:, seg:], cc], 1)
-        else:
-            e.st.step(e.slots, ch, emit=seg, codes=c_, mel_out=m_, wav_out=w_)
 
     roof = b1 = cpu = fe = None
     p50 = lat_stats = None
     if not args.marks:
-        # per-chunk latency: one step for all B streams, host submit -> audio complete on device
-        lats = []
-        for _ in range(args.latency_steps):
-            torch.cuda.synchronize()
-            a = time.perf_counter()
-            one_blocking_step(eng, chunks[j % len(chunks)], codes, mel_out, wav, hist); j += 1
-            torch.cuda.synchronize()
-            lats.append((time.perf_counter() - a) * 1e3)
-        p50 = statistics.median(lats)
-        lat_stats = {"n": len(lats), "p50_ms": p50, "p95_ms": sorted(lats)[min(len(lats) - 1, int(round(0.95 * (len(lats) - 1))))],
-                     "sigma_ms": statistics.pstdev(lats), "min_ms": min(lats), "max_ms": max(lats)}
+        lat_stats = run.latencies(args.latency_steps)
+        p50 = lat_stats["p50_ms"]
 
     if rank == 0 and not args.marks:
         # roofline of the dominant kernel: HIP events around every launch of the matrix kernels on their stream
-        nprof = 5
-        torch.cuda.synchronize()
-        eng.st.profile_begin()
-        for _ in range(nprof):
-            one_blocking_step(eng, chunks[j % len(chunks)], codes, mel_out, wav, hist); j += 1
-        conv_ms, conv_flops, conv_launches = eng.st.profile_end()
-        # the dominant kernel = the instantiation with the largest summed time
-        kernels = sorted(eng.st.profile_kernels(), key=lambda r: -r[1])
-        # The dominant kernel = the kernel (template) with the largest summed time; its instantiations (tile shapes per
-        # vocoder stage) are listed separately in `matrix_kernels`, the single instantiation with the largest summed
-        # time in `largest_instantiation`.
-        fams = {}
-        for kn, ms_, fl_, n_ in kernels:
-            f = fams.setdefault(kn.split("<")[0], [0.0, 0.0, 0, []])
-            f[0] += ms_; f[1] += fl_; f[2] += n_; f[3].append(kn)
-        name, (k_ms, k_fl, k_n, insts) = max(fams.items(), key=lambda kv: kv[1][0])
-        ach = k_fl / (k_ms * 1e-3) / 1e12
-        fam = conv_flops / (conv_ms * 1e-3) / 1e12
-        pmc, pmc_src, pmc_stale = pmc_summary(args.workload)
+        prof = run.kernel_profile()
+        nprof, kernels = prof["nprof"], prof["kernels"]
+        dom = dominant(prof)
+        name, ach = dom["kernel"], dom["achieved"]
+        fam = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
+        tag = args.workload + ("" if args.arith == "auto" else "_" + args.arith)
+        pmc, pmc_src, pmc_stale = pmc_summary(tag)
         traffic = step_bytes = mfma_busy = None
         if pmc:
             hit = [v for k, v in pmc.get("kernels", {}).items() if name in k]
@@ -423,7 +441,8 @@ def main():
             step_bytes = pmc.get("bytes_per_step")
         flops_step = B * frames_per_step * GFLOP_PER_FRAME * 1e9
         bytes_alg = WEIGHT_BYTES_PER_STEP + B * STATE_BYTES_PER_STREAM * (frames_per_step / seg)
-        k_peak, k_peak_basis = kernel_peak(name)
+        k_peak, k_peak_basis = dom["peak"], dom["peak_basis"]
+        step_tflops = flops_step / (ms_step * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": k_peak, "unit": "TFLOP/s",
                 "frac": ach / k_peak, "peak_basis": k_peak_basis, "frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 # limb kernels: the bf16 FLOP/s the MFMAs execute (6 per algorithmic FLOP) against the bf16 dense peak - the same fraction
@@ -431,23 +450,43 @@ def main():
                 "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None,
                 "traffic_stale": pmc_stale if traffic is not None else None, "lib_sha256": lib_sha256(),
                 "mfma_busy_frac_pmc": mfma_busy,
-                "kernel": name, "instantiations": insts, "launches_per_step": k_n / nprof, "avg_launch_us": k_ms * 1e3 / k_n,
+                "kernel": name, "arith": arith, "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
+                "gflop_per_launch": dom["gflop_per_launch"], "kernel_ms_per_step": dom["ms_per_step"], "share_of_step_time": dom["ms_per_step"] / ms_step,
+                # scalar companions of the headline (flat, so that they survive parsers that keep only scalars)
+                "ms_per_step": ms_step, "p50_latency_ms": p50, "p95_latency_ms": lat_stats["p95_ms"] if lat_stats else None,
+                "step_interval_p50_ms": step_stats["p50_ms"] if step_stats else None, "step_interval_p95_ms": step_stats["p95_ms"] if step_stats else None,
+                "step_gflop_algorithmic": flops_step / 1e9, "step_tflops": step_tflops,
+                "step_mfma_frac": step_tflops / PEAK_F32_MFMA_TFLOPS, "step_mfma_frac_basis": "whole step's algorithmic FLOP/s over the f32 MFMA dense peak (157.3): the decoder and Emformer compute on it in both forms",
+                "hbm_bytes_per_step_algorithmic": bytes_alg, "hbm_bytes_per_step_counter": step_bytes,
+                "hbm_counter_source": pmc_src if step_bytes is not None else None,
+                "hbm_GBps_algorithmic": bytes_alg / (ms_step * 1e-3) / 1e9, "hbm_frac_algorithmic": bytes_alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "hbm_GBps_counter": (step_bytes / (ms_step * 1e-3) / 1e9) if step_bytes else None, "hbm_peak_GBps": PEAK_HBM_GBS,
+                "all_matrix_kernels_ms_per_step": prof["conv_ms"] / nprof, "all_matrix_kernels_tflops": fam,
+                "all_matrix_kernels_launches_per_step": prof["conv_launches"] / nprof,
+                arith + "_ms_per_step": ms_step, arith + "_frac": ach / k_peak, arith + "_kernel": name, arith + "_peak": k_peak,
+                "instantiations": dom["instantiations"],
                 "largest_instantiation": {"kernel": kernels[0][0], "ms_per_step": kernels[0][1] / nprof, "tflops": kernels[0][2] / (kernels[0][1] * 1e-3) / 1e12},
-                "gflop_per_launch": k_fl / k_n / 1e9, "share_of_step_time": (k_ms / nprof) / ms_step,
                 "matrix_kernels": [{"kernel": kn, "launches_per_step": n_ / nprof, "us_per_launch": ms_ * 1e3 / n_, "ms_per_step": ms_ / nprof,
                                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "peak": kernel_peak(kn)[0], "frac": fl_ / (ms_ * 1e-3) / 1e12 / kernel_peak(kn)[0],
-                                    "frac_of_f32_mfma_peak": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS} for kn, ms_, fl_, n_ in kernels],
-                "all_matrix_kernels": {"achieved": fam, "frac": fam / PEAK_F32_MFMA_TFLOPS, "launches_per_step": conv_launches / nprof,
-                                       "ms_per_step": conv_ms / nprof, "gflop_per_frame_per_stream": conv_flops / nprof / B / frames_per_step / 1e9},
-                # the whole step against both rooflines (report both, the binding one is the larger fraction)
-                "step": {"gflop_algorithmic": flops_step / 1e9, "tflops": flops_step / (ms_step * 1e-3) / 1e12,
-                         "mfma_frac": flops_step / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-                "hbm": {"bytes_algorithmic": bytes_alg, "bytes_counter": step_bytes, "source": pmc_src if step_bytes is not None else None,
-                        "GB/s": bytes_alg / (ms_step * 1e-3) / 1e9, "frac": bytes_alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                        "counter_GB/s": (step_bytes / (ms_step * 1e-3) / 1e9) if step_bytes else None, "peak": PEAK_HBM_GBS}}
+                                    "frac_of_f32_mfma_peak": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS} for kn, ms_, fl_, n_ in kernels]}
+        # The other arithmetic form of the same workload, same process, same timing code (the library default is what `value`
+        # measures; this is the comparison point): its step time, its dominant kernel against that kernel's own peak.
+        if world == 1 and not args.no_other and not window and not args.streams:
+            other = "f32" if arith == "limb" else "limb"
+            try:
+                o = Runner(ctx, wl, B, rank, world, other)
+                o_dt = o.timed(args.steps, args.warmup)
+                o_lat = o.latencies(max(10, args.latency_steps // 2))
+                od = dominant(o.kernel_profile())
+                o.close()
+                roof.update({other + "_ms_per_step": o_dt / args.steps * 1e3, other + "_frac": od["achieved"] / od["peak"], other + "_kernel": od["kernel"],
+                             other + "_peak": od["peak"], other + "_achieved": od["achieved"], other + "_peak_basis": od["peak_basis"],
+                             other + "_p50_latency_ms": o_lat["p50_ms"], other + "_kernel_ms_per_step": od["ms_per_step"]})
+            except Exception as e:  # noqa: BLE001  (the comparison point must not hide the headline measurement)
+                roof[other + "_error"] = f"{type(e).__name__}: {e}"
         # batch=1 latency configuration (BASELINE.json configs[1]) beside the throughput one
         if args.workload == "b64" and not args.streams and not args.no_b1:
-            e1, ch1 = make_engine(ctx, 1, first_stream=100000)
+            e1, ch1 = make_engine(ctx, 1, first_stream=100000, arith=args.arith)
             c1 = torch.empty(1, seg, dtype=torch.int32, device="cuda")
             m1 = torch.empty(1, seg, 80, device="cuda")
             w1 = torch.empty(1, seg * hop, device="cuda")
@@ -461,6 +500,7 @@ def main():
                     l1.append((time.perf_counter() - a) * 1e3)
             b1 = {"workload": WORKLOADS["b1"]["desc"], "p50_latency_ms": statistics.median(l1),
                   "chunks_per_s": 1e3 / statistics.median(l1)}
+            roof["latency_b1_ms"] = b1["p50_latency_ms"]
             e1.st.close()
         # the step before the path: GPU mel front-end rate for B x 3 s of audio (not part of `value`)
         try:
@@ -486,28 +526,24 @@ def main():
             "metric": "chunks/sec (%d ms chunk, 16 kHz), all streams summed; p50 per-chunk latency beside it" % wl["chunk_ms"],
             "value": total_chunks / dt, "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 via 3\u00d7bf16 limbs, f32 accumulate" if limb else "f32", "data": "synthetic",
+            "dtype": DTYPE[arith], "data": "synthetic",
             "config": {"workload": wl["desc"] if not args.streams else f"batch={B} streams per GPU, {wl['chunk_ms']} ms chunk" + (", windowed" if window else ", stateful"),
-                       "name": args.workload, "baseline_config": wl["config"],
+                       "name": args.workload, "baseline_config": wl["config"], "arith": arith, "arith_requested": args.arith,
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
                        "architecture": "egs/conan_emformer.yaml + egs/hifi_16k320_shuffle.yaml shapes, random-init weights",
                        "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1"},
             "p50_latency_ms": p50, "latency_stats": lat_stats, "step_time_stats": step_stats, "ranks": ranks,
             "schedule": ("throughput and latency: one blocking windowed step" if window else
-                         "throughput: pipelined steps (front-end of chunk t+1 overlaps the vocoder of chunk t on two HIP streams); latency: one blocking fused step"),
+                         "throughput: pipelined steps (the three stages of consecutive chunks overlap on three HIP streams); latency: one blocking fused step"),
             "realtime_streams_supported": (total_chunks / dt) / (1000.0 / wl["chunk_ms"]),
             "roofline": roof, "cpu_baseline": cpu,
         }
-        # the default line is the exact-f32 one; the bf16-limb datapoint of the same workload rides along (a child process: the
-        # arithmetic switch is per stream-set, and its own roofline needs its own profiling pass)
-        if args.workload == "b64" and world == 1 and not args.streams and not args.no_b1 and not args.marks:
-            out["bf16x3_datapoint"] = limb_datapoint(args.steps, args.warmup)
         if b1 is not None:
             out["latency_b1"] = b1
         if fe is not None:
             out["frontend"] = fe
         print(json.dumps(out))
-    eng.st.close()
+    run.close()
     if world > 1:
         dist.destroy_process_group()
 

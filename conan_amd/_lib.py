@@ -12,9 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conan_hip.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_UPS, MAX_RESBLOCKS, MAX_DILATIONS, MAX_DEC_BLOCKS = 8, 4, 4, 16
 MODEL_EMFORMER, MODEL_CONAN, MODEL_HIFIGAN = 1, 2, 4
+
+ARITH_AUTO, ARITH_F32, ARITH_LIMB = 0, 1, 2
+ARITH_NAMES = {"auto": ARITH_AUTO, "f32": ARITH_F32, "limb": ARITH_LIMB}
 
 OK, ERR_INVALID, ERR_MISSING, ERR_SHAPE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
@@ -38,6 +41,11 @@ class ConanCfg(C.Structure):
         ("emf_max_memory_size", C.c_int32), ("emf_tanh_on_mem", C.c_int32)]
 
 
+class StreamsOpts(C.Structure):
+    """conan_streams_opts (include/conan_hip.h)."""
+    _fields_ = [("abi_version", C.c_int32), ("arith", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
 class ConanError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libconan_hip error {code}: {msg}")
@@ -52,6 +60,8 @@ _PROTOS = {
     "conan_ctx_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "conan_ctx_finalize": (C.c_int, [C.c_void_p]),
     "conan_streams_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "conan_streams_create_opts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StreamsOpts), C.POINTER(C.c_void_p)]),
+    "conan_streams_arith": (C.c_int, [C.c_void_p]),
     "conan_streams_destroy": (C.c_int, [C.c_void_p]),
     "conan_streams_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "conan_set_reference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -71,6 +81,7 @@ _PROTOS = {
     "conan_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_streams_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_streams_output_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "conan_streams_test_fault": (C.c_int, [C.c_void_p, C.c_int]),
     "conan_profile_mark": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_step_clock": (C.c_int, [C.c_void_p, C.c_int]),
     "conan_step_clock_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
@@ -139,7 +150,7 @@ class DecoderTaps(C.Structure):
 
 class HifiganTaps(C.Structure):
     """conan_hifigan_taps (include/conan_hip.h)."""
-    _fields_ = [("conv_pre_act", C.c_void_p), ("ups", C.c_void_p * MAX_UPS)]
+    _fields_ = [("conv_pre_act", C.c_void_p), ("ups", C.c_void_p * MAX_UPS), ("stage_out", C.c_void_p * MAX_UPS)]
 
 
 def make_cfg(conan_hp=None, hifigan_hp=None, emformer=True, conan=True, hifigan=True):

@@ -112,8 +112,25 @@ int conan_ctx_finalize(conan_ctx* ctx) {
 }
 
 int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, conan_streams** out) {
+  return conan_streams_create_opts(ctx, max_slots, max_frames, max_ref_frames, nullptr, out);
+}
+
+int conan_streams_arith(const conan_streams* s) {
+  if (!s) { g_err = "null streams"; return CONAN_ERR_INVALID; }
+  return s->rb_limb ? CONAN_ARITH_LIMB : CONAN_ARITH_F32;
+}
+
+int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, const conan_streams_opts* opts,
+                              conan_streams** out) {
   return guarded([&] {
     if (!ctx || !out) throw Error(CONAN_ERR_INVALID, "null argument");
+    int arith = CONAN_ARITH_AUTO;
+    if (opts) {
+      if (opts->abi_version != CONAN_HIP_ABI_VERSION) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.abi_version mismatch");
+      for (int r : opts->reserved) if (r != 0) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.reserved must be 0");
+      arith = opts->arith;
+      if (arith != CONAN_ARITH_AUTO && arith != CONAN_ARITH_F32 && arith != CONAN_ARITH_LIMB) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.arith: 0 (auto), 1 (f32) or 2 (limb)");
+    }
     if (!ctx->finalized) throw Error(CONAN_ERR_STATE, "conan_ctx_finalize must run before conan_streams_create");
     if (max_slots < 1 || max_frames < 1) throw Error(CONAN_ERR_INVALID, "max_slots / max_frames");
     HIP_CHECK(hipSetDevice(ctx->device));
@@ -130,14 +147,28 @@ int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_
       { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
       { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
       s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
-      // fp32 products of the vocoder's matrix kernels as six bf16 limb products (resblock_limb.hip, conv_limb.hip): opt-in - the
-      // default is the exact-f32 MFMA everywhere (CONAN_RB_NOLIMB=1 wins over CONAN_RB_LIMB=1)
-      s->rb_limb = getenv("CONAN_RB_LIMB") != nullptr && getenv("CONAN_RB_NOLIMB") == nullptr;
+      // fp32 products of the vocoder's matrix kernels as six bf16 limb products (resblock_limb.hip, conv_limb.hip) or on the
+      // f32-input MFMA: conan_streams_opts.arith.  AUTO = the limb form wherever the context packed limb weights (ResBlock1
+      // vocoders); the developer switch CONAN_RB_NOLIMB=1 turns AUTO into F32 for A/B runs - it never overrides an explicit request.
+      if (arith == CONAN_ARITH_LIMB && !((ctx->cfg.models & CONAN_MODEL_HIFIGAN) && ctx->has_limb_weights))
+        throw Error(CONAN_ERR_UNSUPPORTED, "arith = limb: this context holds no bf16-limb weights (no HiFi-GAN model, or a vocoder configuration without limb kernels)");
+      s->arith_auto = arith == CONAN_ARITH_AUTO;
+      s->rb_limb = arith == CONAN_ARITH_LIMB || (arith == CONAN_ARITH_AUTO && ctx->has_limb_weights && getenv("CONAN_RB_NOLIMB") == nullptr);
       { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
       { const char* e = getenv("CONAN_DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
       { const char* e = getenv("CONAN_MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }
+      // (a CU-masked front-end stream - developer switch - cannot hold the megakernel's grid resident: its barriers would never complete)
+      { const char* e = getenv("CONAN_FRONT_CUSTRIDE"); if (e && atoi(e) >= 2) s->use_mega = false; }
       { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
+      {  // guard block of the bounded waits: [0] code, [2..3] device address of the host-mapped copy
+        HIP_CHECK(hipHostMalloc((void**)&s->h_guard, 64, hipHostMallocMapped));
+        memset(s->h_guard, 0, 64);
+        unsigned* hdev = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer((void**)&hdev, s->h_guard, 0));
+        s->d_guard = reinterpret_cast<unsigned*>(s->alloc(16));
+        HIP_CHECK(hipMemcpy(s->d_guard + 2, &hdev, sizeof(hdev), hipMemcpyHostToDevice));
+      }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
       s->pin.init((size_t)max_slots);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
@@ -160,7 +191,7 @@ int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which
   return guarded([&] {
     if (!s || !slots) throw Error(CONAN_ERR_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, st);
     const int models = s->ctx->cfg.models & which;
@@ -183,7 +214,7 @@ int conan_set_reference(conan_streams* s, const int32_t* slots, int n, const flo
     if (!s || !slots || !ref_mel_dev || !ref_len) throw Error(CONAN_ERR_INVALID, "null argument (the reference raises ValueError when ref is None)");
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
     if (n < 1 || n > s->max_slots) throw Error(CONAN_ERR_INVALID, "slot count out of range");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_reference(slots, n, ref_mel_dev, ref_len, max_len, (hipStream_t)stream);
   });
@@ -194,7 +225,7 @@ int conan_emformer_step(conan_streams* s, const int32_t* slots, int n, const flo
   return guarded([&] {
     if (!s || !slots || !chunk_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_EMFORMER)) throw Error(CONAN_ERR_STATE, "context holds no Emformer model");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->emformer_step(n, chunk_dev, out_dev, logits_dev, codes_dev, (hipStream_t)stream);
@@ -218,7 +249,7 @@ int conan_emformer_project(conan_streams* s, const char* head, const float* x_de
     if (rows <= 0) return;
     const std::string name = std::string("emf.head.") + head;
     if (!s->ctx->convs.count(name)) throw Error(CONAN_ERR_MISSING, std::string("the Emformer checkpoint holds no output head '") + head + "'");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     hipStream_t st = (hipStream_t)stream;
     s->join(st);
     const ch::PackedConv& pc = s->ctx->conv(name);
@@ -233,7 +264,7 @@ int conan_decoder_step(conan_streams* s, const int32_t* slots, int n, int frames
     if (!s || !slots || !codes_dev || !mel_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
     if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     conan_decoder_taps taps; memset(&taps, 0, sizeof(taps));
@@ -248,7 +279,7 @@ int conan_decoder_step_taps(conan_streams* s, const int32_t* slots, int n, int f
     if (!s || !slots || !codes_dev || !mel_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
     if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     conan_decoder_taps none; memset(&none, 0, sizeof(none));
@@ -265,7 +296,7 @@ int conan_get_style(conan_streams* s, const int32_t* slots, int n, float* style_
       if (slots[i] < 0 || slots[i] >= s->max_slots) throw Error(CONAN_ERR_INVALID, "slot index out of range");
       if (!s->has_ref[slots[i]]) throw Error(CONAN_ERR_STATE, "conan_get_style before conan_set_reference");
     }
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     const int H = s->ctx->cfg.hidden_size;
     for (int i = 0; i < n; ++i) {
@@ -280,7 +311,7 @@ int conan_set_style(conan_streams* s, const int32_t* slots, int n, const float* 
   return guarded([&] {
     if (!s || !slots || !style_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     for (int i = 0; i < n; ++i)
@@ -293,7 +324,7 @@ int conan_get_prosody_ids(conan_streams* s, const int32_t* slots, int n, int32_t
   return guarded([&] {
     if (!s || !slots || !ids_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_CONAN)) throw Error(CONAN_ERR_STATE, "context holds no Conan model");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     for (int i = 0; i < n; ++i)
@@ -308,7 +339,7 @@ int conan_hifigan_step_taps(conan_streams* s, const int32_t* slots, int n, int f
     if (!s || !slots || !mel_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_HIFIGAN)) throw Error(CONAN_ERR_STATE, "context holds no HiFi-GAN model");
     if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->hifigan_step(n, frames, mel_dev, wav_out_dev, pre_tanh_dev, (hipStream_t)stream, taps);
@@ -321,7 +352,7 @@ int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames
     if (!s || !slots || !mel_dev || !wav_out_dev) throw Error(CONAN_ERR_INVALID, "null argument");
     if (!(s->ctx->cfg.models & CONAN_MODEL_HIFIGAN)) throw Error(CONAN_ERR_STATE, "context holds no HiFi-GAN model");
     if (frames < 1 || frames > s->max_frames) throw Error(CONAN_ERR_INVALID, "frames out of range");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, (hipStream_t)stream);
     s->hifigan_step(n, frames, mel_dev, wav_out_dev, pre_tanh_dev, (hipStream_t)stream);
@@ -339,7 +370,7 @@ int conan_step(conan_streams* s, const int32_t* slots, int n, int emit, const fl
     const int seg = s->ctx->cfg.emf_segment;
     if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
     hipStream_t st = (hipStream_t)stream;
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
     s->set_slots(slots, n, st);
     int* codes_seg = codes_dev ? codes_dev : s->d_codes;
@@ -371,7 +402,7 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     const int seg = s->ctx->cfg.emf_segment;
     if (emit < 1 || emit > seg) throw Error(CONAN_ERR_INVALID, "emit must be in [1, segment]");
     if (s->prof_on) throw Error(CONAN_ERR_STATE, "profiling is not available for pipelined steps");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->async_init();
     const long long t = s->async_steps;
     constexpr int NP = conan_streams::NP;
@@ -399,9 +430,13 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     if (t >= NP) HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_front[p], 0));
     int* codes_seg = s->codes_hand[p];
     // developer timing switch (results are then meaningless): CONAN_SKIP_STAGE bit 0 skips the Emformer launch, bit 1 the decoder's
+#ifdef CONAN_DEV_SWITCHES        // `make DEV=1`: timing experiments only, never in the shipped library (a skipped stage returns garbage with CONAN_OK)
     static const int skip = getenv("CONAN_SKIP_STAGE") ? atoi(getenv("CONAN_SKIP_STAGE")) : 0;
     // (the Emformer's workgroups need whole CUs for ~0.15 ms; they are kept away from the pair kernel's launches: see ev_wide)
     static const bool hold = getenv("CONAN_EMF_HOLD") != nullptr;      // (off by default: see streams.h, ev_wide)
+#else
+    constexpr int skip = 0; constexpr bool hold = false;
+#endif
     if (hold && t >= 2 && s->ev_wide[(t + NP - 2) % NP] && s->wide_marked[(t + NP - 2) % NP]) HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_wide[(t + NP - 2) % NP], 0));
     if (tl) HIP_CHECK(hipEventRecord(te[0], s->st_emf));
     if (!(skip & 1)) s->emformer_step(n, mel_chunk_dev, nullptr, nullptr, codes_seg, s->st_emf);
@@ -447,7 +482,7 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
 int conan_step_clock(conan_streams* s, int capacity) {
   return guarded([&] {
     if (!s || capacity < 0 || capacity > 4096) throw Error(CONAN_ERR_INVALID, "conan_step_clock: capacity in [0, 4096]");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     while ((int)s->clock_ev.size() < capacity) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); s->clock_ev.push_back(e); }
     s->clock_on = capacity > 0; s->clock_n = 0;
   });
@@ -456,7 +491,7 @@ int conan_step_clock(conan_streams* s, int capacity) {
 int conan_step_timeline(conan_streams* s, int capacity) {
   return guarded([&] {
     if (!s || capacity < 0 || capacity > 1024) throw Error(CONAN_ERR_INVALID, "conan_step_timeline: capacity in [0, 1024]");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     while ((int)s->tl_ev.size() < capacity * 6) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); s->tl_ev.push_back(e); }
     s->tl_on = capacity > 0; s->tl_n = 0;
   });
@@ -494,6 +529,14 @@ int conan_step_clock_read(conan_streams* s, double* ms_out, int cap) {
   return rc < 0 ? rc : cnt;
 }
 
+int conan_streams_test_fault(conan_streams* s, int kind) {
+  return guarded([&] {
+    if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
+    if (kind < 0 || kind > 3) throw Error(CONAN_ERR_INVALID, "conan_streams_test_fault: kind 0 (off), 1 (decoder megakernel barrier), 2 (Emformer cluster exchange) or 3 (pair kernel flags)");
+    s->test_fault = kind;
+  });
+}
+
 int conan_streams_output_fence(conan_streams* s, void* fence_stream) {
   return guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
@@ -504,7 +547,7 @@ int conan_streams_output_fence(conan_streams* s, void* fence_stream) {
 int conan_streams_join(conan_streams* s, void* stream) {
   return guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     s->join((hipStream_t)stream);
   });
 }
@@ -566,7 +609,7 @@ int conan_profile_kernel(conan_streams* s, int index, char* name, int name_cap, 
 int conan_profile_mark(conan_streams* s, void* stream) {
   return guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
-    HIP_CHECK(hipSetDevice(s->ctx->device));
+    HIP_CHECK(hipSetDevice(s->ctx->device)); s->check_fault();
     cnk::launch_profile_mark((hipStream_t)stream);
   });
 }

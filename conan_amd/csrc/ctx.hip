@@ -106,6 +106,7 @@ void conan_ctx::pack_conv(const std::string& name, const std::vector<float>& W, 
       std::vector<float> bits(lim.size() / 2);
       memcpy(bits.data(), lim.data(), bits.size() * 4);
       pc.wl = upload(bits);
+      has_limb_weights = true;
     }
   }
   convs[name] = pc;
@@ -228,6 +229,7 @@ void conan_ctx::pack_fragments(const std::string& name, const std::string& prefi
     std::vector<float> bits(lim.size() / 2);
     memcpy(bits.data(), lim.data(), bits.size() * 4);
     vecs[name + ".wl"] = upload(bits);
+    has_limb_weights = true;
   }
 }
 

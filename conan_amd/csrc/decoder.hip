@@ -114,6 +114,12 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
       else { e->group_size = mega_gs; e->groups = std::max(1, std::min(njobs, mega_grid / mega_gs)); }
       e->nops = (int)ops.size(); e->barriers = nb; e->flops = mega_rec_flops;
       e->lds_bytes = mega_rec_lds * 4;
+      // the arrival-counter barriers need every workgroup of the grid resident at once: never launch more than the device can hold
+      // (a quarter of the CUs is kept as margin for what else is resident); such a step keeps its separate launches
+      const long long cap = (long long)cnk::decoder_mega_blocks_per_cu(e->lds_bytes) * (ctx->num_cu - ctx->num_cu / 4);
+      if ((long long)e->groups * e->group_size > cap) e->ok = false;
+    }
+    if (e->ok) {
       HIP_CHECK(hipEventSynchronize(e->copied));            // (the entry's previous upload, if any, has long completed)
       memcpy(e->pinned, ops.data(), sizeof(cnk::MegaOp) * ops.size());
       HIP_CHECK(hipMemcpyAsync(e->dev, e->pinned, sizeof(cnk::MegaOp) * ops.size(), hipMemcpyHostToDevice, st));

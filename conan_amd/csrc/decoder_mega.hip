@@ -54,12 +54,16 @@ __device__ __forceinline__ T mg_args(const void* p) {
 }
 
 // arrival counter + sc1 polling; `target` is the count at which every participant has arrived
-__device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target) {
+__device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target, unsigned* guard) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's (write-through) stores have left ...
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before the workgroup's one arrival
-    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
+    SpinGuard sg;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+      __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
+      if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;        // (bounded: kernels.h, SpinGuard)
+    }
   }
   __syncthreads();
 }
@@ -68,7 +72,7 @@ __device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target)
 __global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS,
                                                               const int* __restrict__ slots, const int* __restrict__ pos, const int n, const int T,
                                                               unsigned* __restrict__ gbar, unsigned* __restrict__ bar, const unsigned bar_base,
-                                                              unsigned long long* __restrict__ dbg) {
+                                                              unsigned long long* __restrict__ dbg, unsigned* __restrict__ guard) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   ro::RowTab& tab = *reinterpret_cast<ro::RowTab*>(lds_all);
   float* const lds = lds_all + ro::ROWTAB_FLOATS;
@@ -144,12 +148,12 @@ __global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __re
         } break;
         default: break;           // (MOP_ADVANCE: behind the grid barrier below)
       }
-      if (barrier && type != MOP_ADVANCE) { gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget); }
+      if (barrier && type != MOP_ADVANCE) { gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget, guard); }
       if (dbg && b == 0 && threadIdx.x == 0 && job == g) dbg[1 + o] = __builtin_amdgcn_s_memrealtime();
     }
   }
   // every job is done: advance the frame counters (the operators above read them), re-arm the group counters
-  mg_barrier(bar, bar_base + (unsigned)gridDim.x);
+  mg_barrier(bar, bar_base + (unsigned)gridDim.x, guard);
   if (b == 0) {
     for (int o = 0; o < nops; ++o) {
       mg_cci hdr = (mg_cci)(prog + o);
@@ -171,9 +175,16 @@ int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats) {
   }
 }
 
+// workgroups of the megakernel that one CU can hold at once with `lds_bytes` of dynamic LDS (its barriers need the whole grid resident)
+int decoder_mega_blocks_per_cu(int lds_bytes) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel, 256, (size_t)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return nb;
+}
+
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st) {
   hipLaunchKernelGGL(decoder_mega_kernel, dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                     m.gbar, m.bar, m.bar_base, m.dbg);
+                     m.gbar, m.bar, m.bar_base, m.dbg, m.guard);
 }
 
 }  // namespace cnk

@@ -582,7 +582,12 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       ef_barrier();
       if (tid == 0) __hip_atomic_store(fl + member, xtarget, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag goes out
       if (tid < cs) {
-        while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xtarget) __builtin_amdgcn_s_sleep(2);
+        SpinGuard sg;
+        const unsigned want = xtarget + a.fault;          // (fault != 0: test hook, a value nobody writes)
+        while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+          __builtin_amdgcn_s_sleep(2);
+          if (spin_expired(sg, a.guard, WAIT_EMF_CLUSTER)) break;     // (bounded: kernels.h, SpinGuard)
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

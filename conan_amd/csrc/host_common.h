@@ -86,6 +86,7 @@ struct conan_ctx {
   int64_t weight_bytes = 0;
   int hop = 1;
   int num_cu = 256;
+  bool has_limb_weights = false;   // finalize packed bf16-limb copies of the vocoder's conv weights (resblock_limb.hip / conv_limb.hip)
 
   float* dev_alloc(size_t floats, bool zero = true);
   float* upload(const std::vector<float>& v);

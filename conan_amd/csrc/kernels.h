@@ -21,6 +21,34 @@ struct TRef {
 
 enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4 };
 
+// Bounded cross-workgroup waits.  Three kernels wait for other workgroups of their own launch (decoder_mega: group / grid
+// barriers; emformer_fused: cluster exchange; resblock_pair: partner flags and the tile mailbox).  Forward progress rests on
+// dispatch-order arguments; should one ever be violated, a waiter must not spin for ever - a hung GPU takes the
+// whole box down.  Every such poll loop therefore carries a budget: after kSpinBudgetTicks of the 100 MHz s_memrealtime clock
+// (50 ms; a healthy wait is microseconds) the waiter writes a code into the stream-set's guard block and LEAVES the wait (the
+// launch then finishes with meaningless results); other waiters see the code and leave too.  The host reads the code through a
+// host-mapped word at the next stream-ordered entry point and returns CONAN_ERR_HIP from then on (conan_streams::check_fault).
+//   guard[0]     error code, device memory (agent scope): 0 = healthy
+//   guard[2..3]  address of the host-mapped word the code is copied to
+// The clock is read only every 256th poll iteration, and not at all by waits that end earlier.
+constexpr unsigned long long kSpinBudgetTicks = 5000000ull;
+enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4 };
+struct SpinGuard { unsigned long long t0 = 0; unsigned it = 0; };
+#if defined(__HIPCC__)
+// true: give up (budget spent, or another wait of this stream-set already failed)
+__device__ __forceinline__ bool spin_expired(SpinGuard& g, unsigned* guard, unsigned code) {
+  if ((++g.it & 255u) != 0u || guard == nullptr) return false;
+  if (__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+  const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+  if (g.t0 == 0) { g.t0 = now; return false; }
+  if (now - g.t0 < kSpinBudgetTicks) return false;
+  __hip_atomic_store(guard, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned* host = *reinterpret_cast<unsigned* const*>(guard + 2);
+  if (host) __hip_atomic_store(host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return true;
+}
+#endif
+
 // Causal / shifted 1-D convolution as an implicit GEMM on the f32 MFMA:
 //   y[i][t][co] = epilogue( sum_{j<ktaps} sum_{ci<Cin} W[j][ci][co] * f(x[i][t + j*dil - pad_left][ci]) )
 //   f(v)        = in_act(v)   (LeakyReLU only; the hot layers read tensors their producer stored activated)
@@ -177,6 +205,8 @@ struct RPArgs {
   unsigned* xflag; unsigned* mbox; unsigned* xcount;   // [pairs][8] flags, [pairs][4] tile mailboxes, [pairs][2] tile counts: zero at creation
   int nprob, n, T;                    // branches, slots, rows per slot (<= 32)
   float slope;
+  unsigned* guard;                    // SpinGuard block of the stream-set (nullptr: unbounded waits)
+  int fault;                          // test hook (conan_streams_test_fault): member 1 never posts its partial sums' flags
 };
 bool resblock_pair_supported(int C, int kmax, int span_max, int T);
 size_t resblock_pair_xb_floats(int num_cu);
@@ -315,6 +345,8 @@ struct EmfFusedArgs {
   unsigned* xflag;        // [cluster][EMF_MAX_LAYERS][EMF_MAX_CLUSTER] "partial of this launch is written" (= epoch + 1)
   unsigned* xepoch;       // [cluster] launches this cluster has taken part in
   int fenced;             // 1: release / acquire fences around the exchange as well (CONAN_FENCED=1 cross-check)
+  unsigned* guard;        // SpinGuard block of the stream-set (nullptr: unbounded waits)
+  unsigned fault;         // test hook (conan_streams_test_fault): the cluster waits for a flag value nobody writes
   // memory bank (max_memory_size = M > 0): per layer the PROJECTED key / value rows of the last memory inputs, rings of MB >= M + 1
   // (power of two) entries per slot; entry of segment number j in row j % MB
   int M, MB, tanh_on_mem;
@@ -387,6 +419,7 @@ struct MegaOp {
   union U { RowConvArgs rc; LNArgs ln; XAttnArgs xa; PitchHeadArgs ph; EmbedArgs em; MegaCopy cp; MegaAdvance adv; } u;
 };
 int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats);
+int decoder_mega_blocks_per_cu(int lds_bytes);
 // prog: device copy of nops operators.  njobs 16-row tiles are dealt over `groups` groups of `group_size` workgroups; kw4: the
 // step is one tile and its strips are 16 columns with the K loop split over a workgroup's waves.  gbar: one zero-initialised
 // counter per group, 16 words apart; bar: the grid barrier's counter, counts for ever - bar_base is its value before this
@@ -395,6 +428,7 @@ struct MegaLaunch {
   const MegaOp* prog; int nops, njobs, groups, group_size, kw4, lds_bytes;
   const int* slots; const int* pos; int n, T;
   unsigned* gbar; unsigned* bar; unsigned bar_base; unsigned long long* dbg;
+  unsigned* guard;        // SpinGuard block of the stream-set (nullptr: unbounded waits)
 };
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st);
 

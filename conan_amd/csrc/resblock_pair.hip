@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_kernel(const RPArgs a) {
         rp_xstore4(xb_r, (((par * 2 + (1 - h)) * RO + r) * CH + q32 * 4) * 4, snd);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's partial sums are out ...
-      if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(seq, fl_r, (h * 4 + hw) * 4, 0, RP_SC1);    // ... before its flag (the partner's wave hw reads exactly these rows)
+      if (lane == 0 && !(a.fault && h == 1)) __builtin_amdgcn_raw_buffer_store_b32(seq, fl_r, (h * 4 + hw) * 4, 0, RP_SC1);    // ... before its flag (the partner's wave hw reads exactly these rows)
     };
     auto out_store = [&]() __attribute__((always_inline)) {
       const float4 ob2 = rp_gload4(ob2p);
@@ -288,7 +288,13 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_kernel(const RPArgs a) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) ores[u] = r0 + 8 * u < T ? rp_gload4(oxb + (long long)((oxr0 + (unsigned)(r0 + 8 * u)) & oxm) * C + h * CH + q32 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       // the partner's wave hw has written the rows this wave finishes
-      while ((int)(__builtin_amdgcn_raw_buffer_load_b32(fl_r, ((1 - h) * 4 + hw) * 4, 0, RP_SC1) - oseq) < 0) __builtin_amdgcn_s_sleep(4);
+      {
+        SpinGuard sg;
+        while ((int)(__builtin_amdgcn_raw_buffer_load_b32(fl_r, ((1 - h) * 4 + hw) * 4, 0, RP_SC1) - oseq) < 0) {
+          __builtin_amdgcn_s_sleep(4);
+          if (spin_expired(sg, a.guard, WAIT_PAIR_FLAG)) break;       // (bounded: kernels.h, SpinGuard)
+        }
+      }
       const int par = (int)(oseq & 1u);
       float4 opart[NU];
 #pragma unroll
@@ -327,8 +333,13 @@ __global__ __launch_bounds__(512, 2) void resblock_pair_kernel(const RPArgs a) {
             __builtin_amdgcn_raw_buffer_store_b32((unsigned)(nv + 1) | ((seq & 0x7ffu) << 20), mb_r, (int)(seq & 3u) * 4, 0, RP_SC1);
           } else {
             unsigned w;
-            while ((((w = __builtin_amdgcn_raw_buffer_load_b32(mb_r, (int)(seq & 3u) * 4, 0, RP_SC1)) >> 20) & 0x7ffu) != (seq & 0x7ffu)) __builtin_amdgcn_s_sleep(4);
-            nv = (int)(w & 0xfffffu) - 1;
+            SpinGuard sg;
+            bool dead = false;
+            while ((((w = __builtin_amdgcn_raw_buffer_load_b32(mb_r, (int)(seq & 3u) * 4, 0, RP_SC1)) >> 20) & 0x7ffu) != (seq & 0x7ffu)) {
+              __builtin_amdgcn_s_sleep(4);
+              if (spin_expired(sg, a.guard, WAIT_PAIR_MAILBOX)) { dead = true; break; }     // (bounded: kernels.h, SpinGuard)
+            }
+            nv = dead ? -1 : (int)(w & 0xfffffu) - 1;       // (a member that gave up takes no further tile)
           }
           pv = nv >= 0 ? *(rp_gci)(a.tiles + (long long)nv * 4) : -1;
         }

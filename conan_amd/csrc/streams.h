@@ -74,7 +74,8 @@ struct conan_streams {
   int* sk_counters[3] = {nullptr, nullptr, nullptr};
   int reserve_cus = 0;                     // CUs the pipelined vocoder's persistent launches leave to the front-end stream (CONAN_RESERVE_CUS)
   bool fenced = false;          // CONAN_FENCED=1 at creation: release / acquire fences around the inter-workgroup hand-offs too
-  bool rb_limb = false;         // bf16-limb form of the vocoder's matrix kernels where it exists (CONAN_RB_LIMB=1 at creation; default: exact-f32 MFMA everywhere)
+  bool rb_limb = false;         // bf16-limb form of the vocoder's matrix kernels where it exists (conan_streams_opts.arith, resolved at creation)
+  bool arith_auto = true;       // the caller left the choice to the library: a fused pass with too few tiles to fill the chip keeps the f32 form (launch_rb)
   bool rb_merge = true;         // merged-branch last-dilation launches (CONAN_RB_NOMERGE=1 at creation: separate branches + mean_act)
   int* cp_ticket[3] = {nullptr, nullptr, nullptr};   // conv_post's last-workgroup ticket, per internal stream
   int* rb_sched[2] = {nullptr, nullptr};   // work-queue counters of the fused resblock launches, per stream like the split-K workspaces
@@ -89,6 +90,19 @@ struct conan_streams {
   int slot_gen = 0;
   PinRing pin;
   int* pos_emf = nullptr; int* pos_dec = nullptr; int* pos_voc = nullptr;
+  // bounded cross-workgroup waits (kernels.h, SpinGuard): guard block in device memory + the host-mapped word a waiter that gave
+  // up copies its code to; check_fault() turns a non-zero word into CONAN_ERR_HIP at every stream-ordered entry point, for good
+  unsigned* d_guard = nullptr;
+  unsigned* h_guard = nullptr;
+  int test_fault = 0;           // conan_streams_test_fault: the next launch of that kind waits for an arrival that never comes
+  void check_fault() const {
+    if (!h_guard) return;
+    const unsigned code = *(volatile const unsigned*)h_guard;
+    if (code == 0) return;
+    static const char* what[] = {"?", "decoder_mega_kernel group / grid barrier", "emformer_fused_kernel cluster exchange", "resblock_pair_kernel partner flag", "resblock_pair_kernel tile mailbox"};
+    throw ch::Error(CONAN_ERR_HIP, std::string("a cross-workgroup wait gave up after its 50 ms budget (") + what[code < 5 ? code : 0] +
+                                       "): results since then are invalid and this stream-set is unusable - destroy it and create a new one");
+  }
 
   // --- vocoder
   Ring v_mel, v_pre;
@@ -178,6 +192,7 @@ struct conan_streams {
     for (int i = 0; i < NP; ++i) { if (ev_in[i]) (void)hipEventDestroy(ev_in[i]); if (ev_fence[i]) (void)hipEventDestroy(ev_fence[i]); }
     for (int i = 0; i < NP; ++i) { if (ev_wide[i]) (void)hipEventDestroy(ev_wide[i]); if (ev_emf[i]) (void)hipEventDestroy(ev_emf[i]); if (ev_front[i]) (void)hipEventDestroy(ev_front[i]); if (ev_voc[i]) (void)hipEventDestroy(ev_voc[i]); }
     for (void* p : allocs) (void)hipFree(p);
+    if (h_guard) (void)hipHostFree(h_guard);
     for (auto& e : prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& e : clock_ev) (void)hipEventDestroy(e);
     for (auto& m : mega_cache) { if (m.copied) (void)hipEventDestroy(m.copied); if (m.pinned) (void)hipHostFree(m.pinned); if (m.dev) (void)hipFree(m.dev); }
@@ -232,7 +247,7 @@ struct conan_streams {
   unsigned* mega_bar = nullptr;                  // the grid barrier's arrival counter (counts for ever); the group counters follow it, 16 words apart
   unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished
   unsigned long long* mega_dbg = nullptr;        // CONAN_MEGA_STAMPS=1: per-operator clock stamps of the last launch (printed at destruction)
-  const MegaProgram* mega_dbg_prog = nullptr;
+  int mega_dbg_prog = -1;                        // index into mega_cache (the vector may reallocate)
   std::vector<cnk::MegaOp>* mega_rec = nullptr;  // != nullptr: decoder_ops() records its operators instead of launching them
   bool mega_rec_ok = true; int mega_rec_lds = 0; double mega_rec_flops = 0.0;
   void mega_push(cnk::MegaOp& op, int lds_floats);

@@ -50,6 +50,14 @@ int conan_streams::pick_cfg(int M, int N, int nprob) const {
 
 void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipStream_t st) {
   if (mega_rec) { mega_rec_ok = false; return; }      // (a conv_mfma layer is not a megakernel operator: that step keeps its separate launches)
+  for (int p = 0; p < nprob; ++p) {
+    // both conv kernels address activations with 32-bit offsets from the tensor base (bytes in conv_mfma's direct-to-LDS loader,
+    // floats in conv_limb's window staging)
+    const ConvArgs& a = gin.p[p];
+    if ((long long)(a.x.mode == 0 ? max_slots : a.n) * a.x.slot_stride * 4 >= (1ll << 32))
+      throw Error(CONAN_ERR_UNSUPPORTED, "activation tensor of 4 GiB or more: lower max_slots");
+    if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
+  }
   // the bf16-limb form (conv_limb.hip) where the weights were packed for it and a tile shape fits all problems of the group
   if (rb_limb && nprob >= 1 && nprob <= 3) {
     bool ok = true;
@@ -76,10 +84,6 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     bool ring = a.y.mode == 0 || (a.has_res && a.res.mode == 0) || (a.has_m1 && a.m1.mode == 0) || (a.has_m2 && a.m2.mode == 0) || a.bvec != nullptr;
     ring = ring || a.x.mode == 0;
     if (!ring) { a.slots = nullptr; a.pos = nullptr; }
-    // the direct-to-LDS loader addresses its input with 32-bit byte offsets from the tensor base
-    if ((long long)(a.x.mode == 0 ? max_slots : a.n) * a.x.slot_stride * 4 >= (1ll << 32))
-      throw Error(CONAN_ERR_UNSUPPORTED, "activation tensor of 4 GiB or more: lower max_slots");
-    if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
   }
   // inter-block split-K for launches that cannot fill the chip with tiles but have a long K loop
   const int wsi = ws_index(st);
@@ -174,7 +178,8 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
       mega_rec_flops += 2.0 * (double)a.n * a.T * a.Cout * a.Cout2;
     }
     mega_rec_flops += fl;
-    mega_push(op, ldsf);
+    // (the megakernel places its row table in front of the operator's window: the stand-alone kernel's size + ROWTAB_FLOATS)
+    mega_push(op, cnk::decoder_mega_lds_floats(op, ldsf));
     return;
   }
   profiled(cnk::rowconv_kernel_name(a), fl, st, [&] { cnk::launch_rowconv(a, st); });
@@ -196,6 +201,13 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   bool limb = rb_limb;
   for (int p = 0; p < a.nprob; ++p) { span = std::max(span, (a.p[p].k - 1) * a.p[p].dil); limb = limb && a.p[p].w1l && a.p[p].w2l; }
   limb = limb && a.n <= cnk::kResblockLimbMaxSlots && cnk::resblock_limb_supported(C, kmax, span);
+  // AUTO: the limb pass has one tile height per width (a third to a half of the f32 pass's choices); a launch whose limb tiles
+  // cannot give at least half of the CUs one (a handful of streams) keeps the f32 pass and its shorter tiles.  An explicit
+  // arith = limb request runs the limb pass wherever it exists.
+  if (limb && arith_auto) {
+    const int lr = cnk::resblock_limb_rows(C, span);
+    if ((long long)a.nprob * a.n * ((a.T + lr - 1) / lr) * 2 < cus) limb = false;
+  }
   const int rows = limb ? cnk::resblock_limb_rows(C, span) : cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
   // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
   // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.
@@ -220,6 +232,8 @@ void conan_streams::launch_rp(const cnk::RPArgs& ain, hipStream_t st) {
   const int pairs = ctx->num_cu / 2;
   a.xb = rp_xb[w]; a.xflag = rp_words[w]; a.mbox = rp_words[w] + (size_t)pairs * 8; a.xcount = rp_words[w] + (size_t)pairs * 12;
   a.sched = reinterpret_cast<int*>(rp_words[w] + (size_t)pairs * 14);
+  a.guard = d_guard; a.fault = test_fault == 3 ? 1 : 0;
+  if (test_fault == 3) test_fault = 0;
   double fl = 0.0;
   for (int p = 0; p < a.nprob; ++p) fl += 2.0 * 2.0 * (double)a.n * a.T * 256.0 * 256.0 * a.p[p].k;
   profiled(cnk::resblock_pair_name(a.T), fl, st, [&] {
@@ -228,17 +242,18 @@ void conan_streams::launch_rp(const cnk::RPArgs& ain, hipStream_t st) {
 }
 
 void conan_streams::mega_print_stamps() {
-  if (!mega_dbg || !mega_dbg_prog) return;
+  if (!mega_dbg || mega_dbg_prog < 0 || mega_dbg_prog >= (int)mega_cache.size()) return;
   (void)hipDeviceSynchronize();
-  const MegaProgram& e = *mega_dbg_prog;
+  const MegaProgram& e = mega_cache[mega_dbg_prog];
   std::vector<unsigned long long> h(e.nops + 2);
   if (hipMemcpy(h.data(), mega_dbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
-  static const char* names[] = {"rowconv<1,1,1>", "rowconv<1,1,4>", "rowlin", "layernorm", "xattn", "pitch_head", "embed", "copy32", "advance"};
+  static const char* names[] = {"rowconv<1,1,1>", "rowconv<1,1,4>", "rowlin", "layernorm", "xattn", "pitch_head", "embed", "copy32", "advance", "ffn"};
+  constexpr int nnames = (int)(sizeof(names) / sizeof(names[0]));
   fprintf(stderr, "[decoder_mega] last launch: %d groups x %d workgroups, %d jobs, %d operators, %d group barriers, %.1f us in all (workgroup 0; first job per operator below)\n",
           e.groups, e.group_size, e.njobs, e.nops, e.barriers, (h[e.nops + 1] - h[0]) / 100.0);
   for (int o = 0; o < e.nops; ++o) {
     const cnk::MegaOp& op = e.pinned[o];
-    fprintf(stderr, "  op %2d %-15s strips %4d  barrier %d  %7.2f us", o, names[op.type], op.nbx, op.barrier, (h[o + 1] - h[o]) / 100.0);
+    fprintf(stderr, "  op %2d %-15s strips %4d  barrier %d  %7.2f us", o, (op.type >= 0 && op.type < nnames) ? names[op.type] : "?", op.nbx, op.barrier, (h[o + 1] - h[o]) / 100.0);
     if (op.type <= cnk::MOP_ROWLIN) fprintf(stderr, "   Cin %4d Cout %4d k %d ln %d", op.u.rc.Cin, op.u.rc.Cout, op.u.rc.ktaps, op.u.rc.ln);
     fprintf(stderr, "\n");
   }
@@ -247,11 +262,12 @@ void conan_streams::mega_print_stamps() {
 void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   static const bool stamps = getenv("CONAN_MEGA_STAMPS") != nullptr;
   if (stamps && !mega_dbg) mega_dbg = reinterpret_cast<unsigned long long*>(alloc(2 * (kMegaMaxOps + 4)));
-  if (stamps) mega_dbg_prog = &e;
+  if (stamps) mega_dbg_prog = (int)(&e - mega_cache.data());
   cnk::MegaLaunch m; memset(&m, 0, sizeof(m));
   m.prog = e.dev; m.nops = e.nops; m.njobs = e.njobs; m.groups = e.groups; m.group_size = e.group_size; m.kw4 = e.kw4; m.lds_bytes = e.lds_bytes;
   m.slots = d_slots; m.pos = pos_dec; m.n = e.n; m.T = e.T;
-  m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg;
+  m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg; m.guard = d_guard;
+  if (test_fault == 1) { m.bar_base += 1u; test_fault = 0; }       // test hook: the grid barrier waits for one arrival too many
   profiled("cnk::decoder_mega_kernel", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
 }
@@ -511,13 +527,17 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       launch_group(g1, NB, cfg, st);
       launch_group(g2, NB, cfg, st);
     }
-    last_merged = merged;
-    if (i + 1 < c.voc_num_ups && !merged) {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1]; the last stage's by conv_post, which forms it itself
+    // (a caller that taps the last stage's output gets it from the separate mean launch: conv_post, which otherwise forms the
+    // mean itself, also advances the frame counters the tap's row addresses depend on)
+    const bool tap_last = taps && taps->stage_out[i] && i + 1 == c.voc_num_ups && !merged;
+    last_merged = merged || tap_last;
+    if ((i + 1 < c.voc_num_ups || tap_last) && !merged) {  // xs = leaky_relu(mean_b ResBlock_b(x))   (hifigan_causal.py:324-331), consumed by ups[i+1]; the last stage's by conv_post, which forms it itself
       cnk::MeanActArgs ma; memset(&ma, 0, sizeof(ma));
       for (int b = 0; b < NB; ++b) ma.x[b] = s.xo[b][ND - 1].ref();
       ma.y = s.xs.ref(); ma.slots = d_slots; ma.pos = pos; ma.nsrc = NB; ma.T = T; ma.n = n; ma.C = s.C; ma.slope = LR;
       cnk::launch_mean_act(ma, st);
     }
+    if (taps) tap(taps->stage_out[i], s.xs, T);
     ridx += NB;
   }
   {  // conv_post + tanh on leaky_relu(xs / NB)   (hifigan_causal.py:329-333)
@@ -617,6 +637,7 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
   if (emf_fused) {   // whole step in one launch (emformer_fused.hip)
     cnk::EmfFusedArgs a = emf_fused_args;
     a.chunk = chunk; a.out = out; a.logits = logits; a.codes = codes; a.n = n; a.fenced = fenced ? 1 : 0;
+    a.guard = d_guard; a.fault = 0;
     // Workgroups per stream group: the step is a chain of latency-bound phases on one 16-row tile, so a few streams are
     // spread over up to 8 CUs each (feed-forward hidden units split 8 ways, one exchange per layer); with many streams
     // the groups themselves fill the CUs and the split only has to keep the launch short beside the vocoder.
@@ -631,6 +652,7 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two
       while (a.cs > 1 && groups * a.cs > cap) a.cs >>= 1;
       if (masked && st == st_emf) a.cs = 1;
+      if (test_fault == 2 && a.cs > 1) { a.fault = 0x40000000u; test_fault = 0; }      // test hook: the members wait for a flag value nobody writes
     }
     // algorithmic FLOPs of the step: per stream and layer Q = R + U query rows against the four D x D projections, the
     // D x F x 2 feed-forward, and attention over R + LC + U keys; plus the output projection

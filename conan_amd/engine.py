@@ -87,54 +87,69 @@ class _HostStream:
 
 
 class AudioGatherRing:
-    """Per-step collection of finished audio on rank 0 (the path's only exchange) without serialising
-    the chunk pipeline: audio of step j goes to buffer j % nb; its gather (RCCL on GPUs, gloo on CPU) is enqueued on a
-    side stream behind `join()` (= "step j's audio is complete"), and a buffer is handed out again only after the
-    gather that read it has finished (one event per buffer).
+    """Collection of finished audio on rank 0 (the path's only exchange) without serialising the chunk
+    pipeline: audio of step j goes to buffer j % nb; gathers (RCCL on GPUs, gloo on CPU) are enqueued on a side stream
+    behind `join()` (= "the audio of every step enqueued so far is complete"), and a buffer is handed out again only after
+    the gather that read it has finished.
 
-        ring = AudioGatherRing(lambda: torch.empty(B, samples, device=dev), world, rank)
+        ring = AudioGatherRing(lambda: torch.empty(B, samples, device=dev), world, rank, every=4)
         for j in range(steps):
-            buf = ring.acquire(j)          # current stream waits for the gather that last read this buffer
-            ... enqueue the step that writes buf ...
-            ring.submit(j, join)           # side stream: join(); gather(buf); record
-        ring.drain()
+            buf, fence = ring.acquire(j, fence=True)   # fence: the side stream, when a gather that read buf may be pending
+            ... enqueue the step that writes buf (Streams.step_async(..., out_fence=fence)) ...
+            ring.submit(j, join)                        # every `every`-th step: side stream: join(); gather(group); record
+        ring.flush(steps - 1); ring.drain()
+
+    `every` = steps per gather (SURVEY.md §8e allows per step or per utterance).  With every = 1 each step's buffer is gathered
+    by itself (nb buffers).  With every = E > 1 the ring is 2 groups of E step buffers, contiguous in one allocation: the E
+    buffers of a group travel in ONE collective after the group's last step while the next group's steps already write the
+    other group, and the side stream is touched - one join, one gather, one event record, one output fence for the step that
+    re-opens the group - once per E steps instead of once per step.  (Measured on one MI355X, world 1, where the gather itself
+    is a no-op: the per-step form costs the 64-stream pipelined step 6.5 %)
 
     Pipelined steps should not take the wait on the current stream: it holds back the step's Emformer and decoder stages,
-    which never touch the buffer, and drains the three-stage pipeline (measured on one MI355X: 1.81 -> 2.6 ms per step).
-    `buf, fence = ring.acquire(j, fence=True)` returns the side stream instead (None while no gather can be pending) for
-    `Streams.step_async(..., out_fence=fence)`: only the stage that writes the audio waits for the gather.
+    which never touch the buffer, and drains the three-stage pipeline (measured: 1.81 -> 2.6 ms per step).  `acquire(j,
+    fence=True)` returns the side stream instead (None while no gather can be pending, and for every step but the first of
+    a group) for `Streams.step_async(..., out_fence=fence)`: only the stage that writes the audio waits for the gather.
     """
 
-    def __init__(self, make_buffer, world, rank, nb=4, always=False, on_gathered=None):
-        self.world, self.rank, self.nb = world, rank, nb
-        self.bufs = [make_buffer() for _ in range(nb)]
+    def __init__(self, make_buffer, world, rank, nb=4, always=False, on_gathered=None, every=1):
+        self.world, self.rank = world, rank
+        self.every = max(1, int(every))
+        self.nb = nb if self.every == 1 else 2 * self.every
+        proto = make_buffer()
+        self.pool = proto.new_zeros((self.nb,) + tuple(proto.shape))          # group g = pool[g * every : (g + 1) * every]
+        self.bufs = [self.pool[i] for i in range(self.nb)]
         self.active = world > 1 or always
-        self.cuda = self.bufs[0].is_cuda
+        self.cuda = proto.is_cuda
         self.on_gathered = on_gathered
-        self.gbufs = [torch.empty_like(self.bufs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+        self._g = [proto.new_zeros((self.every,) + tuple(proto.shape)) for _ in range(world)] if (world > 1 and rank == 0) else None
+        self.gbufs = None if self._g is None else [g[0] if self.every == 1 else g for g in self._g]   # what rank 0 last gathered, per rank
+        ngroups = self.nb // self.every
         if self.active and self.cuda:
             self.comm = torch.cuda.Stream()
-            self.done = [torch.cuda.Event() for _ in range(nb)]
+            self.done = [torch.cuda.Event() for _ in range(ngroups)]
         else:
             self.comm = _HostStream()
-            self.done = [_HostStream() for _ in range(nb)]
-        self.submitted = 0
+            self.done = [_HostStream() for _ in range(ngroups)]
+        self.submitted = 0            # gathers enqueued
+        self.last_gathered = None     # last step whose audio has been handed to a gather
+        self.last_sent = None         # the local tensor of that gather (a group of step buffers)
+        self._next = 0                # first step not yet covered by a gather
 
     def acquire(self, j, fence=False):
         k = j % self.nb
-        pending = self.active and j >= self.nb
-        if fence:       # the side stream is in order: everything enqueued on it so far includes the gather that read bufs[k]
+        first = j % self.every == 0                       # the step that re-opens a group is the one that may collide with its gather
+        pending = self.active and j >= self.nb and first
+        if fence:       # the side stream is in order: everything enqueued on it so far includes the gather that read this group
             return self.bufs[k], (self.comm if (pending and self.cuda) else None)
         if pending:
-            (torch.cuda.current_stream() if self.cuda else _HostStream()).wait_event(self.done[k])
+            (torch.cuda.current_stream() if self.cuda else _HostStream()).wait_event(self.done[k // self.every])
         return self.bufs[k]
 
-    def submit(self, j, join=None, wait_current=False):
-        """join: callable making the CURRENT stream wait for step j's audio (Streams.join); wait_current: the audio was
-        produced on the stream that is current now (blocking steps) - the side stream waits for it."""
-        if not self.active:
-            return
-        k = j % self.nb
+    def _gather(self, j, join, wait_current):
+        """One collective for the steps self._next .. j (all in one group)."""
+        g = (j % self.nb) // self.every
+        grp = self.pool[g * self.every:(g + 1) * self.every]
         cur = torch.cuda.current_stream() if self.cuda else None
         ctxm = torch.cuda.stream(self.comm) if self.cuda else self.comm
         with ctxm:
@@ -142,11 +157,30 @@ class AudioGatherRing:
                 self.comm.wait_stream(cur)
             if join is not None:
                 join()
-            out = gather_audio_equal(self.bufs[k], self.world, self.rank, self.gbufs)
+            out = gather_audio_equal(grp, self.world, self.rank, self._g)
             if self.on_gathered is not None and self.rank == 0:
-                self.on_gathered(j, out if self.world > 1 else [self.bufs[k]])
-            self.done[k].record(self.comm) if self.cuda else None
+                src = out if self.world > 1 else [grp]
+                for js in range(self._next, j + 1):
+                    self.on_gathered(js, [b[js % self.every] for b in src])
+            self.done[g].record(self.comm) if self.cuda else None
         self.submitted += 1
+        self.last_gathered, self.last_sent, self._next = j, grp, j + 1
+
+    def submit(self, j, join=None, wait_current=False):
+        """join: callable making the CURRENT stream wait for the audio of every step enqueued so far (Streams.join);
+        wait_current: the audio was produced on the stream that is current now (blocking steps) - the side stream waits for
+        it.  A gather is enqueued when step j completes a group."""
+        if not self.active:
+            self.last_gathered = j
+            return
+        self._join, self._wait_current = join, wait_current
+        if (j + 1) % self.every == 0:
+            self._gather(j, join, wait_current)
+
+    def flush(self, j):
+        """Gather the steps up to j that no gather has covered yet (a timed region that ends inside a group)."""
+        if self.active and j >= self._next:
+            self._gather(j, getattr(self, "_join", None), getattr(self, "_wait_current", False))
 
     def drain(self):
         if self.active:
@@ -157,10 +191,11 @@ class StreamingVoiceConversionEngine:
     """The chunk loop of StreamingVoiceConversion.infer_once (inference/Conan.py:72-166) for many
     streams at once: mel in -> (wav, mel, codes) out, state carried in a conan_streams handle."""
 
-    def __init__(self, ctx, n_streams, max_ref_frames=256, max_frames=None):
+    def __init__(self, ctx, n_streams, max_ref_frames=256, max_frames=None, arith="auto"):
         self.ctx = ctx
         self.n = n_streams
-        self.st = ctx.streams(n_streams, max_frames=max(ctx.cfg.emf_segment, max_frames or 0), max_ref_frames=max_ref_frames)
+        self.arith = arith          # conan_streams_opts.arith of the stream-set: 'auto' | 'f32' | 'limb'
+        self.st = ctx.streams(n_streams, max_frames=max(ctx.cfg.emf_segment, max_frames or 0), max_ref_frames=max_ref_frames, arith=arith)
         self.slots = list(range(n_streams))
         self.seg, self.rc = ctx.cfg.emf_segment, ctx.cfg.emf_right_context
 
@@ -238,7 +273,7 @@ class StreamingVoiceConversionEngine:
         if self.st.max_frames < T:
             mr = self.st.max_ref_frames
             self.st.close()
-            self.st = self.ctx.streams(self.n, max_frames=T, max_ref_frames=mr)
+            self.st = self.ctx.streams(self.n, max_frames=T, max_ref_frames=mr, arith=self.arith)
         self.start(ref_mel, ref_len)
         hop = self.ctx.hop
         wavs, mels, codes = [], [], []

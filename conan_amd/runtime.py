@@ -91,8 +91,10 @@ class Context:
         assert got.value == frames
         return mel
 
-    def streams(self, max_slots, max_frames=4, max_ref_frames=256):
-        return Streams(self, max_slots, max_frames, max_ref_frames)
+    def streams(self, max_slots, max_frames=4, max_ref_frames=256, arith="auto"):
+        """A stream-set.  arith: 'auto' (library default), 'f32' (f32-input MFMA everywhere) or 'limb' (fp32 products of the
+        vocoder's matrix kernels as bf16 limb products) - conan_streams_opts.arith."""
+        return Streams(self, max_slots, max_frames, max_ref_frames, arith)
 
     def close(self):
         if getattr(self, "h", None):
@@ -109,11 +111,14 @@ class Context:
 class Streams:
     """conan_streams: per-slot streaming state + the step functions."""
 
-    def __init__(self, ctx, max_slots, max_frames=4, max_ref_frames=256):
+    def __init__(self, ctx, max_slots, max_frames=4, max_ref_frames=256, arith="auto"):
         self.ctx, self.lib = ctx, ctx.lib
         self.max_slots, self.max_frames, self.max_ref_frames = max_slots, max_frames, max_ref_frames
+        if arith not in _lib.ARITH_NAMES:
+            raise ValueError(f"arith must be one of {sorted(_lib.ARITH_NAMES)}, got {arith!r}")
+        opts = _lib.StreamsOpts(_lib.ABI_VERSION, _lib.ARITH_NAMES[arith])
         h = C.c_void_p()
-        _lib.check(self.lib.conan_streams_create(ctx.h, max_slots, max_frames, max_ref_frames, C.byref(h)))
+        _lib.check(self.lib.conan_streams_create_opts(ctx.h, max_slots, max_frames, max_ref_frames, C.byref(opts), C.byref(h)))
         self._keep = []   # buffers of pipelined steps in flight (released by join())
         self.h = h
         self.dev = torch.device("cuda", ctx.device)
@@ -123,6 +128,11 @@ class Streams:
     @property
     def state_bytes(self):
         return self.lib.conan_streams_state_bytes(self.h)
+
+    @property
+    def arith(self):
+        """'f32' or 'limb': the arithmetic this stream-set's vocoder launches use where both forms exist ('auto' resolved)."""
+        return {_lib.ARITH_F32: "f32", _lib.ARITH_LIMB: "limb"}[_lib.check(self.lib.conan_streams_arith(self.h))]
 
     def _release(self):
         """Buffers of pipelined steps may be dropped once the current torch stream waits for the library's internal
@@ -229,8 +239,9 @@ class Streams:
         self._release()
         return ids, cnt
 
-    def hifigan_step_taps(self, slots, mel):
-        """hifigan_step plus the generator's intermediate tensors: (wav, pre_tanh, conv_pre_act [n,T,C0], [ups_i [n,T*rate_i,C_i]])."""
+    def hifigan_step_taps(self, slots, mel, stage_out=False):
+        """hifigan_step plus the generator's intermediate tensors: (wav, pre_tanh, conv_pre_act [n,T,C0], [ups_i [n,T*rate_i,C_i]]);
+        stage_out=True appends [stage_out_i [n,T*rate_i,C_i]] = leaky_relu(mean of the stage's ResBlocks)."""
         a, p = _i32(slots)
         n = len(a)
         c = self.ctx.cfg
@@ -240,7 +251,7 @@ class Streams:
         wav = torch.empty(n, T * hop, device=self.dev)
         pre = torch.empty(n, T * hop, device=self.dev)
         cpre = torch.empty(n, T, c.voc_initial_channel, device=self.dev)
-        ups, ch_, rate = [], c.voc_initial_channel, 1
+        ups, outs, ch_, rate = [], [], c.voc_initial_channel, 1
         t = _lib.HifiganTaps()
         t.conv_pre_act = cpre.data_ptr()
         for i in range(c.voc_num_ups):
@@ -248,9 +259,12 @@ class Streams:
             rate *= c.voc_up_rates[i]
             ups.append(torch.empty(n, T * rate, ch_, device=self.dev))
             t.ups[i] = ups[-1].data_ptr()
+            if stage_out:
+                outs.append(torch.empty(n, T * rate, ch_, device=self.dev))
+                t.stage_out[i] = outs[-1].data_ptr()
         _lib.check(self.lib.conan_hifigan_step_taps(self.h, p, n, T, _ptr(mel), _ptr(wav), _ptr(pre), C.byref(t), _stream()))
         self._release()
-        return wav, pre, cpre, ups
+        return (wav, pre, cpre, ups, outs) if stage_out else (wav, pre, cpre, ups)
 
     def hifigan_step(self, slots, mel, want_pre_tanh=False, out=None):
         """mel: cuda float32 [n, frames, 80] -> wav [n, frames*hop]."""

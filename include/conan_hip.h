@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 5
+#define CONAN_HIP_ABI_VERSION 6
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -118,6 +118,30 @@ int conan_ctx_finalize(conan_ctx* ctx);
 int conan_streams_create(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, conan_streams** out);
 int conan_streams_destroy(conan_streams* s);
 
+/* Arithmetic of the vocoder's matrix kernels (HifiGanGenerator's Conv1d products, hifigan_causal.py:191-244, 314-333).  Both
+ * forms compute fp32 convolutions with fp32 accumulation and fp32 results; they differ in how an fp32 x fp32 product is formed:
+ *   CONAN_ARITH_F32   every product on the f32-input MFMA (v_mfma_f32_*_f32);
+ *   CONAN_ARITH_LIMB  every fp32 operand split exactly into three bf16 limbs (x = h + m + l), a product as the six largest of
+ *                     the nine limb products on the bf16 MFMA (error of the dropped terms <= 2^-23 |x w|, below the rounding of
+ *                     the fp32 accumulation; tests/test_gpu_arith.py holds both forms against float64).  Operands whose
+ *                     magnitude is below 2^-110 lose their third limb (a bf16 denormal), see DESIGN.md: such products are
+ *                     < 2^-110 |w| and carry >= 16 significant bits.
+ *   CONAN_ARITH_AUTO  the library's default: LIMB wherever a limb kernel exists for the launch (ResBlock1 stages, upsamplers of
+ *                     stream-sets large enough to fill the chip), F32 elsewhere (small stream-sets, ResBlock2, decoder, Emformer).
+ * The choice is a property of the stream-set, fixed at creation, reported by conan_streams_arith(). */
+typedef enum conan_arith { CONAN_ARITH_AUTO = 0, CONAN_ARITH_F32 = 1, CONAN_ARITH_LIMB = 2 } conan_arith;
+typedef struct conan_streams_opts {
+  int32_t abi_version;   /* must be CONAN_HIP_ABI_VERSION */
+  int32_t arith;         /* conan_arith */
+  int32_t reserved[6];   /* must be 0 */
+} conan_streams_opts;
+/* conan_streams_create with options (opts == NULL: all defaults, i.e. conan_streams_create). */
+int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, const conan_streams_opts* opts,
+                              conan_streams** out);
+/* The arithmetic this stream-set's vocoder launches use where both forms exist: CONAN_ARITH_F32 or CONAN_ARITH_LIMB
+ * (AUTO resolved); negative conan_status on a null handle. */
+int conan_streams_arith(const conan_streams* s);
+
 /* Start of utterance for the given slots (replaces `state = None` inference/Conan.py:92 and the
  * zero left-padding of every causal conv).  which = bitmask of CONAN_MODEL_*. */
 int conan_streams_reset(conan_streams* s, const int32_t* slots, int n, int which, void* stream);
@@ -189,10 +213,13 @@ int conan_hifigan_step(conan_streams* s, const int32_t* slots, int n, int frames
 /* conan_hifigan_step with optional taps of the generator's intermediate tensors (the forward hooks a reference
  * maintainer would register on conv_pre / ups[i], hifigan_causal.py:319-322), channel-last; any pointer may be NULL.
  *   conv_pre_act[n][frames][C0]             leaky_relu(conv_pre(mel), 0.1): the tensor ups[0] consumes
- *   ups[i][n][frames*rate_i][C_i]           output of ups[i] after the pixel shuffle (rate_i = prod(up_rates[0..i])) */
+ *   ups[i][n][frames*rate_i][C_i]           output of ups[i] after the pixel shuffle (rate_i = prod(up_rates[0..i]))
+ *   stage_out[i][n][frames*rate_i][C_i]     the MRF stage's output (see the field) */
 typedef struct conan_hifigan_taps {
   float* conv_pre_act;
   float* ups[CONAN_MAX_UPS];
+  float* stage_out[CONAN_MAX_UPS];   /* [n][frames*rate_i][C_i]: leaky_relu(mean_j resblocks[i*num_kernels + j](ups[i] output)), the tensor
+                                        ups[i+1] / conv_post consumes (hifigan_causal.py:324-331) */
 } conan_hifigan_taps;
 int conan_hifigan_step_taps(conan_streams* s, const int32_t* slots, int n, int frames, const float* mel_dev,
                             float* wav_out_dev, float* pre_tanh_dev, const conan_hifigan_taps* taps, void* stream);
@@ -219,6 +246,14 @@ int conan_streams_join(conan_streams* s, void* stream);
  * step's Emformer and decoder stages too, which do not touch the buffer, and drain the pipeline (measured: 1.81 -> 2.6 ms
  * per step at 64 streams).  One-shot: cleared by the step that consumes it. */
 int conan_streams_output_fence(conan_streams* s, void* fence_stream);
+
+/* Test hook for the bounded device-side waits.  Three kernels wait for other workgroups of their own launch (decoder step:
+ * group / grid barriers; Emformer step: cluster exchange; first vocoder stage: partner flags); each such wait carries a 50 ms
+ * budget, after which the waiter records a code and leaves, the launch finishes with meaningless results, and every later
+ * stream-ordered entry point on the stream-set returns CONAN_ERR_HIP (the stream-set must then be destroyed; the context and
+ * the process stay usable).  conan_streams_test_fault(s, kind) makes the NEXT launch of kind 1 (decoder megakernel), 2 (Emformer
+ * clusters) or 3 (pair kernel) wait for an arrival that never comes, so that tests can walk that path on a healthy GPU. */
+int conan_streams_test_fault(conan_streams* s, int kind);
 
 /* Mel front-end (the step before the hot path): librosa_wav2spec as used by
  * StreamingVoiceConversion._wav_to_mel (utils/audio/__init__.py:37-84, inference/Conan.py:57-70), loud_norm off:

@@ -54,7 +54,7 @@ def test_gather_audio_world2(total):
     assert sorted(res) == [(0, True), (1, True)]
 
 
-def _ring_worker(rank, world, port, steps, q):
+def _ring_worker(rank, world, port, steps, q, every=1):
     """The benchmark's step / gather choreography (bench.py: AudioGatherRing) on a gloo group with a stub engine: step j
     of rank r "computes" audio filled with 1000 r + j into the ring buffer it was handed; rank 0 must receive every
     rank's audio of every step, in step order, although buffers are reused every `nb` steps."""
@@ -66,17 +66,21 @@ def _ring_worker(rank, world, port, steps, q):
     def on_gathered(j, bufs):
         seen.append((j, [float(b[0, 0]) for b in bufs], all(bool((b == b[0, 0]).all()) for b in bufs)))
 
-    ring = AudioGatherRing(lambda: torch.zeros(3, 16), world, rank, nb=4, on_gathered=on_gathered)
+    ring = AudioGatherRing(lambda: torch.zeros(3, 16), world, rank, nb=4, on_gathered=on_gathered, every=every)
     joined = []
     for j in range(steps):
         buf, fence = ring.acquire(j, fence=True)      # the benchmark's form: the step takes the side stream as its output fence
         assert fence is None                          # (host-only group: everything is synchronous, nothing to wait for)
         buf.fill_(1000.0 * rank + j)                  # the "vocoder" of step j
         ring.submit(j, join=lambda j=j: joined.append(j))
+    ring.flush(steps - 1)                             # a run that ends inside a group: the rest travels now
     ring.drain()
     dist.barrier()
     dist.destroy_process_group()
-    ok = joined == list(range(steps)) and ring.submitted == steps
+    # one join + one collective per `every` steps (+ the flush of the incomplete last group)
+    want_gathers = (steps + every - 1) // every
+    want_joined = [j for j in range(steps) if (j + 1) % every == 0] + ([steps - 1] if steps % every else [])
+    ok = joined == want_joined and ring.submitted == want_gathers and ring.last_gathered == steps - 1
     if rank == 0:
         ok = ok and [s[0] for s in seen] == list(range(steps))
         ok = ok and all(vals == [1000.0 * r + j for r in range(world)] and uniform for j, vals, uniform in seen)
@@ -85,13 +89,14 @@ def _ring_worker(rank, world, port, steps, q):
     q.put((rank, bool(ok)))
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_bench_gather_choreography(world):
-    """world 8 = the 8-GPU node's rank count (BASELINE.json configs[3]): the choreography the driver's N = 8 run executes."""
+@pytest.mark.parametrize("world,every", [(2, 1), (2, 4), (8, 4)])
+def test_bench_gather_choreography(world, every):
+    """world 8 = the 8-GPU node's rank count (BASELINE.json configs[3]): the choreography the driver's N = 8 run executes
+    (every = 4: one collective per four steps, bench.py's default; 11 steps end inside a group)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, 11, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, 11, q, every)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -106,15 +111,17 @@ def _check_worker(rank, world, port, q):
     from conan_amd.engine import AudioGatherRing
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ring = AudioGatherRing(lambda: torch.zeros(4, 32), world, rank, nb=4)
+    ring = AudioGatherRing(lambda: torch.zeros(4, 32), world, rank, nb=4, every=4)
     g = torch.Generator().manual_seed(100 + rank)
     steps = 6
     for j in range(steps):
         buf, _ = ring.acquire(j, fence=True)
         buf.copy_(torch.randn(4, 32, generator=g))
         ring.submit(j)
+    ring.flush(steps - 1)
     ring.drain()
-    last = ring.bufs[(steps - 1) % ring.nb]
+    assert ring.last_gathered == steps - 1 and ring.submitted == 2
+    last = ring.last_sent                      # the group of step buffers this rank handed to the last gather
     csum = last.view(torch.int32).to(torch.int64).sum().reshape(1)
     sums = [torch.zeros_like(csum) for _ in range(world)]
     dist.all_gather(sums, csum)

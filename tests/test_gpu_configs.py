@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conan_amd import configs, synth
-from tests.conftest import load_golden
+from tests.conftest import ARITHS, assert_arith_ran, kernels_of, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +23,8 @@ def _full_ctx(chp=None):
     return ctx, chp, vhp
 
 
-def test_batch64_full_size_streams_are_independent():
+@pytest.mark.parametrize("arith", ARITHS)
+def test_batch64_full_size_streams_are_independent(arith):
     """configs[2]: 64 concurrent full-size streams.  A stream's output must not depend on which other streams share
     the batch or on its slot: stream k inside the batch of 64 == the same stream run alone (different tile shapes,
     split-K and launch grouping, so equality is up to fp32 re-association)."""
@@ -32,11 +33,11 @@ def test_batch64_full_size_streams_are_independent():
     B, T, Tr = 64, 12, 40
     src = torch.from_numpy(np.concatenate([synth.mel(T, 1234 + s) for s in range(B)])).cuda()
     ref = torch.from_numpy(np.concatenate([synth.mel(Tr, 4321 + s) for s in range(B)])).cuda()
-    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=64)
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=64, arith=arith)
     wav, mel, codes = eng.infer(src, ref)
     assert wav.shape == (B, T * 320) and mel.shape == (B, T, 80) and codes.shape == (B, T)
     assert torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
-    solo = StreamingVoiceConversionEngine(ctx, 1, max_ref_frames=64)
+    solo = StreamingVoiceConversionEngine(ctx, 1, max_ref_frames=64, arith=arith)
     for k in (0, 37, 63):
         w1, m1, c1 = solo.infer(src[k:k + 1], ref[k:k + 1])
         assert torch.equal(c1, codes[k:k + 1])
@@ -48,6 +49,11 @@ def test_batch64_full_size_streams_are_independent():
     # ... and the pipelined schedule (default) is bit-identical to the blocking chunk loop
     wav3, mel3, codes3 = eng.infer(src, ref, pipelined=False)
     assert torch.equal(wav, wav3) and torch.equal(mel, mel3) and torch.equal(codes, codes3)
+    names = kernels_of(eng.st, lambda: eng.st.hifigan_step(eng.slots, mel[:, :4].contiguous()))
+    assert_arith_ran(names, arith)
+    if arith == "limb":      # every ResBlock stage and ups.2 / ups.3 in limb form at 64 streams; no f32 ResBlock pass left
+        assert all(any(("resblock_limb_kernel<%d," % c) in k for k in names) for c in (128, 64, 32)), sorted(names)
+        assert not any("resblock_fused_kernel" in k or "resblock_pair_kernel" in k for k in names), sorted(names)
     eng.st.close(); solo.st.close(); ctx.close()
 
 

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conan_amd import configs, synth
-from tests.conftest import load_golden
+from tests.conftest import assert_arith_ran, kernels_of, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -26,15 +26,22 @@ def _ctx(tiny, emformer=True, conan=True, hifigan=True):
     return ctx, chp, vhp
 
 
-@pytest.fixture(scope="module", params=["tiny", "full"])
+def _streams(ctx, *a, **k):
+    """A stream-set in the arithmetic the module fixture is parametrized with (conan_streams_opts.arith)."""
+    return ctx.streams(*a, arith=ctx.test_arith, **k)
+
+
+@pytest.fixture(scope="module", params=["tiny-f32", "full-f32", "full-limb"])
 def env(request):
-    tiny = request.param == "tiny"
+    size, arith = request.param.split("-")
+    tiny = size == "tiny"
     ctx, chp, vhp = _ctx(tiny)
+    ctx.test_arith = arith
     from oracle.common import to_torch_sd
     sds = {"emformer": to_torch_sd(synth.emformer_state_dict(chp, 0)),
            "conan": to_torch_sd(synth.conan_state_dict(chp, 0)),
            "hifigan": to_torch_sd(synth.hifigan_state_dict(vhp, 0))}
-    yield request.param, ctx, chp, vhp, sds
+    yield size, ctx, chp, vhp, sds
     ctx.close()
 
 
@@ -45,7 +52,7 @@ def test_hifigan_stream_vs_oracle_and_golden(env):
     mel0 = torch.from_numpy(g["mel_12"])[0].T                      # [12,80]
     mel1 = torch.from_numpy(synth.mel(12, 77))[0]
     mels = torch.stack([mel0, mel1]).cuda()                        # [2,12,80]
-    st = ctx.streams(4, max_frames=4, max_ref_frames=16)
+    st = _streams(ctx, 4, max_frames=4, max_ref_frames=16)
     slots = [2, 0]
     st.reset(slots)
     wavs, pres = [], []
@@ -69,6 +76,9 @@ def test_hifigan_stream_vs_oracle_and_golden(env):
     w_b = st.hifigan_step(slots, mels[:, 0:4]).cpu()
     assert torch.equal(w_a, w_b)                                    # bitwise reproducible (no atomics)
     np.testing.assert_allclose(w_a.numpy(), ref[:, :4 * 320].numpy(), atol=1e-4, rtol=0)
+    assert st.arith == ctx.test_arith
+    if tag == "full":       # (4 slots: the C = 32 stage is the one whose fused pass has a limb form at this size)
+        assert_arith_ran(kernels_of(st, lambda: st.hifigan_step(slots, mels[:, 4:8])), ctx.test_arith)
     st.close()
 
 
@@ -78,7 +88,7 @@ def test_hifigan_long_steps_and_ragged_frames(env):
     tag, ctx, chp, vhp, sds = env
     mels = torch.from_numpy(synth.mel(24, 5, 1)).cuda()
     ref = ohifi.generator_forward(sds["hifigan"], vhp, mels.cpu().transpose(1, 2))[:, 0]
-    st = ctx.streams(1, max_frames=12, max_ref_frames=16)
+    st = _streams(ctx, 1, max_frames=12, max_ref_frames=16)
     for plan in ([12, 12], [4] * 6, [5, 1, 6, 3, 9]):
         st.reset([0])
         out, p = [], 0
@@ -95,7 +105,7 @@ def _emformer_stream_vs_oracle(env):
     cfg = oemf.EmformerCfg(chp)
     B, T = 3, 72
     mel = torch.from_numpy(synth.mel(T, 1234, B))
-    st = ctx.streams(4, max_frames=4, max_ref_frames=16)
+    st = _streams(ctx, 4, max_frames=4, max_ref_frames=16)
     slots = [3, 1, 0]
     st.reset(slots)
     state = None
@@ -136,7 +146,7 @@ def test_conan_decoder_vs_oracle_and_golden(env):
     cache2 = oconan.style_pass(sds["conan"], chp, ref2[:, :131])
     o1 = oconan.decode_frames(sds["conan"], chp, content, cache1)
     o2 = oconan.decode_frames(sds["conan"], chp, content2, cache2)
-    st = ctx.streams(4, max_frames=4, max_ref_frames=160)
+    st = _streams(ctx, 4, max_frames=4, max_ref_frames=160)
     slots = [1, 3]
     st.reset(slots)
     st.set_reference(slots, torch.cat([ref, ref2]).cuda(), [150, 131])
@@ -171,7 +181,7 @@ def test_fused_step_vs_oracle_loop(env):
     T, Tr, B = 26, 40, 2            # ragged tail: 26 = 6*4 + 2
     src = synth.mel(T, 1234, B)
     ref = synth.mel(Tr, 4321, B)
-    st = ctx.streams(B, max_frames=4, max_ref_frames=64)
+    st = _streams(ctx, B, max_frames=4, max_ref_frames=64)
     slots = list(range(B))
     st.reset(slots)
     st.set_reference(slots, torch.from_numpy(ref).cuda())
@@ -185,6 +195,9 @@ def test_fused_step_vs_oracle_loop(env):
         assert np.array_equal(code[b].numpy(), c_ref), "code flip (argmax margin); see test_emformer_stream_vs_oracle"
         np.testing.assert_allclose(mel[b].numpy(), m_ref, atol=1e-4, rtol=1e-4)
         np.testing.assert_allclose(wav[b].numpy(), w_ref, atol=1e-4, rtol=0)
+    if tag == "full":
+        chunk0 = torch.from_numpy(src[:, :cfg.segment_length + cfg.right_context_length]).cuda().contiguous()
+        assert_arith_ran(kernels_of(st, lambda: st.step(slots, chunk0)), ctx.test_arith)
     st.close()
 
 

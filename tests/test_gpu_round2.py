@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conan_amd import configs, synth
-from tests.conftest import load_golden
+from tests.conftest import ARITHS, assert_arith_ran, kernels_of, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -201,8 +201,8 @@ def test_merged_branch_launches_equal_separate_branches_bitwise(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------- loop fixture
-@pytest.mark.parametrize("tag,tiny", [("tiny", True), ("full", False)])
-def test_loop_golden_through_hip_steps(tag, tiny):
+@pytest.mark.parametrize("tag,tiny,arith", [("tiny", True, "f32"), ("full", False, "f32"), ("full", False, "limb")])
+def test_loop_golden_through_hip_steps(tag, tiny, arith):
     """tests/golden/loop_{tiny,full}.npz: mel / wav of the reference-semantics loop (inference/Conan.py:95-156) built
     from the IMPORTED reference modules for a given code sequence (tools/make_goldens.py).  The HIP path is fed the
     golden codes chunk by chunk (conan_decoder_step -> conan_hifigan_step, 4 frames per step)."""
@@ -210,7 +210,7 @@ def test_loop_golden_through_hip_steps(tag, tiny):
     ctx, chp, vhp = _ctx(tiny=tiny, emformer=False)
     codes = torch.from_numpy(g["codes"]).int().cuda()[None]
     T = codes.shape[1]
-    st = ctx.streams(2, max_frames=4, max_ref_frames=64)
+    st = ctx.streams(2, max_frames=4, max_ref_frames=64, arith=arith)
     st.reset([1])
     st.set_reference([1], torch.from_numpy(g["ref"]).cuda())
     mels, wavs = [], []
@@ -221,18 +221,20 @@ def test_loop_golden_through_hip_steps(tag, tiny):
     mel, wav = torch.cat(mels, 1)[0].cpu().numpy(), torch.cat(wavs, 1)[0].cpu().numpy()
     np.testing.assert_allclose(mel, g["mel"], atol=1e-4, rtol=1e-4)
     np.testing.assert_allclose(wav, g["wav"], atol=1e-4, rtol=0)
+    if not tiny:
+        assert_arith_ran(kernels_of(st, lambda: st.hifigan_step([1], mels[0])), arith)
     st.close(); ctx.close()
 
 
 # ---------------------------------------------------------------------------------------------- vocoder / VQ taps
-@pytest.mark.parametrize("tag,tiny", [("tiny", True), ("full", False)])
-def test_vocoder_stage_taps_match_reference_goldens(tag, tiny):
+@pytest.mark.parametrize("tag,tiny,arith", [("tiny", True, "f32"), ("full", False, "f32"), ("full", False, "limb")])
+def test_vocoder_stage_taps_match_reference_goldens(tag, tiny, arith):
     """Per-stage tensors of HifiGanGenerator.forward captured by forward hooks on the imported reference
     (conv_pre_12, ups.{i}_12, pre_tanh_12) against the taps of conan_hifigan_step_taps, streamed 4 frames per step."""
     g = load_golden(f"hifigan_{tag}.npz")
     ctx, _, vhp = _ctx(tiny=tiny, emformer=False, conan=False)
     mel = torch.from_numpy(g["mel_12"]).transpose(1, 2).contiguous().cuda()       # [1,12,80]
-    st = ctx.streams(1, max_frames=4, max_ref_frames=16)
+    st = ctx.streams(1, max_frames=4, max_ref_frames=16, arith=arith)
     st.reset([0])
     parts = [st.hifigan_step_taps([0], mel[:, p:p + 4]) for p in range(0, 12, 4)]
     wav = torch.cat([p[0] for p in parts], 1)[0].cpu().numpy()
@@ -247,6 +249,8 @@ def test_vocoder_stage_taps_match_reference_goldens(tag, tiny):
         ref = g[f"ups.{i}_12"].T
         assert up.shape == ref.shape
         np.testing.assert_allclose(up, ref, atol=1e-4 * max(1.0, np.abs(ref).max()), rtol=0)
+    if not tiny:
+        assert_arith_ran(kernels_of(st, lambda: st.hifigan_step([0], mel[:, :4])), arith)
     st.close(); ctx.close()
 
 
@@ -272,7 +276,8 @@ def test_vq_ids_match_reference_golden(tag, tiny):
 
 
 # ---------------------------------------------------------------------------------------------- configs[4]
-def test_config4_b128_seg2_windowed_320ms():
+@pytest.mark.parametrize("arith", ARITHS)
+def test_config4_b128_seg2_windowed_320ms(arith):
     """BASELINE configs[4] as specified: 40 ms chunks (seg 2 + rc 2), batch = 128 streams, Conan / vocoder in windowed
     mode with a 320 ms (16-frame) context: state reset + 18 frames per step, last 2 frames kept; the Emformer stays
     stateful.  Oracle for three streams: the reference modules' restatement fed the same 18-frame window (SURVEY.md §0.6);
@@ -289,7 +294,8 @@ def test_config4_b128_seg2_windowed_320ms():
     T = nchunks * SEG + 2
     src = torch.from_numpy(np.concatenate([synth.mel(T, 1234 + s) for s in range(B)])).cuda()
     ref = torch.from_numpy(np.concatenate([synth.mel(Tr, 4321 + s) for s in range(B)])).cuda()
-    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=64, max_frames=CTX + SEG)
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=64, max_frames=CTX + SEG, arith=arith)
+    assert eng.st.arith == arith
     eng.start(ref)
     hist = torch.zeros(B, 0, dtype=torch.int32, device="cuda")
     outs = []
@@ -311,7 +317,7 @@ def test_config4_b128_seg2_windowed_320ms():
         np.testing.assert_allclose(mel_k[b].cpu().numpy(), m_ref[0, -SEG:].numpy(), atol=1e-4, rtol=1e-4)
         np.testing.assert_allclose(wav_k[b].cpu().numpy(), w_ref[-SEG * 320:].numpy(), atol=1e-4, rtol=0)
     # slot independence: streams run alone (batch of 2, other slots) reproduce their rows of the batch of 128
-    solo = StreamingVoiceConversionEngine(ctx, 2, max_ref_frames=64, max_frames=CTX + SEG)
+    solo = StreamingVoiceConversionEngine(ctx, 2, max_ref_frames=64, max_frames=CTX + SEG, arith=arith)
     for pair in ([5, 100], [63, 64]):
         solo.start(ref[pair])
         h = torch.zeros(2, 0, dtype=torch.int32, device="cuda")
@@ -321,6 +327,9 @@ def test_config4_b128_seg2_windowed_320ms():
             np.testing.assert_allclose(m2.cpu().numpy(), outs[kk][1][pair].cpu().numpy(), atol=2e-5, rtol=1e-5)
             np.testing.assert_allclose(w2.cpu().numpy(), outs[kk][0][pair].cpu().numpy(), atol=2e-5, rtol=0)
         assert torch.equal(h, hist[pair])
+    wmel = torch.from_numpy(synth.mel(CTX + SEG, 3, B)).cuda()
+    eng.st.reset(eng.slots, which=4)
+    assert_arith_ran(kernels_of(eng.st, lambda: eng.st.hifigan_step(eng.slots, wmel)), arith)
     eng.st.close(); solo.st.close(); ctx.close()
 
 

@@ -98,7 +98,8 @@ def test_fence_free_handoffs_match_the_fenced_build_under_concurrency():
     plain.close(); fenced.close(); ctx.close()
 
 
-def test_wide_stage_pairs_match_reference_goldens():
+@pytest.mark.parametrize("arith,S", [("f32", 24), ("limb", 24), ("limb", 48)])
+def test_wide_stage_pairs_match_reference_goldens(arith, S):
     """The first vocoder stage (C = 256) on stream-sets of >= 16 slots runs resblock_pair.hip: a pair of workgroups per
     (branch, stream) tile, xt history ring instead of a halo.  Reference goldens (tools/make_goldens.py: wav_150, wav_12,
     pre_tanh_12) streamed through slot 11 of a 24-slot stream-set while the other slots carry other streams, in steps
@@ -108,8 +109,7 @@ def test_wide_stage_pairs_match_reference_goldens():
     vhp = configs.hifigan_hparams()
     ctx = _voc_ctx(vhp)
     g = load_golden("hifigan_full.npz")
-    S = 24
-    st = ctx.streams(S, max_frames=4, max_ref_frames=16)
+    st = ctx.streams(S, max_frames=4, max_ref_frames=16, arith=arith)
     ids = list(range(S))
     st.reset(ids)
     mel = torch.from_numpy(synth.mel(150, 77, S)).cuda()                               # other streams
@@ -131,6 +131,15 @@ def test_wide_stage_pairs_match_reference_goldens():
     for r in range(3):
         np.testing.assert_allclose(wav12[r], g["wav_12"], atol=1e-4, rtol=0)
         np.testing.assert_allclose(pre12[r], g["pre_tanh_12"][0], atol=1e-4 * max(1.0, np.abs(g["pre_tanh_12"]).max()), rtol=0)
+    # which kernels carried the wide first stage: the f32 pair kernel (16-47 slots in either arithmetic, every f32 stream-set of
+    # >= 16 slots), conv_limb's grouped launches (limb stream-sets of >= 48 slots: 3 dilations x (c1, c2) + ups.2 + ups.3)
+    from tests.conftest import assert_arith_ran, kernels_of
+    names = kernels_of(st, lambda: st.hifigan_step(ids, mel[:, :4].contiguous()))
+    assert_arith_ran(names, arith)
+    if arith == "limb" and S >= 48:
+        assert sum(n for k, n in names.items() if "conv_limb_kernel" in k) >= 6 and not any("resblock_pair_kernel" in k for k in names), sorted(names)
+    else:
+        assert any("resblock_pair_kernel" in k for k in names), sorted(names)
     st.close(); ctx.close()
 
 
@@ -253,17 +262,17 @@ def test_decoder_widths_come_from_the_checkpoint(streams):
     ctx2.close()
 
 
-def _two_stream_sets(ctx, S, env_a, env_b):
-    """Two stream-sets created under the environment switches env_a / env_b (they are read at creation)."""
-    keys = set(env_a) | set(env_b)
+def _two_stream_sets(ctx, S, *envs, arith="limb"):
+    """Stream-sets created under the developer switches of each env (they are read at creation)."""
+    keys = set().union(*envs)
     old = {k: os.environ.get(k) for k in keys}
     try:
         sets = []
-        for env in (env_a, env_b):
+        for env in envs:
             for k in keys:
                 os.environ.pop(k, None)
             os.environ.update(env)
-            sets.append(ctx.streams(S, max_frames=4, max_ref_frames=16))
+            sets.append(ctx.streams(S, max_frames=4, max_ref_frames=16, arith=arith))
     finally:
         for k, v in old.items():
             if v is None:
@@ -280,19 +289,23 @@ def _kernel_names(st, ids, mel):
     return {r[0]: r[3] for r in st.profile_kernels()}       # kernel name -> launches
 
 
-@pytest.mark.parametrize("env,other", [({}, "f32"), ({"CONAN_RB_LIMB": "1", "CONAN_RB_PAIR": "1"}, "pair")])
+@pytest.mark.parametrize("env,other", [({}, "f32"), ({"CONAN_RB_PAIR": "1"}, "pair")])
 def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, other):
     """resblock_limb.hip / conv_limb.hip form every fp32 product from three bf16 limbs per operand (six bf16 MFMA products,
-    accumulated in fp32); CONAN_RB_LIMB=1 at stream-set creation switches them on (the default is the exact-f32 MFMA everywhere).
+    accumulated in fp32); conan_streams_opts.arith selects the form per stream-set.
     64 streams through a limb stream-set - limb kernels in the C = 128 / 64 / 32 ResBlock stages, in ups.2 / ups.3 and, for
     stream-sets of >= 48 slots, conv_limb's grouped launches (three problems of 3 / 7 / 11 taps per launch, list-scheduled tiles)
     for the ResBlock convs of the C = 256 stage - and through a default one (exact-f32 MFMA, pair kernel in the first stage) or
-    one with CONAN_RB_LIMB=1 CONAN_RB_PAIR=1 (limb kernels, but the f32 pair kernel in the first stage): per-stage tensors,
+    a limb one created with the developer switch CONAN_RB_PAIR=1 (limb kernels, but the f32 pair kernel in the first stage): per-stage tensors,
     pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch cross-check uses."""
     vhp = configs.hifigan_hparams()
     ctx = _voc_ctx(vhp)
     S = 64
-    a, b = _two_stream_sets(ctx, S, {"CONAN_RB_LIMB": "1"}, env)
+    a = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="limb")
+    if other == "pair":
+        (b,) = _two_stream_sets(ctx, S, env)[:1]
+    else:
+        b = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32")
     ids = list(range(S))
     mel = torch.from_numpy(synth.mel(16, 9, S)).cuda()
     for st in (a, b):
