@@ -116,7 +116,7 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
       e->lds_bytes = mega_rec_lds * 4;
       // the arrival-counter barriers need every workgroup of the grid resident at once: never launch more than the device can hold
       // (a quarter of the CUs is kept as margin for what else is resident); such a step keeps its separate launches
-      const long long cap = (long long)cnk::decoder_mega_blocks_per_cu(e->lds_bytes) * (ctx->num_cu - ctx->num_cu / 4);
+      const long long cap = (long long)cnk::decoder_mega_blocks_per_cu(e->lds_bytes, rb_limb) * (ctx->num_cu - ctx->num_cu / 4);
       if ((long long)e->groups * e->group_size > cap) e->ok = false;
     }
     if (e->ok) {
@@ -281,12 +281,44 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
   // decoder: CausalConvBlocks (conv.py:127-264)
   int cur = 0;
   const float kscale = (float)std::pow((double)c.dec_kernel, -0.5);
+  // Megakernel, several row tiles: a sub-layer [LN -> k5 conv -> GELU] -> [1x1 conv + residual, masks] is ONE operator (MOP_FFN:
+  // member s of a group computes its 64 hidden columns into LDS and multiplies them at once with its K range of the 1x1 conv;
+  // the 16 x 512 hidden tile never leaves the CUs, one group barrier / gather / write-through round per sub-layer is gone).  The
+  // sub-layer's output x' = ((p0 + .. + p7) + bias + x) * masks then exists as 8 partial tensors until its consumer - the next
+  // sub-layer's LayerNorm prologue, or the post conv's - forms it; that consumer also stores x' (its own consumer's residual).
+  // Two sets of partial tensors alternate: members still read one while the faster ones already write the next.
+  static const bool blk_fuse_on = getenv("CONAN_MEGA_NOBLK") == nullptr;          // developer switch
+  struct BlkParts { bool on = false; const float* xp = nullptr; const float* bias = nullptr; TRef xres, m1, m2; int has_m2 = 0; } bp;
+  int pset = 0;
+  auto blk_consume = [&](cnk::RowConvArgs& a, bool store) {
+    a.xp = bp.xp; a.xp_stride = part_stride; a.xparts = mega_gs; a.xp_ld = H; a.xbias = bp.bias; a.xres = bp.xres; a.has_xres = 1;
+    a.xm1 = bp.m1; a.has_xm1 = 1; a.xm2 = bp.m2; a.has_xm2 = bp.has_m2; a.xstore = store ? 1 : 0;
+  };
   for (int b = 0; b < c.dec_num_blocks; ++b) {
-    const TRef blkmask = b == 0 ? c_mask_out.ref() : c_mask_blk.ref();
+    // (block masks alternate between two buffers: the consumer of block b's last sub-layer reads block b's mask while it writes block b + 1's)
+    const TRef blkmask = b == 0 ? c_mask_out.ref() : ((b & 1) ? c_mask_blk.ref() : c_mask_blk2.ref());
     for (int j = 0; j < c.dec_layers_in_block; ++j) {
       const std::string nm = "conan.dec." + std::to_string(b) + "." + std::to_string(j);
       Ring& lr = c_lnrs[b * c.dec_layers_in_block + j];
       const bool last_sub = b == c.dec_num_blocks - 1 && j == c.dec_layers_in_block - 1;
+      {
+        const PackedConv &p1 = ctx->conv(nm + ".c1"), &p2 = ctx->conv(nm + ".c2");
+        if (mega_rec && blk_fuse_on && n * T > 16 && rowconv_ok(p1, c.dec_dilations[b], T) && p2.wf && p2.k == 1 && p1.Cout % (64 * mega_gs) == 0 &&
+            p1.Cout / mega_gs <= 256 && (p1.Cout / mega_gs == 64 || (p1.Cout / mega_gs) % 128 == 0) && p2.Cin == p1.Cout && p2.Cout == H && H % 64 == 0) {
+          cnk::RowConvArgs a = mk_rc(p1, c_x[cur].ref(), c_h.ref(), n, T, c.dec_dilations[b]);
+          a.ln = 1; a.hist = lr.ref(); a.gamma = ctx->vec(nm + ".ln.g"); a.beta = ctx->vec(nm + ".ln.b");
+          if (j == 0) { a.mask_out = blkmask; a.has_mask_out = 1; }
+          a.out_scale = kscale; a.out_act = cnk::ACT_GELU;
+          float* const pw = (pset ? c_part2 : c_part).base;
+          a.w2 = p2.wf; a.part = pw; a.part_stride = part_stride; a.Cout2 = p2.Cout; a.Cout2_pad = p2.wf_cout_pad;
+          if (bp.on) blk_consume(a, true);          // x = the previous sub-layer's output, still in parts: formed (and stored to c_x[cur]) by this operator's prologue
+          rowconv(a, st);
+          bp.on = true; bp.xp = pw; bp.bias = p2.bias; bp.xres = c_x[cur].ref(); bp.m1 = blkmask; bp.m2 = c_mask_out.ref(); bp.has_m2 = last_sub ? 1 : 0;
+          pset ^= 1; cur ^= 1;
+          continue;
+        }
+      }
+      if (bp.on) { mega_rec_ok = false; return; }      // (a fused sub-layer followed by one that is not: this step keeps its separate launches)
       if (rowconv_ok(ctx->conv(nm + ".c1"), c.dec_dilations[b], T) && rowconv_ok(ctx->conv(nm + ".c2"), 1, T)) {
         // LayerNorm (prologue: new rows normalised in LDS and appended to the layer's ring) -> k5 conv -> x k^-0.5 -> GELU
         cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".c1"), c_x[cur].ref(), c_h.ref(), n, T, c.dec_dilations[b]);
@@ -314,10 +346,12 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
       cur ^= 1;
     }
   }
+  if (bp.on && !rowconv_ok(ctx->conv("conan.dec.post"), 1, T)) { mega_rec_ok = false; return; }
   if (rowconv_ok(ctx->conv("conan.dec.post"), 1, T)) {   // last LayerNorm (x mask) as the prologue of the post conv
     cnk::RowConvArgs a = mk_rc(ctx->conv("conan.dec.post"), c_x[cur].ref(), c_post.ref(), n, T);
     a.ln = 1; a.hist = c_lastr.ref(); a.gamma = ctx->vec("conan.dec.last.g"); a.beta = ctx->vec("conan.dec.last.b");
     a.lnmask = c_mask_out.ref(); a.has_lnmask = 1; a.m1 = c_mask_out.ref(); a.has_m1 = 1;
+    if (bp.on) blk_consume(a, false);               // the last sub-layer's output, from its partial tensors
     rowconv(a, st);
   } else {
     cnk::LNArgs ln = mk_ln(c_x[cur].ref(), c_lastr.ref(), ctx->vec("conan.dec.last.g"), ctx->vec("conan.dec.last.b"), d_slots, pos, n, T, H);

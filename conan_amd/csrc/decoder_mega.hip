@@ -69,7 +69,12 @@ __device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target,
 }
 
 // gbar: one arrival counter per group, 64 bytes apart (zero at launch, zeroed again by the kernel); bar: the grid's (counts for ever)
-__global__ __launch_bounds__(256, 6) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS,
+// OCC = waves per SIMD the register allocation is bounded for: 6 (80 registers: a wave fits beside two waves of every vocoder
+// kernel, the f32 ResBlock passes' 216 included; the operators' bodies then spill ~35 registers to scratch - reloaded once per
+// operator, outside the K loops) for exact-f32 stream-sets; 4 (128 registers, no spills) for bf16-limb stream-sets, whose
+// resident kernels (resblock_limb <= 192, conv_limb's streaming shapes <= 192) leave 2 x 192 + 128 = 512 - tests/test_kernel_resources.py.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS,
                                                               const int* __restrict__ slots, const int* __restrict__ pos, const int n, const int T,
                                                               unsigned* __restrict__ gbar, unsigned* __restrict__ bar, const unsigned bar_base,
                                                               unsigned long long* __restrict__ dbg, unsigned* __restrict__ guard) {
@@ -176,15 +181,21 @@ int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats) {
 }
 
 // workgroups of the megakernel that one CU can hold at once with `lds_bytes` of dynamic LDS (its barriers need the whole grid resident)
-int decoder_mega_blocks_per_cu(int lds_bytes) {
+int decoder_mega_blocks_per_cu(int lds_bytes, bool wide_regs) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel, 256, (size_t)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const hipError_t e = wide_regs ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<4>, 256, (size_t)lds_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<6>, 256, (size_t)lds_bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nb;
 }
 
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st) {
-  hipLaunchKernelGGL(decoder_mega_kernel, dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                     m.gbar, m.bar, m.bar_base, m.dbg, m.guard);
+  if (m.wide_regs)
+    hipLaunchKernelGGL(decoder_mega_kernel<4>, dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard);
+  else
+    hipLaunchKernelGGL(decoder_mega_kernel<6>, dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard);
 }
 
 }  // namespace cnk

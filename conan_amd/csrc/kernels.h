@@ -239,6 +239,11 @@ struct RowConvArgs {
   // consumer side: the NEW rows of x are not a tensor but xparts partial tensors: x = ((p0 + p1 + ..) + xbias) + xres
   const float* xp; long long xp_stride; int xparts, xp_ld;
   const float* xbias; TRef xres; int has_xres;
+  // ... and, for the decoder's fused conv blocks (LN -> k5 conv -> GELU -> 1x1 partial sums, conv.py:127-264), the rest of the
+  // producer's epilogue: x = (((p0 + p1 + ..) + xbias) + xres) * xm1 * xm2; xstore: the summed rows are also stored to `x`
+  // (row r by member r % members), where the NEXT fused operator's consumer finds them as its xres
+  TRef xm1, xm2; int has_xm1, has_xm2, xstore;
+  int hid_overlay;      // MOP_FFN with one 64-column hidden strip per member: the hidden tile overlays the window (read out by then)
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);
 void launch_rowconv(const RowConvArgs& a, hipStream_t st);
@@ -419,7 +424,7 @@ struct MegaOp {
   union U { RowConvArgs rc; LNArgs ln; XAttnArgs xa; PitchHeadArgs ph; EmbedArgs em; MegaCopy cp; MegaAdvance adv; } u;
 };
 int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats);
-int decoder_mega_blocks_per_cu(int lds_bytes);
+int decoder_mega_blocks_per_cu(int lds_bytes, bool wide_regs);
 // prog: device copy of nops operators.  njobs 16-row tiles are dealt over `groups` groups of `group_size` workgroups; kw4: the
 // step is one tile and its strips are 16 columns with the K loop split over a workgroup's waves.  gbar: one zero-initialised
 // counter per group, 16 words apart; bar: the grid barrier's counter, counts for ever - bar_base is its value before this
@@ -429,6 +434,7 @@ struct MegaLaunch {
   const int* slots; const int* pos; int n, T;
   unsigned* gbar; unsigned* bar; unsigned bar_base; unsigned long long* dbg;
   unsigned* guard;        // SpinGuard block of the stream-set (nullptr: unbounded waits)
+  int wide_regs;          // 1: the 128-register build (bf16-limb stream-sets), 0: the 80-register build
 };
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st);
 

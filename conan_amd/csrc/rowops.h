@@ -709,7 +709,11 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
       }
       if (a.xbias) { const float4 q = ldw4(a.xbias + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
       if (a.has_xres) { const float4 q = ld4<true>(row(a.xres, id.i, id.slot, id.pos, id.t) + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+      if (a.has_xm1) { const float mk = ld1<true>(row(a.xm1, id.i, id.slot, id.pos, id.t)); acc.x *= mk; acc.y *= mk; acc.z *= mk; acc.w *= mk; }
+      if (a.has_xm2) { const float mk = ld1<true>(row(a.xm2, id.i, id.slot, id.pos, id.t)); acc.x *= mk; acc.y *= mk; acc.z *= mk; acc.w *= mk; }
       *reinterpret_cast<float4*>(win + (r + (tb.row_seg[r] + 1) * halo) * LDX + c4 * 4) = acc;
+      // (the tensor itself, for the operator behind this one that adds it as its residual)
+      if (a.xstore && (r % nact) == sb) st4<true>(row(a.x, id.i, id.slot, id.pos, id.t) + c4 * 4, acc);
     }
   }
   __syncthreads();
@@ -863,9 +867,10 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
   }
 }
 
-// MOP_FFN (the aligner's feed-forward, prosody_util.py:139-158): after mg_stage (LayerNorm prologue) member `sb` computes ITS
-// HC = Cout / GS hidden columns of the first 1x1 conv (activation applied) into LDS and multiplies them straight away with its
-// K range of the second 1x1 conv: the hidden tensor never leaves the CU and the 2048-deep K loop is split over the group.
+// MOP_FFN (the aligner's feed-forward, prosody_util.py:139-158, and the decoder's conv blocks [LN -> k5 conv -> GELU] ->
+// [1x1 conv + residual], conv.py:127-264): after mg_stage (LayerNorm prologue) member `sb` computes ITS HC = Cout / GS hidden
+// columns of the first conv (k taps; activation applied) into LDS and multiplies them straight away with its K range of the
+// second, 1x1 conv: the hidden tensor never leaves the CU and the second conv's K loop is split over the group.
 // The member's partial sums [rows][Cout2] go to part[sb]; bias, residual and the norm behind them are applied where the sum is
 // consumed (RowConvArgs / LNArgs: xp ..).  LDS: window [wr_max][Cin + 8] | hidden [16][HC + 8].
 template <class A>
@@ -878,10 +883,14 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
   const int lr = lane & 15, lg = lane >> 4;
   const int Cin = a.Cin, LDX = Cin + 8;
   const int HC = a.Cout / GS, LDH = HC + 8;           // hidden columns of this member (a multiple of 64)
-  float* const hid = win + a.wr_max * LDX;
-  {   // ---- first conv: strips sb * HC/64 .. of 64 columns, one 16-column tile per wave, into LDS
-    const int KQ = Cin >> 4;
-    const long long ct_stride = 2ll * KQ * 256;       // k = 1: one tap + the zero tap
+  const bool overlay = a.hid_overlay != 0;            // one strip per member: the hidden tile takes the window's place once it is read out
+  float* const hid = overlay ? win : win + a.wr_max * LDX;
+  {   // ---- first conv (k taps, dilation d): strips sb * HC/64 .. of 64 columns, one 16-column tile per wave, into LDS
+    const int k = a.ktaps;
+    const int KQ = Cin >> 4, NG = k * KQ;             // NG % RC_D == 0 (host)
+    const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
+    const int tstep = a.dil * LDX;
+    const long long ct_stride = (long long)(k + 1) * KQ * 256;       // k taps + the zero tap
     const float* const abase = win + tb.tab[lr] * LDX + 4 * lg;
     for (int s = 0; s < HC / 64; ++s) {
       const int ct0 = (sb * (HC / 64) + s) * 4 + wave;
@@ -891,11 +900,11 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
 #pragma unroll
       for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
       float4 af = *reinterpret_cast<const float4*>(abase);
-      for (int G0 = 0; G0 < KQ; G0 += RC_D) {
+      for (int G0 = 0; G0 < NG; G0 += RC_D) {
 #pragma unroll
         for (int u = 0; u < RC_D; ++u) {
           const int Gn = G0 + u + 1;
-          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < KQ ? Gn * 16 : 0));
+          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < NG ? (Gn >> kqs) * tstep + (Gn & kqm) * 16 : 0));
           f32x4& p = (u & 1) ? acc1 : acc0;
           f32x4& q = (u & 1) ? acc0 : acc1;
           p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
@@ -908,6 +917,7 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
       }
       const int col = ct0 * 16 + lr;
       const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
+      if (overlay) __syncthreads();                   // every wave has read its last window fragment
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = ((acc0[e] + acc1[e]) + bias) * a.out_scale;
@@ -920,31 +930,46 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
   }
   __syncthreads();
   {   // ---- second conv, this member's K range: hidden channels [sb * HC, (sb + 1) * HC) of every 16-column output tile
-    const int KQ2 = a.Cout >> 4, KQm = HC >> 4;       // K groups per tap in memory / of this member
+    const int KQ2 = a.Cout >> 4, KQm = HC >> 4;       // K groups per tap in memory / of this member (4, or a multiple of RC_D)
     const long long ct_stride2 = 2ll * KQ2 * 256;
     const float* const abase = hid + lr * LDH + 4 * lg;
     float* const pbase = a.part + (long long)sb * a.part_stride;
     for (int ct = wave; ct * 16 < a.Cout2_pad; ct += 4) {
       const float* wl = a.w2 + (long long)ct * ct_stride2 + (long long)(sb * KQm) * 256 + lane * 4;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      float4 bw[RC_D];
+      if (KQm >= RC_D) {
+        float4 bw[RC_D];
 #pragma unroll
-      for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
-      float4 af = *reinterpret_cast<const float4*>(abase);
-      for (int G0 = 0; G0 < KQm; G0 += RC_D) {
+        for (int u = 0; u < RC_D; ++u) { bw[u] = ldw4(wl + (long long)u * 256); __builtin_amdgcn_sched_barrier(0); }
+        float4 af = *reinterpret_cast<const float4*>(abase);
+        for (int G0 = 0; G0 < KQm; G0 += RC_D) {
 #pragma unroll
-        for (int u = 0; u < RC_D; ++u) {
-          const int Gn = G0 + u + 1;
-          const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < KQm ? Gn * 16 : 0));
+          for (int u = 0; u < RC_D; ++u) {
+            const int Gn = G0 + u + 1;
+            const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < KQm ? Gn * 16 : 0));
+            f32x4& p = (u & 1) ? acc1 : acc0;
+            f32x4& q = (u & 1) ? acc0 : acc1;
+            p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+            // (past this member's range: the next member's groups / the zero tap - in bounds, never used)
+            bw[u] = ldw4(wl + (long long)(G0 + u + RC_D) * 256);
+            af = afn;
+          }
+        }
+      } else {      // four K groups per member (a 64-column hidden strip): all of them in flight at once
+        float4 bw[4], af[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { bw[u] = ldw4(wl + (long long)u * 256); af[u] = *reinterpret_cast<const float4*>(abase + u * 16); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
           f32x4& p = (u & 1) ? acc1 : acc0;
           f32x4& q = (u & 1) ? acc0 : acc1;
-          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
-          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
-          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
-          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
-          // (past this member's range: the next member's groups / the zero tap - in bounds, never used)
-          bw[u] = ldw4(wl + (long long)(G0 + u + RC_D) * 256);
-          af = afn;
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].x, bw[u].x, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].y, bw[u].y, q, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].z, bw[u].z, p, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u].w, bw[u].w, q, 0, 0, 0);
         }
       }
       const int col = ct * 16 + lr;

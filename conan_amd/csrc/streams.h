@@ -120,7 +120,7 @@ struct conan_streams {
   Ring c_emb, c_pin2, c_lastr;
   std::vector<Ring> c_uvh;      // outputs of the uv predictor's conv layers but the last (each keeps its own left context)
   std::vector<Ring> c_lnrs;     // post-LN rings, one per (block, sub-layer)
-  Lin c_pin, c_q, c_att, c_a1, c_a2, c_ff, c_uv5, c_x[2], c_h, c_post, c_mask_blk, c_mask_out, c_mel, c_part;
+  Lin c_pin, c_q, c_att, c_a1, c_a2, c_ff, c_uv5, c_x[2], c_h, c_post, c_mask_blk, c_mask_blk2, c_mask_out, c_mel, c_part, c_part2;
   float* c_style = nullptr;     // [slot][H]
   float* c_kv = nullptr;        // [slot][2 layers][S_max][2H]
   float* c_kmask = nullptr;     // [slot][S_max]

@@ -171,10 +171,13 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     int ldsf = 0;
     const int v = cnk::rowconv_plan(op.u.rc, &op.nbx, &op.nby, &ldsf);
     op.type = v == 3 ? cnk::MOP_ROWLIN : (v == 2 ? cnk::MOP_RC114 : cnk::MOP_RC111);
-    if (a.w2) {        // fused feed-forward: behind the window, the member's 16 x (Cout / 8 + 8) hidden tile
-      if (v != 0) { mega_rec_ok = false; return; }
+    if (a.w2) {        // fused conv -> 1x1 conv: behind the window, the member's 16 x (Cout / 8 + 8) hidden tile - or, with a single 64-column
+                       // hidden strip per member (the decoder's conv blocks), in the window's place once every wave has read it out
+      if (v != 0 || (a.ktaps * (a.Cin >> 4)) % 8 != 0) { mega_rec_ok = false; return; }
       op.type = cnk::MOP_FFN;
-      ldsf = op.u.rc.wr_max * (a.Cin + 8) + 16 * (a.Cout / mega_gs + 8);
+      const int hc = a.Cout / mega_gs;
+      op.u.rc.hid_overlay = hc == 64 ? 1 : 0;
+      ldsf = op.u.rc.hid_overlay ? std::max(op.u.rc.wr_max * (a.Cin + 8), 16 * (hc + 8)) : op.u.rc.wr_max * (a.Cin + 8) + 16 * (hc + 8);
       mega_rec_flops += 2.0 * (double)a.n * a.T * a.Cout * a.Cout2;
     }
     mega_rec_flops += fl;
@@ -266,9 +269,9 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   cnk::MegaLaunch m; memset(&m, 0, sizeof(m));
   m.prog = e.dev; m.nops = e.nops; m.njobs = e.njobs; m.groups = e.groups; m.group_size = e.group_size; m.kw4 = e.kw4; m.lds_bytes = e.lds_bytes;
   m.slots = d_slots; m.pos = pos_dec; m.n = e.n; m.T = e.T;
-  m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg; m.guard = d_guard;
+  m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg; m.guard = d_guard; m.wide_regs = rb_limb ? 1 : 0;
   if (test_fault == 1) { m.bar_base += 1u; test_fault = 0; }       // test hook: the grid barrier waits for one arrival too many
-  profiled("cnk::decoder_mega_kernel", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
+  profiled(rb_limb ? "cnk::decoder_mega_kernel<4>" : "cnk::decoder_mega_kernel<6>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
 }
 
@@ -745,8 +748,9 @@ void conan_streams::build_decoder() {
   c_lastr = mk_ring(H, 1, c.dec_post_kernel - 1, &dec_state);
   c_pin = mk_lin(F, H); c_q = mk_lin(F, H); c_att = mk_lin(F, H); c_a1 = mk_lin(F, H); c_a2 = mk_lin(F, H);
   c_ff = mk_lin(F, ffn); c_uv5 = mk_lin(F, uvh); c_x[0] = mk_lin(F, H); c_x[1] = mk_lin(F, H); c_h = mk_lin(F, 2 * H);
-  c_post = mk_lin(F, H); c_mask_blk = mk_lin(F, 1); c_mask_out = mk_lin(F, 1); c_mel = mk_lin(F, c.num_mels);
+  c_post = mk_lin(F, H); c_mask_blk = mk_lin(F, 1); c_mask_blk2 = mk_lin(F, 1); c_mask_out = mk_lin(F, 1); c_mel = mk_lin(F, c.num_mels);
   c_part = mk_lin(F, 16 * H);       // decoder megakernel: the 8 group members' partial sums of a fused feed-forward, [member][row][H]
+  c_part2 = mk_lin(F, 16 * H);      // ... and a second set: consecutive fused conv blocks write one while the members still read the other
   S_max = (max_ref + 3) / 4;
   if (S_max > 512) throw Error(CONAN_ERR_UNSUPPORTED, "max_ref_frames > 2048");
   c_style = alloc((size_t)max_slots * H);

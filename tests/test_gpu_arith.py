@@ -11,11 +11,14 @@ fused ResBlock passes C = 128 / 64 / 32 (resblock_limb) and the upsamplers ups.2
 the kernel read and the tensor it wrote through conan_hifigan_step_taps, evaluates the float64 reference on the tensor read,
 and asserts
 
-    rms error(limb) <= 1.25 x rms error(f32)      and      max error(limb) <= 1.25 x max error(f32)
+    rms error(limb) <= 1.25 x rms error(f32)      and      tail error(limb) <= 1.25 x tail error(f32)
 
-on four families of inputs: N(0, 1)-like activations (the synthetic checkpoint), per-channel scales 2^-20 .. 2^20, weights and
-inputs with uniformly random 23-bit mantissas, and magnitudes around 2^-60.  A fifth case states what happens where the limb form
-leaves its exact range: operands (or products) so small that a third limb or a cross product is a bf16 / fp32 denormal.
+(tail = the 99.9th percentile of the per-channel-normalised |error|; the single largest error - one sample out of 1e5..1e6
+roundings, which scatters by tens of per cent between two correct kernels - is printed and held to 2 x) on five families of
+inputs: N(0, 1)-like activations (the synthetic checkpoint), per-channel scales 2^-20 .. 2^20, weights and inputs with uniformly
+random 23-bit mantissas, magnitudes around 2^-60, and magnitudes around 2^-110 - where the third limb of an operand is a bf16
+DENORMAL (the split is exact down to |x| = 2^-109: bf16 denormals reach 2^-133 and the bf16 MFMA honours them; measured: the limb
+kernels keep the f32 kernels' error there).  A last case states what happens below that range.
 Weight-norm is folded on the host (one fp32 tensor per conv in the checkpoint, `<prefix>.weight`), so the library and the
 float64 reference multiply bit-identical weights."""
 import numpy as np
@@ -71,9 +74,9 @@ def _case(name, vhp):
                 e = int(np.round(np.log2(1.0 / np.sqrt(fan)))) - 1
                 sd[k] = _random_mantissas(rng, sd[k].shape, e - 2, e + 1)
         mel = _random_mantissas(rng, mel.shape, -3, 1)
-    elif name in ("tiny60", "tiny110"):
-        # activations around 2^-60 / 2^-110 in every stage: the first upsampler scaled down, no biases behind it
-        sc = np.float32(2.0 ** (-60 if name == "tiny60" else -110))
+    elif name in ("tiny60", "tiny110", "tiny125"):
+        # activations around 2^-60 / 2^-110 / 2^-125 in every stage: the first upsampler scaled down, no biases behind it
+        sc = np.float32(2.0 ** -int(name[4:]))
         sd["ups.0.conv.conv.weight"] = sd["ups.0.conv.conv.weight"] * sc
         sd["ups.0.conv.conv.bias"] = sd["ups.0.conv.conv.bias"] * sc
         for k in list(sd):
@@ -101,17 +104,25 @@ def _run(ctx, arith, mel):
 
 
 def _errors(got, want):
-    """(rms error / rms of the reference, max error / max of the reference, rms over channels of the per-channel relative rms
-    error) of got [n, rows, C] fp32 against want float64."""
+    """Error statistics of got [n, rows, C] fp32 against want float64:
+      rms   rms error / rms of the reference;
+      p999  the 99.9th percentile of |error| / (rms of the reference in that channel): the tail of the error distribution with
+            every channel weighted alike;
+      max   max |error| / (rms of the reference in its channel): ONE sample (the largest of 1e5-1e6 roundings), so it scatters by
+            tens of per cent between two correct kernels that round differently - bounded loosely;
+      chrms rms over channels of the per-channel relative rms error."""
     e = got.double() - want
     rms = float(e.pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
-    mx = float(e.abs().max() / want.abs().max())
-    ch = (e.pow(2).mean((0, 1)).sqrt() / want.pow(2).mean((0, 1)).sqrt().clamp_min(1e-300))
-    return rms, mx, float(ch.pow(2).mean().sqrt())
+    crms = want.pow(2).mean((0, 1)).sqrt().clamp_min(1e-300)
+    en = (e.abs() / crms).flatten()
+    p999 = float(torch.quantile(en[:: max(1, en.numel() // 2000000)], 0.999))
+    mx = float(en.max())
+    ch = e.pow(2).mean((0, 1)).sqrt() / crms
+    return rms, p999, mx, float(ch.pow(2).mean().sqrt())
 
 
 def _measure(case):
-    """Per kernel under test: {name: {arith: (rms, max, per-channel rms)}} + the kernels each stream-set launched."""
+    """Per kernel under test: {name: {arith: (rms, p99.9, max, per-channel rms), "ref_rms": ..}} + the kernels each stream-set launched."""
     from conan_amd.runtime import Context
     from oracle import hifigan as ohifi
     vhp = configs.hifigan_hparams()
@@ -134,12 +145,14 @@ def _measure(case):
                     acc = acc + ohifi.resblock1(sd64, i * nb + j, up64, vhp["resblock_dilation_sizes"][j])
                 want = torch.nn.functional.leaky_relu(acc / nb, ohifi.LRELU_SLOPE).transpose(1, 2)
             res.setdefault(f"stage.{i}", {})[arith] = _errors(outs[i], want)
+            res[f"stage.{i}"]["ref_rms"] = float(want.pow(2).mean().sqrt())
             if i + 1 < len(ups):
                 # the next upsampler: conv + pixel shuffle in float64 on the tensor it read (the stage output, already activated)
                 with torch.no_grad():
                     y = ohifi._cconv(sd64, f"ups.{i + 1}.conv.conv", outs[i].double().transpose(1, 2))
                     want_up = ohifi.pixel_shuffle_1d(y, vhp["upsample_rates"][i + 1]).transpose(1, 2)
                 res.setdefault(f"ups.{i + 1}", {})[arith] = _errors(ups[i + 1], want_up)
+                res[f"ups.{i + 1}"]["ref_rms"] = float(want_up.pow(2).mean().sqrt())
     ctx.close()
     return res, ran
 
@@ -158,38 +171,39 @@ def _check_kernels(ran):
 LIMB_KERNELS = ("stage.0", "stage.1", "stage.2", "stage.3", "ups.2", "ups.3")
 
 
-@pytest.mark.parametrize("case", ["normal", "scales", "mantissas", "tiny60"])
+@pytest.mark.parametrize("case", ["normal", "scales", "mantissas", "tiny60", "tiny110"])
 def test_limb_error_against_float64_is_within_the_f32_mfma_kernels(case):
     res, ran = _measure(case)
     _check_kernels(ran)
-    print(f"\n[arith-vs-f64] case {case}: relative error (rms, max, per-channel rms) f32 | limb")
+    print(f"\n[arith-vs-f64] case {case}: relative error (rms, p99.9, max, per-channel rms) f32 | limb | ratios")
     for k in sorted(res):
         f, l = res[k]["f32"], res[k]["limb"]
-        print(f"  {k:8s} f32 {f[0]:.3e} {f[1]:.3e} {f[2]:.3e} | limb {l[0]:.3e} {l[1]:.3e} {l[2]:.3e} | ratio {l[0] / f[0]:.2f} {l[1] / f[1]:.2f} {l[2] / f[2]:.2f}")
+        print(f"  {k:8s} f32 {f[0]:.3e} {f[1]:.3e} {f[2]:.3e} {f[3]:.3e} | limb {l[0]:.3e} {l[1]:.3e} {l[2]:.3e} {l[3]:.3e} | "
+              f"{l[0] / f[0]:.2f} {l[1] / f[1]:.2f} {l[2] / f[2]:.2f} {l[3] / f[3]:.2f}")
     for k in LIMB_KERNELS:
         f, l = res[k]["f32"], res[k]["limb"]
         assert f[0] < 2e-6 and l[0] < 2e-6, (k, f, l)                     # both are fp32-accurate convolutions
         assert l[0] <= 1.25 * f[0], (case, k, "rms", f, l)
-        assert l[1] <= 1.25 * f[1], (case, k, "max", f, l)
-        assert l[2] <= 1.25 * f[2], (case, k, "per-channel rms", f, l)
+        assert l[1] <= 1.25 * f[1], (case, k, "99.9th percentile", f, l)
+        assert l[3] <= 1.25 * f[3], (case, k, "per-channel rms", f, l)
+        assert l[2] <= 2.0 * f[2], (case, k, "max (one sample)", f, l)
 
 
 def test_limb_underflow_range_is_stated():
-    """Where the limb form leaves its exact range.  The third limb of an operand |x| < 2^-110 is a bf16 denormal, and the cross
-    products h * l', m * m', l * h' of a product |x w| < 2^-100 are fp32 denormals; the matrix unit treats denormal operands /
-    products as zero.  The limb result then carries the first two limb pairs only: a relative error of up to 2^-15 per product
-    instead of 2^-24 - on values below 2^-100 (1e-30), i.e. an ABSOLUTE error below 2^-115.  (Audio, mel and every activation
-    of the path live between 1e-6 and 1e3; the f32 kernels are exact to fp32 rounding down to their own denormal range.)
-    Asserted here, with every stage's activations pushed to ~2^-110: the limb stream-set stays finite, agrees with float64 to
-    2^-13 relative (graceful: never worse than two limbs), and the f32 stream-set keeps its 2e-6."""
-    res, ran = _measure("tiny110")
+    """Below the exact range.  An fp32 operand splits exactly into three bf16 limbs as long as its last significand bit is a bf16
+    (denormal) value: |x| >= 2^-109.  Below that the third limb is rounded at bf16's denormal spacing 2^-133, an ABSOLUTE error of
+    at most 2^-134 per operand - on products below 2^-109 |w|, i.e. below 1e-33 for the weights of this path (activations, mel and
+    audio live between 1e-6 and 1e3).  Asserted with every stage's activations pushed to ~2^-125 (fp32's own denormal range begins
+    at 2^-126): the limb stream-set stays finite, its absolute error stays below 2^-130, and it agrees with float64 to 2^-7
+    relative - graceful, never worse than two limbs; the f32 stream-set is the yardstick."""
+    res, ran = _measure("tiny125")
     _check_kernels(ran)
-    print("\n[arith-vs-f64] case tiny110 (activations ~2^-110): relative error (rms, max) f32 | limb")
+    print("\n[arith-vs-f64] case tiny125 (activations ~2^-125): relative error (rms, p99.9, max, per-channel rms) f32 | limb; rms of the reference")
     for k in sorted(res):
         f, l = res[k]["f32"], res[k]["limb"]
-        print(f"  {k:8s} f32 {f[0]:.3e} {f[1]:.3e} | limb {l[0]:.3e} {l[1]:.3e}")
+        print(f"  {k:8s} f32 {f[0]:.3e} {f[1]:.3e} {f[2]:.3e} | limb {l[0]:.3e} {l[1]:.3e} {l[2]:.3e} | ref rms {res[k]['ref_rms']:.3e}")
     for k in LIMB_KERNELS:
         f, l = res[k]["f32"], res[k]["limb"]
         assert np.isfinite(l[0]) and np.isfinite(f[0])
-        assert f[0] < 2e-6, (k, f)
-        assert l[0] <= 2.0 ** -13 and l[1] <= 2.0 ** -12, (k, l)
+        assert l[0] <= 2.0 ** -7, (k, l)
+        assert l[0] * res[k]["ref_rms"] <= 2.0 ** -130, (k, l, res[k]["ref_rms"])
