@@ -81,6 +81,7 @@ _PROTOS = {
     "conan_step_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "conan_streams_join": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_streams_output_fence": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "conan_streams_output_fence_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_streams_test_fault": (C.c_int, [C.c_void_p, C.c_int]),
     "conan_profile_mark": (C.c_int, [C.c_void_p, C.c_void_p]),
     "conan_step_clock": (C.c_int, [C.c_void_p, C.c_int]),

@@ -462,9 +462,12 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     HIP_CHECK(hipEventRecord(s->ev_front[p], s->st_front));
     HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_front[p], 0));
     if (s->fence_set) {      // the caller's output fence: only the stage that writes the audio buffer waits for it
-      HIP_CHECK(hipEventRecord(s->ev_fence[p], s->fence_stream));
-      HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_fence[p], 0));
-      s->fence_set = false;
+      if (s->fence_event) HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->fence_event, 0));
+      else {
+        HIP_CHECK(hipEventRecord(s->ev_fence[p], s->fence_stream));
+        HIP_CHECK(hipStreamWaitEvent(s->st_voc, s->ev_fence[p], 0));
+      }
+      s->fence_set = false; s->fence_event = nullptr;
     }
     if (tl) HIP_CHECK(hipEventRecord(te[4], s->st_voc));
     if (!s->ev_wide[p]) HIP_CHECK(hipEventCreateWithFlags(&s->ev_wide[p], hipEventDisableTiming));
@@ -540,7 +543,14 @@ int conan_streams_test_fault(conan_streams* s, int kind) {
 int conan_streams_output_fence(conan_streams* s, void* fence_stream) {
   return guarded([&] {
     if (!s) throw Error(CONAN_ERR_INVALID, "null streams");
-    s->fence_stream = (hipStream_t)fence_stream; s->fence_set = true;
+    s->fence_stream = (hipStream_t)fence_stream; s->fence_event = nullptr; s->fence_set = true;
+  });
+}
+
+int conan_streams_output_fence_event(conan_streams* s, void* event) {
+  return guarded([&] {
+    if (!s || !event) throw Error(CONAN_ERR_INVALID, "null argument");
+    s->fence_event = (hipEvent_t)event; s->fence_stream = nullptr; s->fence_set = true;
   });
 }
 

@@ -287,7 +287,12 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
   // sub-layer's output x' = ((p0 + .. + p7) + bias + x) * masks then exists as 8 partial tensors until its consumer - the next
   // sub-layer's LayerNorm prologue, or the post conv's - forms it; that consumer also stores x' (its own consumer's residual).
   // Two sets of partial tensors alternate: members still read one while the faster ones already write the next.
-  static const bool blk_fuse_on = getenv("CONAN_MEGA_NOBLK") == nullptr;          // developer switch
+  // MEASURED (64 streams, one box, alternating runs): the decoder step alone 0.535 against 0.542 ms and the blocking step's p50
+  // 2.012 against 2.048 ms - but the pipelined step 1.440 against 1.420 ms: every member reads all 8 partial tensors (1 MB per
+  // job and sub-layer through sc1 loads: +100 MB of HBM fetches per step, 253 against 150 MB for the launch), which the vocoder's
+  // kernels feel.  Throughput is the headline, so the fused form is OFF unless CONAN_MEGA_BLK=1 (developer switch, read per
+  // recording; tests/test_gpu_round4.py runs it against the separate launches).
+  const bool blk_fuse_on = getenv("CONAN_MEGA_BLK") != nullptr;
   struct BlkParts { bool on = false; const float* xp = nullptr; const float* bias = nullptr; TRef xres, m1, m2; int has_m2 = 0; } bp;
   int pset = 0;
   auto blk_consume = [&](cnk::RowConvArgs& a, bool store) {

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           if (sb < nbx) {      // (members without a strip skip the gather as well)
             float4 bw[8];
             const float warm = ro::mg_wwarm<1>(a, sb);
-            ro::mg_stage(a, tab, lds, sb, nbx < GS ? nbx : GS);
+            ro::mg_stage<(OCC < 6)>(a, tab, lds, sb, nbx < GS ? nbx : GS);
             ro::mg_keep(warm);
             for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<1, false>(a, tab, bx, lds, bw);
           }
@@ -114,15 +114,15 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           if (sb < nbx) {
             float4 bw[4];
             const float warm = ro::mg_wwarm<4>(a, sb);
-            ro::mg_stage(a, tab, lds, sb, nbx < GS ? nbx : GS);
+            ro::mg_stage<(OCC < 6)>(a, tab, lds, sb, nbx < GS ? nbx : GS);
             ro::mg_keep(warm);
             for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4, false>(a, tab, bx, lds, bw);
           }
         } break;
         case MOP_FFN: {        // LayerNorm -> 1x1 -> activation -> 1x1 partial sums, the hidden columns split over the members
           const auto& a = MG_AS4(RowConvArgs, &op->u);
-          ro::mg_stage(a, tab, lds, sb, GS);
-          ro::mg_ffn(a, tab, sb, GS, lds);
+          ro::mg_stage<(OCC < 6)>(a, tab, lds, sb, GS);
+          ro::mg_ffn<(OCC < 6)>(a, tab, sb, GS, lds);
         } break;
         case MOP_ROWLIN: {
           const auto& a = MG_AS4(RowConvArgs, &op->u);

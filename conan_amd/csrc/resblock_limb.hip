@@ -486,10 +486,10 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
         nxt = nn; nn = -1; pn = -1;
         if (nxt >= 0) pn = stage(nxt);
       }
+      if (ht == 0) meta[2] = nxt >= 0 ? pn : -1;         // the matrix waves read nxt's branch behind B1: c2's K loop ends by fetching nxt's first weight blocks
       hbar();                                            // B3: the previous tile's accumulators are in registers (out_fetch)
       hbar();                                            // B1: xt complete, window free
       if (nxt >= 0) win_write();
-      if (ht == 0) meta[2] = nxt >= 0 ? pn : -1;         // the matrix waves read nxt's branch behind B4
       hbar();                                            // B4
       hbar();                                            // B2: c2 accumulators in LDS, next window staged
       out_fetch(p, i, t0, slot, pos);
@@ -583,6 +583,13 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       }
     }
     RL_BAR(st_b1);                                       // B1: xt complete, window free
+    // The next tile's branch is known by now (the helpers publish it before B3): c2's K loop refills its weight ring, behind its
+    // last taps, with the first blocks of THAT tile's c1 - fetched behind B4 instead, their L2 round trip (2-3 k cycles) stood in
+    // front of every tile's first MFMA (7 % of a C = 128 tile, a quarter of a C = 32 one).
+    pn = __builtin_amdgcn_readfirstlane(meta[2]);
+    const int pnx = pn >= 0 ? pn : p;
+    const long long csn = (long long)(RL_SEL(pnx, k) + 1) * G::KB * G::BLK;
+    const u16* const w1n = RL_SEL(pnx, w1l) + (long long)ct0 * csn + lane * 8;
     // ---------------- c2
     {
       f32x4 acc[G::NRW2][G::NCW];
@@ -592,13 +599,8 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
         for (int c = 0; c < G::NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int rt0 = wr * G::NRW2;
       RL_GEMM(rl_gemm<G::NRW2, G::NCW, LDB, G::KB, G::RING>(xt, G::PLX, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
-                                                           w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride, acc, bw, lane));
+                                                           w1n, csn, acc, bw, lane));
       RL_BAR(st_b4);                                     // B4: every matrix wave is done reading xt
-      pn = __builtin_amdgcn_readfirstlane(meta[2]);
-      if (pn >= 0) {
-        const long long csn = (long long)(RL_SEL(pn, k) + 1) * G::KB * G::BLK;
-        rl_prefetch_w<G::NCW, G::RING>(bw, RL_SEL(pn, w1l) + (long long)ct0 * csn + lane * 8, csn);
-      }
 #pragma unroll
       for (int c = 0; c < G::NCW; ++c) {
         const int col = (ct0 + c) * 16 + 4 * lg;

@@ -644,7 +644,7 @@ __device__ __forceinline__ RowId row_id(const RowTab& tb, const int r) {
 // `first` (the member that owns strip 0) appends the normalised rows to the layer's ring and writes the block mask
 // (sb of nact: this member's index among the members that stage this operator - the normalised rows they all compute are
 // appended to the layer's ring / the block mask is written by member row % nact, so that no single member carries the stores)
-template <class A>
+template <bool WIDE = false, class A>
 __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const int sb, const int nact) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));             // (no hoisting of per-lane arithmetic out of this function: the 80-register bound is tight)
@@ -691,29 +691,49 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
     }
   }
   if (a.xparts > 0) {
-    // the NEW rows of x are the sum of the group members' partial tensors (+ bias, + residual), summed in member order; one
-    // 16-byte column group at a time with all its partial loads in flight
+    // the NEW rows of x are the sum of the group members' partial tensors (+ bias, + residual, x masks), summed in member order.
+    // Every load of a 16-byte column group - its partials, the residual, the masks - is issued before the first is consumed: one
+    // L2 round trip per group.
+    constexpr int EB = 1;      // (two groups per thread in flight cost the 128-register build 15 spilled registers: one)
     const int nq = tb.nvalid * C4;
 #pragma unroll 1
-    for (int e = tid; e < nq; e += 256) {
-      const int r = e / C4, c4 = e - r * C4;
-      const RowId id = row_id(tb, r);
-      const long long off = (long long)(id.i * a.T + id.t) * a.xp_ld + c4 * 4;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int p0 = 0; p0 < a.xparts; p0 += 8) {
-        float4 pv[8];
+    for (int e0 = tid; e0 < nq; e0 += 256 * EB) {
+      float4 pv[EB][8], xr[EB];
+      float mk[EB];
+      RowId id[EB];
+      int rr[EB], cc[EB];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) pv[p] = p0 + p < a.xparts ? ld4<true>(a.xp + (p0 + p) * a.xp_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int b = 0; b < EB; ++b) {
+        const int e = e0 + 256 * b, ev = e < nq ? e : e0;
+        rr[b] = ev / C4; cc[b] = ev - rr[b] * C4;
+        id[b] = row_id(tb, rr[b]);
+        const long long off = (long long)(id[b].i * a.T + id[b].t) * a.xp_ld + cc[b] * 4;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) if (p0 + p < a.xparts) { if (p0 + p == 0) acc = pv[p]; else { acc.x += pv[p].x; acc.y += pv[p].y; acc.z += pv[p].z; acc.w += pv[p].w; } }
+        for (int p = 0; p < 8; ++p) pv[b][p] = p < a.xparts ? ld4<true>(a.xp + p * a.xp_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xr[b] = a.has_xres ? ld4<true>(row(a.xres, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        mk[b] = 1.f;
+        if (a.has_xm1) mk[b] = ld1<true>(row(a.xm1, id[b].i, id[b].slot, id[b].pos, id[b].t));
+        if (a.has_xm2) mk[b] *= ld1<true>(row(a.xm2, id[b].i, id[b].slot, id[b].pos, id[b].t));
       }
-      if (a.xbias) { const float4 q = ldw4(a.xbias + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
-      if (a.has_xres) { const float4 q = ld4<true>(row(a.xres, id.i, id.slot, id.pos, id.t) + c4 * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
-      if (a.has_xm1) { const float mk = ld1<true>(row(a.xm1, id.i, id.slot, id.pos, id.t)); acc.x *= mk; acc.y *= mk; acc.z *= mk; acc.w *= mk; }
-      if (a.has_xm2) { const float mk = ld1<true>(row(a.xm2, id.i, id.slot, id.pos, id.t)); acc.x *= mk; acc.y *= mk; acc.z *= mk; acc.w *= mk; }
-      *reinterpret_cast<float4*>(win + (r + (tb.row_seg[r] + 1) * halo) * LDX + c4 * 4) = acc;
-      // (the tensor itself, for the operator behind this one that adds it as its residual)
-      if (a.xstore && (r % nact) == sb) st4<true>(row(a.x, id.i, id.slot, id.pos, id.t) + c4 * 4, acc);
+#pragma unroll
+      for (int b = 0; b < EB; ++b) {
+        const int e = e0 + 256 * b;
+        float4 acc = pv[b][0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) if (p < a.xparts) { acc.x += pv[b][p].x; acc.y += pv[b][p].y; acc.z += pv[b][p].z; acc.w += pv[b][p].w; }
+        if (a.xparts > 8) {      // (groups of 16 members - developer switch: the second eight, in member order)
+          const long long off = (long long)(id[b].i * a.T + id[b].t) * a.xp_ld + cc[b] * 4;
+          for (int p = 8; p < a.xparts; ++p) { const float4 q = ld4<true>(a.xp + p * a.xp_stride + off); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+        }
+        if (a.xbias) { const float4 q = ldw4(a.xbias + cc[b] * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+        if (a.has_xres) { acc.x += xr[b].x; acc.y += xr[b].y; acc.z += xr[b].z; acc.w += xr[b].w; }
+        if (a.has_xm1 | a.has_xm2) { acc.x *= mk[b]; acc.y *= mk[b]; acc.z *= mk[b]; acc.w *= mk[b]; }
+        if (e < nq) {
+          *reinterpret_cast<float4*>(win + (rr[b] + (tb.row_seg[rr[b]] + 1) * halo) * LDX + cc[b] * 4) = acc;
+          // (the tensor itself, for the operator behind this one that adds it as its residual)
+          if (a.xstore && (rr[b] % nact) == sb) st4<true>(row(a.x, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4, acc);
+        }
+      }
     }
   }
   __syncthreads();
@@ -873,7 +893,7 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
 // second, 1x1 conv: the hidden tensor never leaves the CU and the second conv's K loop is split over the group.
 // The member's partial sums [rows][Cout2] go to part[sb]; bias, residual and the norm behind them are applied where the sum is
 // consumed (RowConvArgs / LNArgs: xp ..).  LDS: window [wr_max][Cin + 8] | hidden [16][HC + 8].
-template <class A>
+template <bool WIDE = false, class A>
 __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int sb, const int GS, float* __restrict__ win) {
   constexpr int RC_D = 8;
   int tid = threadIdx.x;
@@ -928,10 +948,16 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
       }
     }
   }
+  const int KQ2 = a.Cout >> 4, KQm = HC >> 4;         // second conv: K groups per tap in memory / of this member (4, or a multiple of RC_D)
+  const long long ct_stride2 = 2ll * KQ2 * 256;
+  float4 bwn[4];                                        // KQm == 4: the weights of the wave's next column tile (the first one: fetched across the barrier)
+  if (KQm < RC_D) {
+    const float* wn = a.w2 + (long long)wave * ct_stride2 + (long long)(sb * KQm) * 256 + lane * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bwn[u] = ldw4(wn + (long long)u * 256);
+  }
   __syncthreads();
   {   // ---- second conv, this member's K range: hidden channels [sb * HC, (sb + 1) * HC) of every 16-column output tile
-    const int KQ2 = a.Cout >> 4, KQm = HC >> 4;       // K groups per tap in memory / of this member (4, or a multiple of RC_D)
-    const long long ct_stride2 = 2ll * KQ2 * 256;
     const float* const abase = hid + lr * LDH + 4 * lg;
     float* const pbase = a.part + (long long)sb * a.part_stride;
     for (int ct = wave; ct * 16 < a.Cout2_pad; ct += 4) {
@@ -958,10 +984,15 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
             af = afn;
           }
         }
-      } else {      // four K groups per member (a 64-column hidden strip): all of them in flight at once
+      } else {      // four K groups per member (a 64-column hidden strip): the next column tile's weights are in flight while this one is multiplied
         float4 bw[4], af[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { bw[u] = ldw4(wl + (long long)u * 256); af[u] = *reinterpret_cast<const float4*>(abase + u * 16); }
+        for (int u = 0; u < 4; ++u) { bw[u] = bwn[u]; af[u] = *reinterpret_cast<const float4*>(abase + u * 16); }
+        if ((ct + 4) * 16 < a.Cout2_pad) {
+          const float* wn = a.w2 + (long long)(ct + 4) * ct_stride2 + (long long)(sb * KQm) * 256 + lane * 4;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bwn[u] = ldw4(wn + (long long)u * 256);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           f32x4& p = (u & 1) ? acc1 : acc0;

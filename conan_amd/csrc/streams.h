@@ -171,6 +171,7 @@ struct conan_streams {
                                                // event re-recorded while its previous record is still pending stalls the pipeline)
   hipEvent_t ev_fence[NP] = {};                // output fences (conan_streams_output_fence)
   hipStream_t fence_stream = nullptr; bool fence_set = false;
+  hipEvent_t fence_event = nullptr;            // conan_streams_output_fence_event: wait for this recorded event instead of the stream's tail
   int* codes_hand[NP] = {};                    // code hand-off buffers Emformer -> decoder [max_slots][segment]
   // workspace index of a stream: 0 caller / pipelined decoder, 1 pipelined vocoder, 2 pipelined Emformer
   int ws_index(hipStream_t st) const { return (st_voc && st == st_voc) ? 1 : ((st_emf && st == st_emf) ? 2 : 0); }

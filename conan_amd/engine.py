@@ -108,8 +108,9 @@ class AudioGatherRing:
 
     Pipelined steps should not take the wait on the current stream: it holds back the step's Emformer and decoder stages,
     which never touch the buffer, and drains the three-stage pipeline (measured: 1.81 -> 2.6 ms per step).  `acquire(j,
-    fence=True)` returns the side stream instead (None while no gather can be pending, and for every step but the first of
-    a group) for `Streams.step_async(..., out_fence=fence)`: only the stage that writes the audio waits for the gather.
+    fence=True)` returns the event recorded behind the gather that last read the buffer's group instead (None while no gather
+    can be pending, and for every step but the first of a group) for `Streams.step_async(..., out_fence=fence)`: only the
+    stage that writes the audio waits, and only for that gather.
     """
 
     def __init__(self, make_buffer, world, rank, nb=4, always=False, on_gathered=None, every=1):
@@ -140,8 +141,9 @@ class AudioGatherRing:
         k = j % self.nb
         first = j % self.every == 0                       # the step that re-opens a group is the one that may collide with its gather
         pending = self.active and j >= self.nb and first
-        if fence:       # the side stream is in order: everything enqueued on it so far includes the gather that read this group
-            return self.bufs[k], (self.comm if (pending and self.cuda) else None)
+        if fence:       # the event recorded right behind the gather that read this group (NOT the side stream's tail: a later gather's
+                        # join is already enqueued there, and it waits for the newest step)
+            return self.bufs[k], (self.done[k // self.every] if (pending and self.cuda) else None)
         if pending:
             (torch.cuda.current_stream() if self.cuda else _HostStream()).wait_event(self.done[k // self.every])
         return self.bufs[k]

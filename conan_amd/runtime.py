@@ -298,8 +298,8 @@ class Streams:
     def step_async(self, slots, mel_chunk, wav_out, emit=None, codes=None, mel_out=None, out_fence=None):
         """Pipelined chunk step (conan_step_async): returns at once; the front-end of the next call overlaps this
         call's vocoder.  `wav_out` (and the optional outputs) must be caller-owned tensors kept alive until join().
-        out_fence: a torch.cuda.Stream whose work enqueued so far must finish before this step's vocoder writes `wav_out`
-        (conan_streams_output_fence: e.g. the stream of a collective that still reads the buffer)."""
+        out_fence: a torch.cuda.Stream whose work enqueued so far - or a recorded torch.cuda.Event that - must finish before this
+        step's vocoder writes `wav_out` (conan_streams_output_fence / _event: e.g. the collective that still reads the buffer)."""
         a, p = _i32(slots)
         n = len(a)
         emit = self.seg if emit is None else int(emit)
@@ -308,7 +308,10 @@ class Streams:
         assert wav_out.is_cuda and wav_out.is_contiguous() and wav_out.numel() >= n * emit * self.ctx.hop
         self._keep.append((mel_chunk, wav_out, codes, mel_out))
         if out_fence is not None:
-            _lib.check(self.lib.conan_streams_output_fence(self.h, C.c_void_p(out_fence.cuda_stream)))
+            if isinstance(out_fence, torch.cuda.Event):      # an event recorded behind the one operation that read wav_out
+                _lib.check(self.lib.conan_streams_output_fence_event(self.h, C.c_void_p(out_fence.cuda_event)))
+            else:
+                _lib.check(self.lib.conan_streams_output_fence(self.h, C.c_void_p(out_fence.cuda_stream)))
         _lib.check(self.lib.conan_step_async(self.h, p, n, emit, _ptr(mel_chunk), _ptr(codes), _ptr(mel_out), _ptr(wav_out), _stream()))
 
     def join(self):

@@ -246,6 +246,11 @@ int conan_streams_join(conan_streams* s, void* stream);
  * step's Emformer and decoder stages too, which do not touch the buffer, and drain the pipeline (measured: 1.81 -> 2.6 ms
  * per step at 64 streams).  One-shot: cleared by the step that consumes it. */
 int conan_streams_output_fence(conan_streams* s, void* fence_stream);
+/* The same with an event the caller has ALREADY recorded (hipEvent_t as void*) - e.g. right behind the one collective that read the
+ * buffer: the vocoder stage then waits for that collective only, not for whatever else has been enqueued on its stream since (a
+ * later gather's join waits for the newest step's audio: fencing on the stream's tail would make step t's vocoder wait for the
+ * side stream to have seen step t-1's completion - a cross-stream round trip per fence).  One-shot like the stream form. */
+int conan_streams_output_fence_event(conan_streams* s, void* event);
 
 /* Test hook for the bounded device-side waits.  Three kernels wait for other workgroups of their own launch (decoder step:
  * group / grid barriers; Emformer step: cluster exchange; first vocoder stage: partner flags); each such wait carries a 50 ms

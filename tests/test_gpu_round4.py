@@ -129,3 +129,37 @@ def test_arith_option_through_the_c_abi():
         dec.streams(2, 4, 16, arith="limb")
     assert ei.value.code == _lib.ERR_UNSUPPORTED
     d.close(); dec.close()
+
+
+def test_fused_conv_block_operators_equal_the_separate_launches(monkeypatch):
+    """CONAN_MEGA_BLK=1 (developer switch; off by default because it costs the pipelined step 1.4 % - DESIGN.md): the decoder's
+    eight sub-layers [LN -> k5 conv -> GELU] -> [1x1 conv + residual, masks] as ONE megakernel operator each (the 16 x 512 hidden
+    tile stays in LDS, the 1x1 conv's K loop is split over the group, the consumer forms x' from 8 partial tensors) against the same
+    step as ~38 separate launches: 12 steps of 4 frames at 24 streams, mel within fp32 re-association; the fused program twice gives
+    the same bits."""
+    from conan_amd.runtime import Context
+    chp = configs.conan_hparams()
+    ctx = Context(chp, None, 0, emformer=False, conan=True, hifigan=False)
+    ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
+    ctx.finalize()
+    S = 24
+    monkeypatch.setenv("CONAN_MEGA_BLK", "1")
+    a, a2 = ctx.streams(S, 4, 64), ctx.streams(S, 4, 64)
+    monkeypatch.setenv("CONAN_DEC_MEGA", "0")
+    b = ctx.streams(S, 4, 64)
+    monkeypatch.delenv("CONAN_DEC_MEGA")
+    ids = list(range(S))
+    ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
+    codes = torch.from_numpy(synth.codes(48, S)).int().cuda()
+    for st in (a, a2, b):
+        st.reset(ids); st.set_reference(ids, ref)
+    for i in range(0, 48, 4):
+        c = codes[:, i:i + 4].contiguous()
+        ma, ma2, mb = a.decoder_step(ids, c), a2.decoder_step(ids, c), b.decoder_step(ids, c)
+        assert torch.equal(ma, ma2)
+        np.testing.assert_allclose(ma.cpu().numpy(), mb.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    names = kernels_of(a, lambda: a.decoder_step(ids, codes[:, :4].contiguous()))
+    assert any("decoder_mega_kernel" in k for k in names)
+    for st in (a, a2, b):
+        st.close()
+    ctx.close()
