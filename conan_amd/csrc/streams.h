@@ -75,7 +75,7 @@ struct conan_streams {
   int reserve_cus = 0;                     // CUs the pipelined vocoder's persistent launches leave to the front-end stream (CONAN_RESERVE_CUS)
   bool fenced = false;          // CONAN_FENCED=1 at creation: release / acquire fences around the inter-workgroup hand-offs too
   bool rb_limb = false;         // bf16-limb form of the vocoder's matrix kernels where it exists (conan_streams_opts.arith, resolved at creation)
-  bool arith_auto = true;       // the caller left the choice to the library: a fused pass with too few tiles to fill the chip keeps the f32 form (launch_rb)
+  bool arith_auto = true;       // the caller left the choice to the library (conan_streams_opts.arith == AUTO)
   bool rb_merge = true;         // merged-branch last-dilation launches (CONAN_RB_NOMERGE=1 at creation: separate branches + mean_act)
   int* cp_ticket[3] = {nullptr, nullptr, nullptr};   // conv_post's last-workgroup ticket, per internal stream
   int* rb_sched[2] = {nullptr, nullptr};   // work-queue counters of the fused resblock launches, per stream like the split-K workspaces

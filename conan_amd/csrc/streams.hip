@@ -204,13 +204,8 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   bool limb = rb_limb;
   for (int p = 0; p < a.nprob; ++p) { span = std::max(span, (a.p[p].k - 1) * a.p[p].dil); limb = limb && a.p[p].w1l && a.p[p].w2l; }
   limb = limb && a.n <= cnk::kResblockLimbMaxSlots && cnk::resblock_limb_supported(C, kmax, span);
-  // AUTO: the limb pass has one tile height per width (a third to a half of the f32 pass's choices); a launch whose limb tiles
-  // cannot give at least half of the CUs one (a handful of streams) keeps the f32 pass and its shorter tiles.  An explicit
-  // arith = limb request runs the limb pass wherever it exists.
-  if (limb && arith_auto) {
-    const int lr = cnk::resblock_limb_rows(C, span);
-    if ((long long)a.nprob * a.n * ((a.T + lr - 1) / lr) * 2 < cus) limb = false;
-  }
+  // (AUTO takes the limb pass wherever it exists, like an explicit request: measured at 1 / 4 / 8 / 16 / 32 streams the limb pass is
+  // never the slower one - 0.72 against 0.87 ms per pipelined step at 8 streams, equal at one - tools/arith_sweep.sh)
   const int rows = limb ? cnk::resblock_limb_rows(C, span) : cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
   // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
   // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.

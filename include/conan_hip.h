@@ -123,11 +123,12 @@ int conan_streams_destroy(conan_streams* s);
  *   CONAN_ARITH_F32   every product on the f32-input MFMA (v_mfma_f32_*_f32);
  *   CONAN_ARITH_LIMB  every fp32 operand split exactly into three bf16 limbs (x = h + m + l), a product as the six largest of
  *                     the nine limb products on the bf16 MFMA (error of the dropped terms <= 2^-23 |x w|, below the rounding of
- *                     the fp32 accumulation; tests/test_gpu_arith.py holds both forms against float64).  Operands whose
- *                     magnitude is below 2^-110 lose their third limb (a bf16 denormal), see DESIGN.md: such products are
- *                     < 2^-110 |w| and carry >= 16 significant bits.
- *   CONAN_ARITH_AUTO  the library's default: LIMB wherever a limb kernel exists for the launch (ResBlock1 stages, upsamplers of
- *                     stream-sets large enough to fill the chip), F32 elsewhere (small stream-sets, ResBlock2, decoder, Emformer).
+ *                     the fp32 accumulation; tests/test_gpu_arith.py holds both forms against float64: measured 0.8-1.1 x the
+ *                     f32 kernels' rms error).  The split is exact for |x| >= 2^-109 (the third limb may be a bf16 denormal: the
+ *                     bf16 MFMA honours them, measured at 2^-110); smaller operands lose low bits of the third limb, an absolute
+ *                     error below 2^-130.
+ *   CONAN_ARITH_AUTO  the library's default: LIMB wherever the context holds limb weights and a limb kernel exists for the launch
+ *                     (ResBlock1 stages; upsamplers whose tiles fill the chip), F32 elsewhere (ResBlock2, decoder, Emformer).
  * The choice is a property of the stream-set, fixed at creation, reported by conan_streams_arith(). */
 typedef enum conan_arith { CONAN_ARITH_AUTO = 0, CONAN_ARITH_F32 = 1, CONAN_ARITH_LIMB = 2 } conan_arith;
 typedef struct conan_streams_opts {
