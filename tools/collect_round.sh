@@ -4,6 +4,11 @@
 R=${R:-r4}; export ROUND=$R
 O=gpurun_out/profiles_$R; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q -rs 2>&1 | grep -v "amdgpu.ids" | tail -12 > $O/${R}_pytest_gpu.txt
+# the float64 error tables of both arithmetic forms (tests/test_gpu_arith.py prints them)
+timeout 900 python -m pytest tests/test_gpu_arith.py -q -s 2>&1 | grep -v "amdgpu.ids" > $O/${R}_arith_vs_f64.txt
+# per-operator stamps of the decoder megakernel alone, the stages alone against the pipelined step
+timeout 300 python tools/mega_probe.py 64 2>&1 | grep -v "amdgpu.ids" > $O/${R}_decoder_mega_stamps.txt
+timeout 300 python tools/stage_times.py 64 2>&1 | grep -v "amdgpu.ids" | grep -v "^  op\|decoder_mega\]" > $O/${R}_stage_times.txt
 bash tools/collect_profiles.sh b64 auto > $O/collect_b64.log 2>&1       # first: the bench lines below read profiles/${R}_b64_pmc.json
 bash tools/collect_profiles.sh b64 f32 > $O/collect_b64_f32.log 2>&1
 timeout 900 python bench.py 2> $O/bench_default.err | grep '^{' > $O/${R}_b64_bench.json
