@@ -163,3 +163,37 @@ def test_fused_conv_block_operators_equal_the_separate_launches(monkeypatch):
     for st in (a, a2, b):
         st.close()
     ctx.close()
+
+
+def test_grouped_gather_ring_with_event_fences_on_the_gpu():
+    """The multi-rank audio hand-off on ONE rank (always=True: side stream, join, event per group of four steps, and the output
+    fence as the event recorded behind the gather that last read the group - conan_streams_output_fence_event): 19 pipelined steps
+    through engine.AudioGatherRing(every=4) must hand on_gathered every step's audio, in order, bit-identical to the blocking
+    loop - buffers are reused every 8 steps, so a fence that let the vocoder overwrite a buffer under its gather would show."""
+    from conan_amd.engine import AudioGatherRing
+    ctx, chp, vhp = _ctx(emformer=True)
+    S, N, hop = 8, 19, ctx.hop
+    a, b = ctx.streams(S, 4, 64), ctx.streams(S, 4, 64)
+    ids = list(range(S))
+    ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
+    src = torch.from_numpy(synth.mel(4 * N + 8, 9, S)).cuda()
+    for st in (a, b):
+        st.reset(ids); st.set_reference(ids, ref)
+    got = {}
+    ring = AudioGatherRing(lambda: torch.empty(S, 4 * hop, device="cuda"), 1, 0, always=True, every=4,
+                           on_gathered=lambda j, bufs: got.__setitem__(j, bufs[0].clone()))
+    assert ring.nb == 8
+    fences = 0
+    for j in range(N):
+        buf, fence = ring.acquire(j, fence=True)
+        fences += fence is not None
+        assert fence is None or isinstance(fence, torch.cuda.Event)
+        a.step_async(ids, src[:, 4 * j:4 * j + 6].contiguous(), buf, emit=4, out_fence=fence)
+        ring.submit(j, join=a.join)
+    ring.flush(N - 1); ring.drain()
+    a.join(); torch.cuda.synchronize()
+    assert fences == 2 and ring.submitted == 5 and sorted(got) == list(range(N))     # fences at steps 8 and 16; gathers after 3, 7, 11, 15 and the flush
+    for j in range(N):
+        _, _, w = b.step(ids, src[:, 4 * j:4 * j + 6].contiguous())
+        assert torch.equal(w, got[j]), j
+    a.close(); b.close(); ctx.close()
