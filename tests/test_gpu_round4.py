@@ -192,7 +192,7 @@ def test_grouped_gather_ring_with_event_fences_on_the_gpu():
         ring.submit(j, join=a.join)
     ring.flush(N - 1); ring.drain()
     a.join(); torch.cuda.synchronize()
-    assert fences == 2 and ring.submitted == 5 and sorted(got) == list(range(N))     # fences at steps 8 and 16; gathers after 3, 7, 11, 15 and the flush
+    assert fences == 3 and ring.submitted == 5 and sorted(got) == list(range(N))     # fences at steps 8, 12 and 16 (a group re-opens); gathers after 3, 7, 11, 15 and the flush
     for j in range(N):
         _, _, w = b.step(ids, src[:, 4 * j:4 * j + 6].contiguous())
         assert torch.equal(w, got[j]), j
