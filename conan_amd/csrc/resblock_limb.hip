@@ -481,9 +481,12 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       if (deep && nxt >= 0) pn = stage(nxt);
       draw_issue(have, deep ? nxt : cur, deep ? pn : p);   // deep: the tile after nxt
       if (pending) out_store();
-      int nn = draw_take(have);
+      // deep: the drawn index is not needed before the next tile's loop top - it is TAKEN behind B2, a whole tile after the atomic
+      // was issued (taken here, its L2 round trip stood in front of B3 whenever c1 was shorter than it: the 3-tap tiles of the
+      // C = 32 stage spent 7 % of a block's life waiting there)
+      int nn = -1;
       if (!deep) {
-        nxt = nn; nn = -1; pn = -1;
+        nxt = draw_take(have); pn = -1;
         if (nxt >= 0) pn = stage(nxt);
       }
       if (ht == 0) meta[2] = nxt >= 0 ? pn : -1;         // the matrix waves read nxt's branch behind B1: c2's K loop ends by fetching nxt's first weight blocks
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       hbar();                                            // B2: c2 accumulators in LDS, next window staged
       out_fetch(p, i, t0, slot, pos);
       pending = true;
+      if (deep) nn = draw_take(have);
       if (nxt < 0) break;
       cur = nxt;
       decode(cur, p, i, t0);
