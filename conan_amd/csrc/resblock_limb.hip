@@ -524,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
   const int ct0 = wc * G::NCW;
   const int lr = lane & 15, lg = lane >> 4;
 #if RL_STAMPS
-  unsigned long long st_gemm = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_bar = 0, st_b3 = 0, st_b1 = 0, st_b4 = 0, st_b2 = 0;
+  unsigned long long st_gemm = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_bar = 0, st_b3 = 0, st_b1 = 0, st_b4 = 0, st_b2 = 0, st_e1 = 0, st_e2 = 0, st_tiles = 0;
 #define RL_T() __builtin_amdgcn_s_memtime()
 #define RL_BAR(acc_) do { const unsigned long long q0_ = RL_T(); bar(); const unsigned long long q1_ = RL_T(); acc_ += q1_ - q0_; st_bar += q1_ - q0_; } while (0)
 #define RL_GEMM(...) do { const unsigned long long s0_ = RL_T(); __VA_ARGS__; asm volatile("s_nop 0" ::"v"(acc[0][0][0])); st_gemm += RL_T() - s0_; } while (0)
@@ -563,6 +563,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       RL_GEMM(rl_gemm<G::NRW1, G::NCW, LDB, G::KB, G::RING>(win, G::PLW, rt0 * 16, d, k, w1 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
                                                            w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride, acc, bw, lane));
       RL_BAR(st_b3);                                     // B3
+#if RL_STAMPS
+      const unsigned long long e1_0 = RL_T();
+#endif
 #pragma unroll
       for (int c = 0; c < G::NCW; ++c) {
         const int col = (ct0 + c) * 16 + 4 * lg;
@@ -585,6 +588,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
           }
         }
       }
+#if RL_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_e1 += RL_T() - e1_0; ++st_tiles;
+#endif
     }
     RL_BAR(st_b1);                                       // B1: xt complete, window free
     // The next tile's branch is known by now (the helpers publish it before B3): c2's K loop refills its weight ring, behind its
@@ -605,6 +611,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       RL_GEMM(rl_gemm<G::NRW2, G::NCW, LDB, G::KB, G::RING>(xt, G::PLX, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
                                                            w1n, csn, acc, bw, lane));
       RL_BAR(st_b4);                                     // B4: every matrix wave is done reading xt
+#if RL_STAMPS
+      const unsigned long long e2_0 = RL_T();
+#endif
 #pragma unroll
       for (int c = 0; c < G::NCW; ++c) {
         const int col = (ct0 + c) * 16 + 4 * lg;
@@ -613,6 +622,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
           if (rt0 + r < NR2) *reinterpret_cast<f32x4*>(accimg + ((rt0 + r) * 16 + lr) * G::LDA + col) = acc[r][c];
         }
       }
+#if RL_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_e2 += RL_T() - e2_0;
+#endif
     }
     RL_BAR(st_b2);                                       // B2
     p = pn;
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 #if RL_STAMPS
   if (a.dbg && tid == 0) {
     unsigned long long* o = a.dbg + blockIdx.x * 4;
-    if (blockIdx.x == 0) { unsigned long long* q = a.dbg + 256 * 4; q[0] = st_b3; q[1] = st_b1; q[2] = st_b4; q[3] = st_b2; }
+    if (blockIdx.x == 0) { unsigned long long* q = a.dbg + 256 * 4; q[0] = st_b3; q[1] = st_b1; q[2] = st_b4; q[3] = st_b2; q[4] = st_e1; q[5] = st_e2; q[6] = st_tiles; q[7] = st_gemm; q[8] = __builtin_amdgcn_s_memtime() - st_t0; }
     o[0] = st_gemm; o[1] = __builtin_amdgcn_s_memtime() - st_t0; o[2] = __builtin_amdgcn_s_memrealtime() - st_r0; o[3] = st_bar;
   }
 #endif

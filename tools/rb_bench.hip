@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
       float* dmean = nullptr;
       if (merge) { CHECK(hipMalloc(&dmean, (size_t)B * ss * 4)); CHECK(hipMemset(dmean, 0, (size_t)B * ss * 4)); a.merge = 1; a.ymean = a.p[0].y; a.ymean.base = dmean; }
       unsigned long long* ddbg = nullptr;
-      CHECK(hipMalloc(&ddbg, 260 * 4 * 8)); CHECK(hipMemset(ddbg, 0, 260 * 4 * 8));
+      CHECK(hipMalloc(&ddbg, 264 * 4 * 8)); CHECK(hipMemset(ddbg, 0, 264 * 4 * 8));
       a.dbg = ddbg;
       int* dsched; CHECK(hipMalloc(&dsched, 8)); CHECK(hipMemset(dsched, 0, 8)); a.sched = dsched;
       const int rows = limb ? cnk::resblock_limb_rows(C, 10 * d) : getenv("RB_ROWS") && C == 64 ? atoi(getenv("RB_ROWS")) : cnk::resblock_fused_rows(C, T, B, 21, 11, num_cu);
@@ -177,14 +177,15 @@ int main(int argc, char** argv) {
       printf("%s C=%3d T=%5d dil=%d rows/tile=%3d: max|err| %.2e (max|ref| %.2f) stray=%lld  %8.1f us  %6.1f TFLOP/s (%.1f%% of 157.3)\n", limb ? "limb" : "f32 ", C, T, d, rows, worst, scale, stray,
              ms * 1e3, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 157.3 * 100);
       {
-        std::vector<unsigned long long> hd(260 * 4);
+        std::vector<unsigned long long> hd(264 * 4);
         CHECK(hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost));
         if (hd[1]) {
           double g = 0, t = 0, r = 0, bw = 0; int nb = 0; double tmax = 0;
           for (int b = 0; b < 256; ++b) if (hd[b * 4 + 1]) { g += hd[b * 4]; t += hd[b * 4 + 1]; r += hd[b * 4 + 2]; bw += hd[b * 4 + 3]; tmax = std::max(tmax, (double)hd[b * 4 + 2]); ++nb; }
           printf("   stamps (%d blocks): gemm %.0f cyc = %.1f%% of block life, barriers %.1f%%, life %.0f cyc = %.1f us avg / %.1f us max, clock %.2f GHz\n", nb, g / nb, 100 * g / t,
                  100 * bw / t, t / nb, r / nb / 100.0, tmax / 100.0, (t / nb) / (r / nb / 100.0) / 1e3);
-          printf("   block 0 barrier cycles: B3 %llu  B1 %llu  B4 %llu  B2 %llu\n", hd[1024], hd[1025], hd[1026], hd[1027]);
+          printf("   block 0 barrier cycles: B3 %llu  B1 %llu  B4 %llu  B2 %llu;  %llu tiles: c1 epilogue %llu  c2 epilogue %llu  gemm %llu  life %llu  -> other %lld\n", hd[1024], hd[1025], hd[1026], hd[1027],
+                 hd[1030], hd[1028], hd[1029], hd[1031], hd[1032], (long long)hd[1032] - (long long)(hd[1024] + hd[1025] + hd[1026] + hd[1027] + hd[1028] + hd[1029] + hd[1031]));
 
         }
       }
