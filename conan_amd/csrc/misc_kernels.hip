@@ -361,9 +361,15 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
     for (int j = 0; j < a.k; ++j) {
       const float4* xr = reinterpret_cast<const float4*>(cps + (threadIdx.x + j) * ld);
       const float4* wr = reinterpret_cast<const float4*>(sw + j * a.C);
-      for (int c = 0; c < c4n; ++c) {       // (the products in channel order, as a scalar loop over c adds them)
-        const float4 x4 = xr[c], w4 = wr[c];
-        acc += x4.x * w4.x; acc += x4.y * w4.y; acc += x4.z * w4.z; acc += x4.w * w4.w;
+      // (the products in channel order, as a scalar loop over c adds them; eight 16-byte fragment pairs in flight per round - one
+      // pair per iteration made the loop a chain of LDS latencies)
+      for (int c0 = 0; c0 < c4n; c0 += 8) {
+        float4 x4[8], w4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int c = c0 + u < c4n ? c0 + u : c0; x4[u] = xr[c]; w4[u] = wr[c]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c0 + u < c4n) { acc += x4[u].x * w4[u].x; acc += x4[u].y * w4[u].y; acc += x4[u].z * w4[u].z; acc += x4[u].w * w4[u].w; }
       }
     }
     acc += a.bias;
