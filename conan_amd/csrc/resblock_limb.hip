@@ -34,6 +34,12 @@
 
 #define RL_MAX_SLOTS 256      // batch indices whose {slot, pos} the block keeps in LDS (launches with more take the f32 kernel)
 
+#ifndef RL_HELPER_PRIO
+#define RL_HELPER_PRIO 3      // (developer builds: the helper waves' s_setprio level)
+#endif
+#ifndef RL_MATRIX_PRIO
+#define RL_MATRIX_PRIO 0
+#endif
 #ifndef RL_STAMPS
 #define RL_STAMPS 0     // developer builds (tools/rb_bench -DRL_STAMPS=1): cycle stamps of the matrix waves per block
 #endif
@@ -153,9 +159,11 @@ __device__ __forceinline__ void rl_gemm(const u16* __restrict__ src, const int p
 #pragma unroll
           for (int c = 0; c < NCW; ++c)
             acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[SL][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]), acc[r][c], 0, 0, 0);
+#ifndef RL_ABLATE_A      // (developer ablation: no A re-reads, wrong results: what the LDS fragment reads cost the K loops)
           if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + r * 16 * LDB);
           if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + r * 16 * LDB);
           if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + r * 16 * LDB);
+#endif
         }
       const bool own = j + 2 < k;
       const u16* wsrc = own ? wl + (long long)(j + 2) * 1536 : wl_next + (long long)(j + 2 - k) * 1536;
@@ -212,9 +220,11 @@ __device__ __forceinline__ void rl_gemm(const u16* __restrict__ src, const int p
           for (int c = 0; c < NCW; ++c)
             acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[q % RING][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]),
                                                                 acc[r][c], 0, 0, 0);
+#ifndef RL_ABLATE_A      // (developer ablation: no A re-reads, wrong results: what the LDS fragment reads cost the K loops)
           if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + r * 16 * LDB);
           if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + r * 16 * LDB);
           if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + r * 16 * LDB);
+#endif
         }
       if (q + RING < KB) {
 #pragma unroll
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
   if (wave >= 4) {
     // ============================================================ helper waves: window loader + output writer
     const int ht = tid - 256;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(RL_HELPER_PRIO);
     auto hbar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // The next tile's window in two halves: win_issue() - behind B3, while the matrix waves are still in c1's epilogue - puts its
     // global loads in flight (registers); win_write() - behind B1, when the window is dead - applies LeakyReLU, splits into limbs
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
   }
 
   // ============================================================== matrix waves
+  if (RL_MATRIX_PRIO) __builtin_amdgcn_s_setprio(RL_MATRIX_PRIO);
   auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   const int wc = wave % (4 / G::RSPLIT);
   const int wr = wave / (4 / G::RSPLIT);
