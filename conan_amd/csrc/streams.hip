@@ -354,7 +354,9 @@ void conan_streams::build_vocoder() {
     // so an input keeps (k-1)*(dil+1) rows of history and neither xt nor activated twins exist
     // (stream-sets of a few slots cannot fill the chip with whole-width tiles: they keep the two-launch plan for the wide
     // stages; at C = 32 a tile is short enough that the single pass wins even for one stream: 0.99 -> 0.95 ms per chunk)
-    s.fused = c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && (max_slots >= 8 || ch_ <= 32 || getenv("CONAN_RB_FUSED") != nullptr);
+    // (limb stream-sets: from 4 slots - measured per chunk at 4 / 6 streams 0.591 / 0.676 ms fused against 0.603 / 0.714 ms with the
+    // two-launch plan in the wide stages, blocking p50 0.98 / 1.14 against 1.03 / 1.19 ms; at 1-3 streams the two-launch plan is as fast or faster)
+    s.fused = c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && (max_slots >= (rb_limb ? 4 : 8) || ch_ <= 32 || getenv("CONAN_RB_FUSED") != nullptr);
     for (int b = 0; b < c.voc_num_resblocks && s.fused; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d)
         s.fused = s.fused && cnk::resblock_fused_supported(ch_, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
