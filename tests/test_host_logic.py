@@ -267,3 +267,31 @@ def test_three_bf16_limbs_carry_an_fp32_value_and_six_products_its_product():
     assert np.max(np.abs(six - exact) / np.abs(exact)) <= 2.0 ** -22
     # ... against which the fp32 product itself is off by up to 2^-24
     assert np.max(np.abs((x * w).astype(np.float64) - exact) / np.abs(exact)) <= 2.0 ** -24
+
+
+def test_ctypes_mirror_matches_the_c_header(tmp_path):
+    """include/conan_hip.h compiled as plain C (gcc): the size of every struct the ctypes binding mirrors, the enum values of
+    conan_status / conan_arith and the ABI version must be what conan_amd/_lib.py declares - a field added on one side only
+    would otherwise shift every argument behind it silently."""
+    import shutil
+    import subprocess
+    from conan_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not present")
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "conan_hip.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(conan_cfg), sizeof(conan_mel_cfg), sizeof(conan_decoder_taps), sizeof(conan_hifigan_taps),\n'
+                   '         sizeof(conan_streams_opts), sizeof(void*));\n'
+                   '  printf("%d %d %d %d\\n", CONAN_HIP_ABI_VERSION, CONAN_ARITH_AUTO, CONAN_ARITH_F32, CONAN_ARITH_LIMB);\n'
+                   '  printf("%d %d %d %d %d %d %d\\n", CONAN_OK, CONAN_ERR_INVALID, CONAN_ERR_MISSING, CONAN_ERR_SHAPE, CONAN_ERR_HIP, CONAN_ERR_STATE, CONAN_ERR_UNSUPPORTED);\n'
+                   '  printf("%d %d %d %d\\n", CONAN_MAX_UPS, CONAN_MAX_RESBLOCKS, CONAN_MAX_DILATIONS, CONAN_MAX_DEC_BLOCKS);\n  return 0;\n}\n')
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.dirname(_lib.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    sizes = [int(x) for x in out[0].split()]
+    assert sizes == [C.sizeof(_lib.ConanCfg), C.sizeof(_lib.MelCfg), C.sizeof(_lib.DecoderTaps), C.sizeof(_lib.HifiganTaps), C.sizeof(_lib.StreamsOpts), C.sizeof(C.c_void_p)]
+    assert [int(x) for x in out[1].split()] == [_lib.ABI_VERSION, _lib.ARITH_AUTO, _lib.ARITH_F32, _lib.ARITH_LIMB]
+    assert [int(x) for x in out[2].split()] == [_lib.OK, _lib.ERR_INVALID, _lib.ERR_MISSING, _lib.ERR_SHAPE, _lib.ERR_HIP, _lib.ERR_STATE, _lib.ERR_UNSUPPORTED]
+    assert [int(x) for x in out[3].split()] == [_lib.MAX_UPS, _lib.MAX_RESBLOCKS, _lib.MAX_DILATIONS, _lib.MAX_DEC_BLOCKS]
+    # every entry point the header declares has a prototype in the binding, and the other way round
+    assert sorted(_lib._PROTOS) == _lib.declared_symbols()
