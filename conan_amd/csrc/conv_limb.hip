@@ -50,8 +50,19 @@ __device__ __forceinline__ void cl_split(const float x, u16& h, u16& m, u16& l) 
   h = __builtin_bit_cast(u16, hb); m = __builtin_bit_cast(u16, mb); l = __builtin_bit_cast(u16, lb);
 }
 
-constexpr int CL_LDB = 48;          // bf16 elements per window row: 32 channels + 16 (a stride of 2 mod 4 16-byte slots: conflict-free ds_read_b128)
+constexpr int CL_LDB = 48;          // bf16 elements per window row and limb plane: 32 channels + 16
+constexpr int CL_RS = 3 * CL_LDB;   // a window row holds its three limb planes side by side: 288 bytes, a stride of 2 mod 4 16-byte slots (conflict-free
+                                    // ds_read_b128), and a row's three A fragments are ONE address register + immediate offsets (planes of wr_max rows each
+                                    // needed a v_add per read, into the register the MFMA in front of it was still reading: a write-after-read stall per read)
 constexpr int CL_NIT = 12;          // float4 per helper thread and slice: windows of up to 384 rows
+#ifndef CL_RING1
+#define CL_RING1 4                  // weight blocks in flight per wave with one column tile per wave
+#endif
+
+template <int I, int N, class F>
+__device__ __forceinline__ void cl_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); cl_static_for<I + 1, N>(f); }
+}
 
 }  // namespace
 
@@ -66,10 +77,11 @@ template <int NRW, int NCW, int RW, int CW>
 __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g) {
   static_assert(RW * CW == 4, "four matrix waves");
   constexpr int TM = 16 * NRW * RW, TN = 16 * NCW * CW;
-  extern __shared__ __attribute__((aligned(16))) u16 lds[];      // [2 buffers][3 planes][wr_max][CL_LDB]
+  extern __shared__ __attribute__((aligned(16))) u16 lds[];      // [2 buffers][wr_max][3 planes][CL_LDB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int plane = g.wr_max * CL_LDB;                           // elements per plane
+  const int plane = g.wr_max * CL_LDB;                           // elements per buffer / 3
+  constexpr int PO = CL_LDB;                                     // plane offset inside a row
   auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto tile_word = [&](int idx, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(g.tiles + (long long)idx * 4 + w)); };
   // this block's tiles: assign[b * per + i] until -1 (host-balanced)
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
           const int i = i0 + s, slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
           const int row = ((ring ? pv * xrate : 0) + xoff + ta + o) & xmask;
           roff[u] = (int)((long long)(ring ? slot : i) * xss) + row * xC + c4 * 4;
-          loff[u] = w * CL_LDB + c4 * 4;
+          loff[u] = w * CL_RS + c4 * 4;
         }
       }
       const int nblk = Cin / 32;
@@ -136,8 +148,8 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
             }
             u16* d = dstb + loff[u];
             *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
-            *reinterpret_cast<uint2*>(d + plane) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
-            *reinterpret_cast<uint2*>(d + 2 * plane) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
+            *reinterpret_cast<uint2*>(d + PO) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
+            *reinterpret_cast<uint2*>(d + 2 * PO) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
           }
         }
         if (cb + 1 < nblk) {
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 #pragma unroll
     for (int r = 0; r < NRW; ++r) {
       const int row = (wr_ * NRW + r) * 16 + lr, s = row / Tt, tl = row - s * Tt;
-      abase[r] = (s * wrs + tl) * CL_LDB + 8 * lg;
+      abase[r] = (s * wrs + tl) * CL_RS + 8 * lg;
     }
     f32x4 acc[NRW][NCW];
 #pragma unroll
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     }
     // weight blocks in flight: four with one column tile per wave (a block is 6 * NRW MFMAs = 0.2 us of work there - two blocks
     // ahead is less than an L2 round trip under load), two with two
-    constexpr int RING = NCW == 1 ? 4 : 2;
+    constexpr int RING = NCW == 1 ? CL_RING1 : 2;
     f32x4 bw[RING][NCW][3];
 #pragma unroll
     for (int s = 0; s < RING; ++s)
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     f32x4 af[NRW][3];
     int j = 0;                                                   // tap of block gb
     const u16* buf = lds;
-    const int dstep = dil * CL_LDB;
+    const int dstep = dil * CL_RS;
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
     auto step = [&](const int gb, auto slot_c) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_c)::value;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 #pragma unroll
         for (int r = 0; r < NRW; ++r)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) af[r][p] = *reinterpret_cast<const f32x4*>(buf + p * plane + abase[r]);
+          for (int p = 0; p < 3; ++p) af[r][p] = *reinterpret_cast<const f32x4*>(buf + abase[r] + p * PO);
       }
       const bool more = j + 1 < k;                               // the next tap reads the same slice, dil rows further
       const u16* anext = buf + (more ? (j + 1) * dstep : 0);
@@ -234,8 +246,8 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
           for (int c = 0; c < NCW; ++c)
             acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[SL][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]), acc[r][c], 0, 0, 0);
 #ifndef CL_ABL_A      // (developer ablation: no A re-reads)
-          if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + 2 * plane + abase[r]);
-          if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + plane + abase[r]);
+          if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + abase[r] + 2 * PO);
+          if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + abase[r] + PO);
           if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + abase[r]);
 #endif
         }
@@ -270,19 +282,8 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     ++st_tiles;
 #endif
     int gb = 0;
-    for (; gb + RING <= NB; gb += RING) {
-      step(gb, std::integral_constant<int, 0>{});
-      step(gb + 1, std::integral_constant<int, 1>{});
-      if constexpr (RING == 4) {
-        step(gb + 2, std::integral_constant<int, 2>{});
-        step(gb + 3, std::integral_constant<int, 3>{});
-      }
-    }
-    if (gb < NB) step(gb, std::integral_constant<int, 0>{});
-    if constexpr (RING == 4) {
-      if (gb + 1 < NB) step(gb + 1, std::integral_constant<int, 1>{});
-      if (gb + 2 < NB) step(gb + 2, std::integral_constant<int, 2>{});
-    }
+    for (; gb + RING <= NB; gb += RING) cl_static_for<0, RING>([&](auto sl) __attribute__((always_inline)) { step(gb + decltype(sl)::value, sl); });
+    cl_static_for<0, RING - 1>([&](auto sl) __attribute__((always_inline)) { if (gb + decltype(sl)::value < NB) step(gb + decltype(sl)::value, sl); });
 #ifdef CL_STAMPS
     asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
     st_loop += __builtin_amdgcn_s_memtime() - st_l0;
