@@ -281,7 +281,37 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     const unsigned long long st_bar0 = st_bar;
     ++st_tiles;
 #endif
+    // The epilogue's operands - bias and, for c2, the residual rows - are requested here, a whole K loop before their use (loaded in
+    // the epilogue, their round trip - 1-2 k cycles - stood at the end of every tile: 43.2 / 45.1 -> 40.5 / 42.2 us per launch of the
+    // C = 256 c2 convs; issued behind the first blocks of the loop instead - vmcnt is in-order: the loop's counted waits for weight
+    // blocks then also wait for these - 42.4 / 43.7).  Only in the builds whose register budget
+    // has room for them (16 + 4 registers with four row tiles and one column tile per wave).
+    constexpr bool PRE = NRW * NCW <= 4;
+    f32x4 pre_b[PRE ? NCW : 1], pre_r[PRE ? NRW : 1][PRE ? NCW : 1];
+    auto pre_issue = [&]() __attribute__((always_inline)) {
+     if constexpr (PRE) {
+      const float* bias = CL_SEL(q, bias);
+      const int Cout = CL_SEL(q, Cout);
+      const bool hres = CL_SEL(q, has_res) != 0;
+      const bool rring = CL_SEL(q, res.mode) == 0;
+      const float* rb = CL_SEL(q, res.base);
+      const int rC = CL_SEL(q, res.C), rmask = rring ? CL_SEL(q, res.lmask) : -1, rrate = CL_SEL(q, res.rate), roffs = CL_SEL(q, res.off);
+      const long long rss = CL_SEL(q, res.slot_stride);
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) {
+        const int cc = (ct0 + c) * 16 + 4 * lg;
+        pre_b[c] = (bias && cc < Cout) ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+          const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
+          const int rrow = ((rring ? epos[r] * rrate : 0) + roffs + t) & rmask;
+          pre_r[r][c] = (hres && cc < Cout) ? cl_gload(rb + (long long)(rring ? eslot[r] : i) * rss + (long long)rrow * rC + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    };
     int gb = 0;
+    pre_issue();
     for (; gb + RING <= NB; gb += RING) cl_static_for<0, RING>([&](auto sl) __attribute__((always_inline)) { step(gb + decltype(sl)::value, sl); });
     cl_static_for<0, RING - 1>([&](auto sl) __attribute__((always_inline)) { if (gb + decltype(sl)::value < NB) step(gb + decltype(sl)::value, sl); });
 #ifdef CL_STAMPS
@@ -315,13 +345,16 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         for (int c = 0; c < NCW; ++c) {
           const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
           if (cc < Cout) {
-            const f32x4 bq = bias ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 bq;
+            if constexpr (PRE) bq = pre_b[c];
+            else bq = bias ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 o = acc[r][c] + bq;
             if (oact == ACT_LRELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * oslope;
             }
-            if (hres) {
+            if constexpr (PRE) { if (hres) o += pre_r[r][c]; }
+            else if (hres) {
               const int rrow = ((rring ? pv * rrate : 0) + roffs + t) & rmask;
               o += cl_gload(rb + (long long)(rring ? slot : i) * rss + (long long)rrow * rC + cc);
             }

@@ -1,7 +1,7 @@
 // Developer tool: timing (and a sampled check against a scalar restatement) of cnk::conv_limb_kernel on the C = 256 ResBlock
 // convs of the vocoder's first stage: three problems (3 / 7 / 11 taps) per launch, 64 streams x 32 rows, ring inputs.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I conan_amd/csrc tools/cl_bench.hip conan_amd/csrc/conv_limb.hip -o tools/bin/cl_bench
-//   tools/bin/cl_bench [streams=64] [dil=5] [iters=20] [shape=0]
+//   tools/bin/cl_bench [streams=64] [dil=5] [iters=20] [shape=-1: chosen] [residual=0: c1 form (LeakyReLU out) | 1: c2 form (+ x, raw out)]
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -38,6 +38,7 @@ static std::vector<unsigned short> pack_limb(const std::vector<float>& W, int Co
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, dil = argc > 2 ? atoi(argv[2]) : 5, iters = argc > 3 ? atoi(argv[3]) : 20;
+  const bool resid = argc > 5 && atoi(argv[5]) != 0;
   const int C = 256, T = 32, rate = 8, ks[3] = {3, 7, 11};
   const float slope = 0.1f;
   std::mt19937 rng(5);
@@ -72,10 +73,11 @@ int main(int argc, char** argv) {
     a.x = r; r.base = dy + (size_t)b * B * ss; a.y = r;
     a.wl = dwl; a.bias = db; a.slots = dslots; a.pos = dpos;
     a.Cin = C; a.Cin_pad = C; a.Cin_alloc = C; a.Cout = C; a.Cout_pad = C; a.ktaps = k; a.dil = dil; a.pad_left = (k - 1) * dil;
-    a.T = T; a.n = B; a.in_act = cnk::ACT_LRELU; a.in_slope = slope; a.out_act = cnk::ACT_LRELU; a.out_slope = slope; a.out_scale = 1.f; a.shuffle_r = 1;
+    a.T = T; a.n = B; a.in_act = cnk::ACT_LRELU; a.in_slope = slope; a.out_act = resid ? cnk::ACT_NONE : cnk::ACT_LRELU; a.out_slope = slope; a.out_scale = 1.f; a.shuffle_r = 1;
+    if (resid) { a.res = a.x; a.has_res = 1; }
   }
   g.nprob = 3;
-  const int shape = argc > 4 ? atoi(argv[4]) : cnk::conv_limb_shape(g.p, 3, num_cu);
+  const int shape = (argc > 4 && atoi(argv[4]) >= 0) ? atoi(argv[4]) : cnk::conv_limb_shape(g.p, 3, num_cu);
   printf("shape %d (%s), %d streams, dil %d\n", shape, cnk::conv_limb_name(shape), B, dil);
   if (!cnk::launch_conv_limb(g, shape, num_cu, 0)) { printf("launch failed\n"); return 1; }
   CHECK(hipDeviceSynchronize());
@@ -90,7 +92,8 @@ int main(int argc, char** argv) {
       const float* xx = xr + (size_t)(((long long)pos * rate + t + j * dil - (k - 1) * dil) & (L - 1)) * C;
       for (int ci = 0; ci < C; ++ci) { const float v = xx[ci] > 0.f ? xx[ci] : xx[ci] * slope; s += (double)W[b][((size_t)co * C + ci) * k + j] * v; }
     }
-    float want = (float)s + bias[b][co]; want = want > 0.f ? want : want * slope;
+    float want = (float)s + bias[b][co];
+    if (resid) want += xr[(size_t)(((long long)pos * rate + t) & (L - 1)) * C + co]; else want = want > 0.f ? want : want * slope;
     const float got = hy[(size_t)b * B * ss + (size_t)slot * ss + (size_t)(((long long)pos * rate + t) & (L - 1)) * C + co];
     worst = std::max(worst, (double)std::fabs(want - got)); scale = std::max(scale, (double)std::fabs(want));
   }
