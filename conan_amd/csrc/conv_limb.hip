@@ -286,10 +286,18 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     // C = 256 c2 convs; issued behind the first blocks of the loop instead - vmcnt is in-order: the loop's counted waits for weight
     // blocks then also wait for these - 42.4 / 43.7).  Only in the builds whose register budget
     // has room for them (16 + 4 registers with four row tiles and one column tile per wave).
-    constexpr bool PRE = NRW * NCW <= 4;
-    f32x4 pre_b[PRE ? NCW : 1], pre_r[PRE ? NRW : 1][PRE ? NCW : 1];
+    constexpr bool PRE = NRW * NCW <= 4;      // the residual rows too; the bias in every build
+    f32x4 pre_b[NCW], pre_r[PRE ? NRW : 1][PRE ? NCW : 1];
     auto pre_issue = [&]() __attribute__((always_inline)) {
-     if constexpr (PRE) {
+     if constexpr (!PRE) {
+      const float* bias = CL_SEL(q, bias);
+      const int Cout = CL_SEL(q, Cout);
+#pragma unroll
+      for (int c = 0; c < NCW; ++c) {
+        const int cc = (ct0 + c) * 16 + 4 * lg;
+        pre_b[c] = (bias && cc < Cout) ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+     } else {
       const float* bias = CL_SEL(q, bias);
       const int Cout = CL_SEL(q, Cout);
       const bool hres = CL_SEL(q, has_res) != 0;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 #endif
     // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
     {
-      const float* bias = CL_SEL(q, bias);
+
       const int oact = CL_SEL(q, out_act);
       const float oslope = CL_SEL(q, out_slope);
       const int shuf = CL_SEL(q, shuffle_r), Cout = CL_SEL(q, Cout), Cq = Cout / shuf;
@@ -345,10 +353,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         for (int c = 0; c < NCW; ++c) {
           const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
           if (cc < Cout) {
-            f32x4 bq;
-            if constexpr (PRE) bq = pre_b[c];
-            else bq = bias ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            f32x4 o = acc[r][c] + bq;
+            f32x4 o = acc[r][c] + pre_b[c];
             if (oact == ACT_LRELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * oslope;
