@@ -41,13 +41,17 @@ typedef const int __attribute__((address_space(1)))* gci;
 __device__ __forceinline__ f32x4 cl_gload(const void* p) { return *(gcf4)(p); }
 __device__ __forceinline__ void cl_gstore(float* p, const f32x4 v) { *(gf4)(p) = v; }
 
-__device__ __forceinline__ void cl_split(const float x, u16& h, u16& m, u16& l) {
-  const __bf16 hb = (__bf16)x;
-  const float r1 = x - (float)hb;
-  const __bf16 mb = (__bf16)r1;
-  const float r2 = r1 - (float)mb;
-  const __bf16 lb = (__bf16)r2;
-  h = __builtin_bit_cast(u16, hb); m = __builtin_bit_cast(u16, mb); l = __builtin_bit_cast(u16, lb);
+// two values at a time on the packed VALU forms (resblock_limb.hip, rl_split2): the same roundings in half the instructions
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cl_split2(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  const f32x2 r1 = x - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  const f32x2 r2 = r1 - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
 constexpr int CL_LDB = 48;          // bf16 elements per window row and limb plane: 32 channels + 16
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const int* pos = CL_SEL(q, pos);
       const bool act = CL_SEL(q, in_act) == ACT_LRELU;
       const float slope = CL_SEL(q, in_slope);
+      const float act_slope = act ? slope : 1.f;
       // per thread: the rows it stages (window row w = idx / 8, 4-channel group idx % 8), as float offsets from xb
       int roff[CL_NIT], loff[CL_NIT];
       const int total = wr * 8;
@@ -139,17 +144,19 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
 #pragma unroll
         for (int u = 0; u < CL_NIT; ++u) {
           if (roff[u] >= 0) {
-            u16 h[4], m[4], l[4];
+            unsigned h[2], m[2], l[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float s = v[u][e];
-              if (act) s = s > 0.f ? s : s * slope;
-              cl_split(s, h[e], m[e], l[e]);
+            for (int e = 0; e < 2; ++e) {
+              f32x2 s = {v[u][2 * e], v[u][2 * e + 1]};
+              // (LeakyReLU with 0 < slope < 1 as max(x, slope * x): the same bits as x > 0 ? x : x * slope; act_slope is 1 without it)
+              const f32x2 sx = s * act_slope;
+              s = (f32x2){__builtin_fmaxf(s[0], sx[0]), __builtin_fmaxf(s[1], sx[1])};
+              cl_split2(s, h[e], m[e], l[e]);
             }
             u16* d = dstb + loff[u];
-            *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
-            *reinterpret_cast<uint2*>(d + PO) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
-            *reinterpret_cast<uint2*>(d + 2 * PO) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
+            *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2*>(d + PO) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(d + 2 * PO) = make_uint2(l[0], l[1]);
           }
         }
         if (cb + 1 < nblk) {
@@ -445,6 +452,7 @@ bool shape_fits(const CLShape& s, const ConvArgs& a) {
 bool conv_limb_supported(const ConvArgs& a) {
   if (!a.wl || a.x.mode != 0 || a.Cin % 32 || a.Cout % 4 || a.has_m1 || a.has_m2 || a.bvec || a.lens || a.out_scale != 1.f) return false;
   if (a.in_act != ACT_NONE && a.in_act != ACT_LRELU) return false;
+  if (a.in_act == ACT_LRELU && !(a.in_slope > 0.f && a.in_slope <= 1.f)) return false;      // (the helpers form it as max(x, slope * x))
   if (a.out_act != ACT_NONE && a.out_act != ACT_LRELU) return false;
   if (a.shuffle_r > 1 && ((a.Cout / a.shuffle_r) % 4 || a.Cout % a.shuffle_r)) return false;
   if (a.x.C % 4 || a.y.C % 4 || (a.has_res && a.res.C % 4)) return false;

@@ -69,14 +69,26 @@ __device__ __forceinline__ f32x4 rl_gload(const void* p) { return *(gcf4)(p); }
 __device__ __forceinline__ float4 rl_gload4(const float* p) { const f32x4 v = *(gcf4)(p); return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void rl_gstore4(float* p, const float4 v) { *(gf4)(p) = (f32x4){v.x, v.y, v.z, v.w}; }
 
-// x = h + m + l (round-to-nearest-even at every step; the two subtractions are exact)
-__device__ __forceinline__ void rl_split(const float x, u16& h, u16& m, u16& l) {
-  const __bf16 hb = (__bf16)x;
-  const float r1 = x - (float)hb;
-  const __bf16 mb = (__bf16)r1;
-  const float r2 = r1 - (float)mb;
-  const __bf16 lb = (__bf16)r2;
-  h = __builtin_bit_cast(u16, hb); m = __builtin_bit_cast(u16, mb); l = __builtin_bit_cast(u16, lb);
+// x = h + m + l: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even at every step; the two subtractions are
+// exact.  Two values at a time on the packed VALU forms (v_cvt_pk_bf16_f32, v_pk_add_f32): 6-7 instead of 11 instructions per
+// element with the LeakyReLU in front - the matrix waves run c1's epilogue themselves, between two K loops
+// (7-9 % of a block's life at C = 64 / 32), and the helpers' splits issue into the vector port the MFMAs use.
+// h / m / l: two bf16 each, element 0 in the low half - the plane words as they are stored.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rl_split2(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+  const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  const f32x2 r1 = x - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  const f32x2 r2 = r1 - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+// leaky_relu for 0 < slope < 1: max(x, slope * x) - the same bits as (x > 0 ? x : x * slope), signed zeros included
+__device__ __forceinline__ f32x2 rl_lrelu2(const f32x2 x, const float slope) {
+  const f32x2 sx = x * slope;
+  return (f32x2){__builtin_fmaxf(x[0], sx[0]), __builtin_fmaxf(x[1], sx[1])};
 }
 
 template <int C_, int NR2_, int SPAN_>
@@ -315,18 +327,14 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       for (int u = 0; u < NIT; ++u) {
         const int idx = ht + 256 * u;
         const int w = idx / G::C4, c4 = idx - w * G::C4;
-        float q[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
-        u16 h[4], m[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float s = q[e] > 0.f ? q[e] : q[e] * slope;
-          rl_split(s, h[e], m[e], l[e]);
-        }
+        unsigned h[2], m[2], l[2];
+        rl_split2(rl_lrelu2((f32x2){wv[u].x, wv[u].y}, slope), h[0], m[0], l[0]);
+        rl_split2(rl_lrelu2((f32x2){wv[u].z, wv[u].w}, slope), h[1], m[1], l[1]);
         if (idx < wtotal) {
           u16* dst = win + w * LDB + c4 * 4;
-          *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
-          *reinterpret_cast<uint2*>(dst + G::PLW) = make_uint2((unsigned)m[0] | (unsigned)m[1] << 16, (unsigned)m[2] | (unsigned)m[3] << 16);
-          *reinterpret_cast<uint2*>(dst + 2 * G::PLW) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h[0], h[1]);
+          *reinterpret_cast<uint2*>(dst + G::PLW) = make_uint2(m[0], m[1]);
+          *reinterpret_cast<uint2*>(dst + 2 * G::PLW) = make_uint2(l[0], l[1]);
         }
       }
       if (ht == 0) meta[0] = wzr;
@@ -577,28 +585,31 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 #if RL_STAMPS
       const unsigned long long e1_0 = RL_T();
 #endif
+      // (rows before the start of the stream - c2's zero padding - exist in a slot's first steps only: the selects that blank them
+      // are compiled for those tiles alone)
+      auto epilogue1 = [&](auto zr_c) __attribute__((always_inline)) {
+        constexpr bool ZR = decltype(zr_c)::value;
 #pragma unroll
-      for (int c = 0; c < G::NCW; ++c) {
-        const int col = (ct0 + c) * 16 + 4 * lg;
+        for (int c = 0; c < G::NCW; ++c) {
+          const int col = (ct0 + c) * 16 + 4 * lg;
 #pragma unroll
-        for (int r = 0; r < G::NRW1; ++r) {
-          if (rt0 + r < G::NR1) {
-            const int m = (rt0 + r) * 16 + lr;
-            u16 h[4], mm[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float v = acc[r][c][e] + b1v[c][e];
-              v = v > 0.f ? v : v * slope;
-              v = m < zrows ? 0.f : v;
-              rl_split(v, h[e], mm[e], l[e]);
+          for (int r = 0; r < G::NRW1; ++r) {
+            if (rt0 + r < G::NR1) {
+              const int m = (rt0 + r) * 16 + lr;
+              unsigned h[2], mm[2], l[2];
+              const f32x4 v = acc[r][c] + b1v[c];
+              rl_split2(rl_lrelu2((f32x2){v[0], v[1]}, slope), h[0], mm[0], l[0]);
+              rl_split2(rl_lrelu2((f32x2){v[2], v[3]}, slope), h[1], mm[1], l[1]);
+              const bool zr = ZR && m < zrows;
+              u16* dst = xt + m * LDB + col;
+              *reinterpret_cast<uint2*>(dst) = zr ? make_uint2(0u, 0u) : make_uint2(h[0], h[1]);
+              *reinterpret_cast<uint2*>(dst + G::PLX) = zr ? make_uint2(0u, 0u) : make_uint2(mm[0], mm[1]);
+              *reinterpret_cast<uint2*>(dst + 2 * G::PLX) = zr ? make_uint2(0u, 0u) : make_uint2(l[0], l[1]);
             }
-            u16* dst = xt + m * LDB + col;
-            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | (unsigned)h[1] << 16, (unsigned)h[2] | (unsigned)h[3] << 16);
-            *reinterpret_cast<uint2*>(dst + G::PLX) = make_uint2((unsigned)mm[0] | (unsigned)mm[1] << 16, (unsigned)mm[2] | (unsigned)mm[3] << 16);
-            *reinterpret_cast<uint2*>(dst + 2 * G::PLX) = make_uint2((unsigned)l[0] | (unsigned)l[1] << 16, (unsigned)l[2] | (unsigned)l[3] << 16);
           }
         }
-      }
+      };
+      if (zrows > 0) epilogue1(std::true_type{}); else epilogue1(std::false_type{});
 #if RL_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_e1 += RL_T() - e1_0; ++st_tiles;
 #endif
@@ -680,6 +691,7 @@ static bool launch_rl(const RBArgs& ain, int num_cu, hipStream_t st) {
   if (!a.sched) return false;
   for (int p = 0; p < a.nprob; ++p) if (!a.p[p].w1l || !a.p[p].w2l) return false;
   if (a.n > RL_MAX_SLOTS) return false;
+  if (!(a.slope > 0.f && a.slope <= 1.f)) return false;      // (LeakyReLU is formed as max(x, slope * x))
   for (int p = 0; p < 3; ++p) a.order[p] = p;
   std::stable_sort(a.order, a.order + a.nprob, [&](int x, int y) { return a.p[x].k > a.p[y].k; });
   const int grid = std::min(a.merge ? total / a.nprob : total, num_cu);
