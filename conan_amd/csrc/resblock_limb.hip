@@ -405,6 +405,13 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     // block that is dispatched late - its CU held by another stream's kernel for 100-200 us: the Emformer's workgroups need whole
     // CUs - then finds the queue empty and leaves, instead of starting a statically assigned first tile when everyone else is done
     // (pipelined steps: the launches' maxima were 60-80 us above their means).
+#if RL_STAMPS
+    const unsigned long long h_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long h_t[6] = {0, 0, 0, 0, 0, 0};
+#define RL_HT(i_) h_t[i_] = __builtin_amdgcn_s_memtime() - h_t0
+#else
+#define RL_HT(i_)
+#endif
     int dv0 = 0;
     if (wave == 4 && lane == 0) dv0 = __hip_atomic_fetch_add(a.sched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // {slot, pos} of every batch index, once: a drawn tile is then decoded without a global load behind the draw itself
@@ -437,7 +444,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       if (cur >= 0) decode(cur, p, i, t0);
       if (lane == 0) { meta[1] = cur; meta[2] = p; meta[3] = 0; }
     }
+    RL_HT(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // B(-1), block-wide: the table and the first tile are published
+    RL_HT(1);
     if (wave != 4) {
       cur = __builtin_amdgcn_readfirstlane(meta[1]);
       if (cur >= 0) decode(cur, p, i, t0);
@@ -445,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     if (cur >= 0) {
     int slot = __builtin_amdgcn_readfirstlane(sptab[2 * i]), pos = __builtin_amdgcn_readfirstlane(sptab[2 * i + 1]);
     win_issue(p, i, t0, slot, pos);
+    RL_HT(2);
     int gen = 1;                                         // generation of the published draw (meta[3])
     // draw(known_idx, known_p): issue; publish(): wave 4 lane 0 hands the index to the other helper waves through LDS
     int dv = 0, dnext = -1;                              // wave 4 lane 0: the counter value, in flight (NOT touched before draw_take: a
@@ -489,8 +499,14 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
       draw_issue(1, cur, p);
       nxt = draw_take(1);
     }
+    RL_HT(3);
     win_write();
+    RL_HT(4);
     hbar();                                              // B0: first window staged
+    RL_HT(5);
+#if RL_STAMPS
+    if (a.dbg && blockIdx.x == 0 && wave == 4 && lane == 0) { unsigned long long* q = a.dbg + 256 * 4 + 12; for (int e = 0; e < 6; ++e) q[e] = h_t[e]; }
+#endif
     bool pending = false;                                // a fetched output tile waits for its stores
     for (;;) {
       // cur's c1 is running and the helpers have nothing else to do: everything up to the next window's loads happens here, so
@@ -543,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
   const int ct0 = wc * G::NCW;
   const int lr = lane & 15, lg = lane >> 4;
 #if RL_STAMPS
-  unsigned long long st_gemm = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_bar = 0, st_b3 = 0, st_b1 = 0, st_b4 = 0, st_b2 = 0, st_e1 = 0, st_e2 = 0, st_tiles = 0;
+  unsigned long long st_gemm = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_bar = 0, st_b3 = 0, st_b1 = 0, st_b4 = 0, st_b2 = 0, st_e1 = 0, st_e2 = 0, st_tiles = 0, st_head = 0, st_pre = 0, st_mid = 0;
 #define RL_T() __builtin_amdgcn_s_memtime()
 #define RL_BAR(acc_) do { const unsigned long long q0_ = RL_T(); bar(); const unsigned long long q1_ = RL_T(); acc_ += q1_ - q0_; st_bar += q1_ - q0_; } while (0)
 #define RL_GEMM(...) do { const unsigned long long s0_ = RL_T(); __VA_ARGS__; asm volatile("s_nop 0" ::"v"(acc[0][0][0])); st_gemm += RL_T() - s0_; } while (0)
@@ -560,7 +576,13 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     rl_prefetch_w<G::NCW, G::RING>(bw, RL_SEL(p, w1l) + (long long)ct0 * cs + lane * 8, cs);
   }
   bar();                                                 // B0
+#if RL_STAMPS
+  st_head = RL_T() - st_t0;
+#endif
   while (p >= 0) {
+#if RL_STAMPS
+    const unsigned long long top_ = RL_T();
+#endif
     const int k = RL_SEL(p, k), d = RL_SEL(p, dil);
     const u16* const w1 = RL_SEL(p, w1l);
     const u16* const w2 = RL_SEL(p, w2l);
@@ -579,6 +601,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 #pragma unroll
         for (int c = 0; c < G::NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int rt0 = wr * G::NRW1;
+#if RL_STAMPS
+      st_pre += RL_T() - top_;
+#endif
       RL_GEMM(rl_gemm<G::NRW1, G::NCW, LDB, G::KB, G::RING>(win, G::PLW, rt0 * 16, d, k, w1 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
                                                            w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride, acc, bw, lane));
       RL_BAR(st_b3);                                     // B3
@@ -618,6 +643,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
     // The next tile's branch is known by now (the helpers publish it before B3): c2's K loop refills its weight ring, behind its
     // last taps, with the first blocks of THAT tile's c1 - fetched behind B4 instead, their L2 round trip (2-3 k cycles) stood in
     // front of every tile's first MFMA (7 % of a C = 128 tile, a quarter of a C = 32 one).
+#if RL_STAMPS
+    const unsigned long long mid_ = RL_T();
+#endif
     pn = __builtin_amdgcn_readfirstlane(meta[2]);
     const int pnx = pn >= 0 ? pn : p;
     const long long csn = (long long)(RL_SEL(pnx, k) + 1) * G::KB * G::BLK;
@@ -630,6 +658,9 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 #pragma unroll
         for (int c = 0; c < G::NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int rt0 = wr * G::NRW2;
+#if RL_STAMPS
+      st_mid += RL_T() - mid_;
+#endif
       RL_GEMM(rl_gemm<G::NRW2, G::NCW, LDB, G::KB, G::RING>(xt, G::PLX, rt0 * 16, 1, k, w2 + (long long)ct0 * ct_stride + lane * 8, ct_stride,
                                                            w1n, csn, acc, bw, lane));
       RL_BAR(st_b4);                                     // B4: every matrix wave is done reading xt
@@ -654,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void resblock_limb_kernel(const RBArgs a) {
 #if RL_STAMPS
   if (a.dbg && tid == 0) {
     unsigned long long* o = a.dbg + blockIdx.x * 4;
-    if (blockIdx.x == 0) { unsigned long long* q = a.dbg + 256 * 4; q[0] = st_b3; q[1] = st_b1; q[2] = st_b4; q[3] = st_b2; q[4] = st_e1; q[5] = st_e2; q[6] = st_tiles; q[7] = st_gemm; q[8] = __builtin_amdgcn_s_memtime() - st_t0; }
+    if (blockIdx.x == 0) { unsigned long long* q = a.dbg + 256 * 4; q[0] = st_b3; q[1] = st_b1; q[2] = st_b4; q[3] = st_b2; q[4] = st_e1; q[5] = st_e2; q[6] = st_tiles; q[7] = st_gemm; q[8] = __builtin_amdgcn_s_memtime() - st_t0; q[9] = st_head; q[10] = st_pre; q[11] = st_mid; }
     o[0] = st_gemm; o[1] = __builtin_amdgcn_s_memtime() - st_t0; o[2] = __builtin_amdgcn_s_memrealtime() - st_r0; o[3] = st_bar;
   }
 #endif

@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
       printf("%s C=%3d T=%5d dil=%d rows/tile=%3d: max|err| %.2e (max|ref| %.2f) stray=%lld  %8.1f us  %6.1f TFLOP/s (%.1f%% of 157.3)\n", limb ? "limb" : "f32 ", C, T, d, rows, worst, scale, stray,
              ms * 1e3, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 157.3 * 100);
       {
-        std::vector<unsigned long long> hd(264 * 4);
+        std::vector<unsigned long long> hd(264 * 4);      // (256 blocks x 4 + block 0's 12 extra words)
         CHECK(hipMemcpy(hd.data(), ddbg, hd.size() * 8, hipMemcpyDeviceToHost));
         if (hd[1]) {
           double g = 0, t = 0, r = 0, bw = 0; int nb = 0; double tmax = 0;
@@ -186,6 +186,8 @@ int main(int argc, char** argv) {
                  100 * bw / t, t / nb, r / nb / 100.0, tmax / 100.0, (t / nb) / (r / nb / 100.0) / 1e3);
           printf("   block 0 barrier cycles: B3 %llu  B1 %llu  B4 %llu  B2 %llu;  %llu tiles: c1 epilogue %llu  c2 epilogue %llu  gemm %llu  life %llu  -> other %lld\n", hd[1024], hd[1025], hd[1026], hd[1027],
                  hd[1030], hd[1028], hd[1029], hd[1031], hd[1032], (long long)hd[1032] - (long long)(hd[1024] + hd[1025] + hd[1026] + hd[1027] + hd[1028] + hd[1029] + hd[1031]));
+          printf("   block 0 helper wave: table + draw issued %llu, B(-1) passed %llu, window loads issued %llu, (deep draw) %llu, window written %llu, B0 passed %llu\n", hd[1036], hd[1037], hd[1038], hd[1039], hd[1040], hd[1041]);
+          printf("   block 0: %llu cycles before the first tile, %llu between a tile's start and its c1 K loop, %llu between B1 and c2's K loop (sums over its tiles)\n", hd[1033], hd[1034], hd[1035]);
 
         }
       }
