@@ -74,7 +74,7 @@ def test_400_pipelined_steps_equal_the_blocking_loop(full_ctx, S, arith):
 def test_an_unmet_wait_gives_up_and_is_reported(full_ctx, kind, name):
     from conan_amd import _lib
     ctx = full_ctx
-    S = 24                                   # megakernel (6 tiles), Emformer clusters (12 groups x 8), pair kernel (>= 16 slots, f32)
+    S = 24                                   # megakernel (6 tiles), Emformer clusters (12 groups x 4), pair kernel (>= 16 slots, f32)
     st = ctx.streams(S, 4, 64, arith="f32")
     ids = list(range(S))
     st.reset(ids); st.set_reference(ids, torch.from_numpy(synth.mel(40, 8, S)).cuda())
