@@ -364,12 +364,14 @@ void conan_streams::build_vocoder() {
     // tile (resblock_pair.hip).  A tile is all rows of a stream's step, so the stream-set must not take more than 32 rows per
     // step in this stage (windowed / whole-utterance stream-sets keep the two-launch plan), and it needs enough streams to
     // give the chip tiles.
-    // ... unless the stream-set is large enough for conv_limb's grouped launches (three problems of 3 / 7 / 11 taps, 64-row tiles:
-    // 6 tiles per stream, so >= 43 streams give every CU one): alone the two forms take the same time (6 x 48 against 3 x 98 us at
-    // 64 streams), but in the pipelined step the limb convs - LDS-bound, a third of the MFMA rate - leave the decoder and the
-    // Emformer more of the CUs they share than the f32-MFMA-dense pair kernel does: 1.408 against 1.427 ms per step, three
-    // alternating runs on one box (p95 of the step intervals 1.53 against 1.57).  CONAN_RB_PAIR=1 keeps the pair kernel.
-    const bool limb_groups = rb_limb && max_slots >= 48 && getenv("CONAN_RB_PAIR") == nullptr;
+    // ... for exact-f32 stream-sets.  bf16-limb stream-sets of the same sizes run this stage's convs as conv_limb's grouped launches
+    // (three problems of 3 / 7 / 11 taps per launch, 64-row tiles: 6 tiles per stream): 6 x 33-44 us against the pair kernel's 3 x 96-99,
+    // which is the time of ONE tile at any stream count below 128 - measured per pipelined step / blocking p50 at 16 / 24 / 32 / 40
+    // streams 0.806 -> 0.760 / 1.45 -> 1.36, 0.906 -> 0.818 / 1.58 -> 1.48, 0.992 -> 0.949 / 1.66 -> 1.58, 1.170 -> 1.083 / 1.89 -> 1.79 ms
+    // (round 4, late; until then from 48 slots on, where the two took the same time alone before conv_limb's last 10 %).  Below 16
+    // slots the stage keeps conv_mfma's two-launch plan with its split-K tails: the grouped limb launches would be 2-5 % faster per
+    // pipelined step there and 5-9 % slower per blocking step.  CONAN_RB_PAIR=1 keeps the pair kernel.
+    const bool limb_groups = rb_limb && max_slots >= 16 && getenv("CONAN_RB_PAIR") == nullptr;
     if (!s.fused && !limb_groups && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
         c.voc_num_resblocks <= kMaxBranches && max_slots >= (getenv("CONAN_RP_MIN_SLOTS") ? atoi(getenv("CONAN_RP_MIN_SLOTS")) : 16) && max_frames * rate <= 32) {
       s.pair = true;

@@ -6,7 +6,7 @@
 
 Both are fp32 convolutions of the SAME fp32 inputs and weights, so the yardstick for either is the same convolution evaluated
 in float64 (oracle/hifigan.py restates hifigan_causal.py:217-244 ResBlock1 and :191-212 the pixel-shuffle upsampler; run on
-float64 tensors it is that evaluation).  Per kernel - the MRF stage C = 256 (conv_limb's grouped launches at >= 48 slots), the
+float64 tensors it is that evaluation).  Per kernel - the MRF stage C = 256 (conv_limb's grouped launches at >= 16 slots), the
 fused ResBlock passes C = 128 / 64 / 32 (resblock_limb) and the upsamplers ups.2 / ups.3 (conv_limb) - the test takes the tensor
 the kernel read and the tensor it wrote through conan_hifigan_step_taps, evaluates the float64 reference on the tensor read,
 and asserts

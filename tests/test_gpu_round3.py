@@ -100,8 +100,9 @@ def test_fence_free_handoffs_match_the_fenced_build_under_concurrency():
 
 @pytest.mark.parametrize("arith,S", [("f32", 24), ("limb", 24), ("limb", 48)])
 def test_wide_stage_pairs_match_reference_goldens(arith, S):
-    """The first vocoder stage (C = 256) on stream-sets of >= 16 slots runs resblock_pair.hip: a pair of workgroups per
-    (branch, stream) tile, xt history ring instead of a halo.  Reference goldens (tools/make_goldens.py: wav_150, wav_12,
+    """The first vocoder stage (C = 256) on exact-f32 stream-sets of >= 16 slots runs resblock_pair.hip: a pair of workgroups per
+    (branch, stream) tile, xt history ring instead of a halo; bf16-limb stream-sets of >= 16 slots run its convs as conv_limb's
+    grouped launches.  Reference goldens (tools/make_goldens.py: wav_150, wav_12,
     pre_tanh_12) streamed through slot 11 of a 24-slot stream-set while the other slots carry other streams, in steps
     of 4 frames with a ragged tail (150 = 37 x 4 + 2; then 12 frames as 3 + 1 + 4 + 2 + 2: 24, 8, 32, 16 and 16 rows in
     the wide stage)."""
@@ -131,12 +132,12 @@ def test_wide_stage_pairs_match_reference_goldens(arith, S):
     for r in range(3):
         np.testing.assert_allclose(wav12[r], g["wav_12"], atol=1e-4, rtol=0)
         np.testing.assert_allclose(pre12[r], g["pre_tanh_12"][0], atol=1e-4 * max(1.0, np.abs(g["pre_tanh_12"]).max()), rtol=0)
-    # which kernels carried the wide first stage: the f32 pair kernel (16-47 slots in either arithmetic, every f32 stream-set of
-    # >= 16 slots), conv_limb's grouped launches (limb stream-sets of >= 48 slots: 3 dilations x (c1, c2) + ups.2 + ups.3)
+    # which kernels carried the wide first stage: the f32 pair kernel (every f32 stream-set of >= 16 slots), conv_limb's grouped
+    # launches (limb stream-sets of >= 16 slots: 3 dilations x (c1, c2); from 48 slots on ups.2 + ups.3 as well)
     from tests.conftest import assert_arith_ran, kernels_of
     names = kernels_of(st, lambda: st.hifigan_step(ids, mel[:, :4].contiguous()))
     assert_arith_ran(names, arith)
-    if arith == "limb" and S >= 48:
+    if arith == "limb":
         assert sum(n for k, n in names.items() if "conv_limb_kernel" in k) >= 6 and not any("resblock_pair_kernel" in k for k in names), sorted(names)
     else:
         assert any("resblock_pair_kernel" in k for k in names), sorted(names)
@@ -152,9 +153,9 @@ def test_wide_stage_pairs_equal_the_two_launch_plan_per_stage():
     old = os.environ.get("CONAN_RB_NOPAIR")
     try:
         os.environ.pop("CONAN_RB_NOPAIR", None)
-        a = ctx.streams(S, max_frames=4, max_ref_frames=16)
+        a = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32")       # (the pair kernel is the exact-f32 form of this stage)
         os.environ["CONAN_RB_NOPAIR"] = "1"
-        b = ctx.streams(S, max_frames=4, max_ref_frames=16)
+        b = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32")
     finally:
         if old is None:
             os.environ.pop("CONAN_RB_NOPAIR", None)
@@ -294,7 +295,7 @@ def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, other):
     """resblock_limb.hip / conv_limb.hip form every fp32 product from three bf16 limbs per operand (six bf16 MFMA products,
     accumulated in fp32); conan_streams_opts.arith selects the form per stream-set.
     64 streams through a limb stream-set - limb kernels in the C = 128 / 64 / 32 ResBlock stages, in ups.2 / ups.3 and, for
-    stream-sets of >= 48 slots, conv_limb's grouped launches (three problems of 3 / 7 / 11 taps per launch, list-scheduled tiles)
+    stream-sets of >= 16 slots, conv_limb's grouped launches (three problems of 3 / 7 / 11 taps per launch, list-scheduled tiles)
     for the ResBlock convs of the C = 256 stage - and through a default one (exact-f32 MFMA, pair kernel in the first stage) or
     a limb one created with the developer switch CONAN_RB_PAIR=1 (limb kernels, but the f32 pair kernel in the first stage): per-stage tensors,
     pre-tanh and audio agree to fp32 re-association - the same bound the pair / two-launch cross-check uses."""
