@@ -479,9 +479,11 @@ int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu) {
       const double u = (double)p[q].ktaps * p[q].Cin * TM * TN;
       tiles += t; units += u * t; umax = std::max(umax, u);
     }
-    // (a single problem needs a tile for every CU; a group of problems is what the C = 256 ResBlock stage launches, whose alternative
-    // - the f32 pair kernel - takes the time of one whole tile at any size: from a third of the CUs on, streams.hip build_vocoder)
-    if (!ok || tiles * (nprob > 1 ? 3 : 1) < num_cu) continue;
+    // (a single problem - ups.2 / ups.3 - from a tile for every second CU on: 16 / 24 streams measured 0.767 -> 0.762 / 0.827 -> 0.810 ms
+    // per step against conv_mfma's f32 passes, nothing either way below that; a group of problems is what the C = 256 ResBlock stage
+    // launches, whose alternative - the f32 pair kernel - takes the time of one whole tile at any size: from a third of the CUs on,
+    // streams.hip build_vocoder)
+    if (!ok || tiles * (nprob > 1 ? 3 : 2) < num_cu) continue;
     // (a single problem in 64-row tiles - ups.1: 320 tiles, two rounds - measured slower than conv_mfma's f32 pass with its
     // split-K tail, 78 against 72 us; groups of problems are list-scheduled and take them)
     if (nprob == 1 && TM < 80 && forced < 0) continue;

@@ -133,7 +133,7 @@ def test_wide_stage_pairs_match_reference_goldens(arith, S):
         np.testing.assert_allclose(wav12[r], g["wav_12"], atol=1e-4, rtol=0)
         np.testing.assert_allclose(pre12[r], g["pre_tanh_12"][0], atol=1e-4 * max(1.0, np.abs(g["pre_tanh_12"]).max()), rtol=0)
     # which kernels carried the wide first stage: the f32 pair kernel (every f32 stream-set of >= 16 slots), conv_limb's grouped
-    # launches (limb stream-sets of >= 16 slots: 3 dilations x (c1, c2); from 48 slots on ups.2 + ups.3 as well)
+    # launches (limb stream-sets of >= 16 slots: 3 dilations x (c1, c2); from 16 slots on ups.2 + ups.3 as well: a tile for every second CU)
     from tests.conftest import assert_arith_ran, kernels_of
     names = kernels_of(st, lambda: st.hifigan_step(ids, mel[:, :4].contiguous()))
     assert_arith_ran(names, arith)
