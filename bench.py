@@ -11,6 +11,13 @@ Inputs (synthetic mel chunks, reference mels, random-init weights of the egs/con
 egs/hifi_16k320_shuffle.yaml architectures) are resident in HBM before the timed region.
 Streams are sharded across ranks (weak scaling: B per GPU fixed); the only collective is the RCCL
 gather of the finished audio to rank 0, inside the timed region.  Rank 0 prints ONE JSON line.
+
+Timing: W untimed warm-up steps, barrier + synchronize, exactly K timed steps, barrier + synchronize (Runner.timed).  Before the W
+steps the stream-set is primed once as part of its setup (Runner.prime, --prime N, default 100 pipelined steps = 0.13 s; reported as
+config.priming_steps): the first steps of a freshly built process are not the stream's throughput (the host enqueues them slower, the
+GPU comes out of seconds of idling).  What K and W do to the reading, one box: K = 200 / W = 30 1.308 ms per step, K = 60 / W = 10
+1.33 (the defaults), K = 20 / W = 5 1.36-1.38 primed and 1.41-1.42 unprimed - a timed region starts from an empty pipeline, so it pays the
+first chunk's Emformer + decoder latency (0.73 ms) before its first vocoder step: 0.037 ms per step at K = 20, 0.004 at K = 200.
 """
 import argparse
 import json
@@ -231,6 +238,7 @@ class Runner:
                                     every=int(os.environ.get("CONAN_BENCH_GATHER_EVERY", "4")))
         self.hist = [torch.randint(0, 100, (B, self.window), dtype=torch.int32, device="cuda")] if self.window else None
         self.j = 0
+        self.primed = 0
 
     def step(self):
         j, eng, seg = self.j, self.eng, self.seg
@@ -265,6 +273,19 @@ class Runner:
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def prime(self, n):
+        """Setup, before the W warm-up steps: n pipelined steps of the workload itself, then a barrier.  A process that has just
+        built its context and stream-set is cold in ways W = 5 steps do not cure - Python / ctypes paths run for the first time
+        (the host needs 1.2 ms to enqueue a step at first, 0.85 ms later, against 1.3 ms of GPU time per step), the GPU comes out
+        of seconds of idling: completion intervals of the first steps after a cold start read 1.66, 1.41, 1.35, 1.32, 1.31 ms
+        (means of 5, tools/cold_series.py) - a server's first 30 ms, not its throughput.  Reported as config.priming_steps."""
+        if self.window:
+            n = min(n, 10)       # (windowed steps are blocking and long: a few are enough)
+        for _ in range(n):
+            self.step()
+        self.barrier()
+        self.primed = n
 
     def timed(self, steps, warmup, marks=False):
         """W untimed + exactly K timed steps between barrier + synchronize on both sides -> seconds (this rank's clock)."""
@@ -349,6 +370,8 @@ def main():
     ap.add_argument("--arith", default="auto", choices=["auto", "f32", "limb"],
                     help="arithmetic of the vocoder's matrix kernels (conan_streams_opts.arith); auto = the library's default, which `value` measures")
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
+    ap.add_argument("--prime", type=int, default=int(os.environ.get("CONAN_BENCH_PRIME", "100")),
+                    help="setup: pipelined steps run once after the stream-set is built, before the W warm-up steps (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-steps", type=int, default=40)
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency leg (keeps profiler summaries to one workload)")
@@ -374,6 +397,8 @@ def main():
     arith = run.arith                     # what the library resolved `auto` to: the form `value` is measured in
     hop, seg = run.hop, run.seg
 
+    if args.prime > 0:
+        run.prime(args.prime)
     dt = run.timed(args.steps, args.warmup, marks=args.marks)
     j = run.j
     # Every rank's own clock, its device, and a check of the exchange: the audio rank 0 gathered for the LAST gathered step must
@@ -509,6 +534,8 @@ def main():
             try:
                 run.close()                      # (one stream-set at a time: the other form is timed as the headline was)
                 o = Runner(ctx, wl, B, rank, world, other)
+                if args.prime > 0:
+                    o.prime(args.prime)
                 o_dt = o.timed(args.steps, args.warmup)
                 o_lat = o.latencies(max(10, args.latency_steps // 2))
                 od = dominant(o.kernel_profile())
@@ -532,7 +559,8 @@ def main():
                        "name": args.workload, "baseline_config": wl["config"], "arith": arith, "arith_requested": args.arith,
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
                        "architecture": "egs/conan_emformer.yaml + egs/hifi_16k320_shuffle.yaml shapes, random-init weights",
-                       "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1"},
+                       "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1",
+                       "priming_steps": run.primed},
             "p50_latency_ms": p50, "latency_stats": lat_stats, "step_time_stats": step_stats, "ranks": ranks,
             "schedule": ("throughput and latency: one blocking windowed step" if window else
                          "throughput: pipelined steps (the three stages of consecutive chunks overlap on three HIP streams); latency: one blocking fused step"),
