@@ -18,6 +18,10 @@ config.priming_steps): the first steps of a freshly built process are not the st
 GPU comes out of seconds of idling).  What K and W do to the reading, one box: K = 200 / W = 30 1.308 ms per step, K = 60 / W = 10
 1.33 (the defaults), K = 20 / W = 5 1.36-1.38 primed and 1.41-1.42 unprimed - a timed region starts from an empty pipeline, so it pays the
 first chunk's Emformer + decoder latency (0.73 ms) before its first vocoder step: 0.037 ms per step at K = 20, 0.004 at K = 200.
+Both readings are in the line (round 5): the very same timed(K, W) runs once BEFORE the priming pass -> roofline.ms_per_step_unprimed
+(exactly what `--warmup W` alone gives), and once after it -> ms_per_step / value.  roofline.vocoder_alone_ms is the vocoder stage's
+launches back to back on one stream (conan_hifigan_step loop, no front-end resident), roofline.frontend_cost_ms = ms_per_step minus it:
+what the Emformer + decoder stages cost the pipelined step.
 """
 import argparse
 import json
@@ -203,7 +207,7 @@ def pmc_summary(tag):
     from inside the benchmark): profiles/r<round>_<tag>_pmc.json, made by tools/collect_profiles.sh + tools/summarize_pmc.py
     (newest round first).  The summary records the sha256 of the library it was collected with; `stale` says whether that
     differs from the library loaded now (a summary without a hash counts as stale)."""
-    for rnd in ("r4",):
+    for rnd in ("r5", "r4"):
         path = os.path.join(REPO, "profiles", f"{rnd}_{tag}_pmc.json")
         try:
             d = json.load(open(path))
@@ -332,6 +336,21 @@ class Runner:
         return {"n": len(lats), "p50_ms": statistics.median(lats), "p95_ms": sorted(lats)[min(len(lats) - 1, int(round(0.95 * (len(lats) - 1))))],
                 "sigma_ms": statistics.pstdev(lats), "min_ms": min(lats), "max_ms": max(lats)}
 
+    def vocoder_alone(self, n=60, warm=10):
+        """ms per vocoder step with nothing else on the chip: conan_hifigan_step for all B streams, enqueued back to back on the
+        caller's stream (the launches the pipelined step's vocoder stage makes), one synchronize at the end."""
+        if self.window:
+            return None
+        st, mel = self.eng.st, (torch.rand(self.B, self.seg, 80, device="cuda") * 4 - 5)
+        for _ in range(warm):
+            st.hifigan_step(self.eng.slots, mel, out=self.wav)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            st.hifigan_step(self.eng.slots, mel, out=self.wav)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
     def kernel_profile(self, nprof=5):
         """HIP events around every launch of the matrix kernels on their launch stream (blocking steps): per kernel template
         ('family') and per instantiation the summed time, algorithmic FLOPs and launches."""
@@ -397,6 +416,9 @@ def main():
     arith = run.arith                     # what the library resolved `auto` to: the form `value` is measured in
     hop, seg = run.hop, run.seg
 
+    # the unprimed reading: exactly W warm-up + K timed steps on the freshly built stream-set (what --warmup alone means) ...
+    dt_unprimed = run.timed(args.steps, args.warmup) if (args.prime > 0 and not args.marks) else None
+    # ... and the steady-state one behind the priming pass: `value`
     if args.prime > 0:
         run.prime(args.prime)
     dt = run.timed(args.steps, args.warmup, marks=args.marks)
@@ -441,10 +463,12 @@ def main():
     frames_per_step = (window + seg) if window else seg           # decoder / vocoder frames computed per stream per step
 
     roof = b1 = cpu = fe = None
-    p50 = lat_stats = None
+    p50 = lat_stats = voc_alone = None
     if not args.marks:
         lat_stats = run.latencies(args.latency_steps)
         p50 = lat_stats["p50_ms"]
+        if rank == 0:
+            voc_alone = run.vocoder_alone()
 
     if rank == 0 and not args.marks:
         # roofline of the dominant kernel: HIP events around every launch of the matrix kernels on their stream
@@ -478,7 +502,9 @@ def main():
                 "kernel": name, "arith": arith, "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                 "gflop_per_launch": dom["gflop_per_launch"], "kernel_ms_per_step": dom["ms_per_step"], "share_of_step_time": dom["ms_per_step"] / ms_step,
                 # scalar companions of the headline (flat, so that they survive parsers that keep only scalars)
-                "ms_per_step": ms_step, "p50_latency_ms": p50, "p95_latency_ms": lat_stats["p95_ms"] if lat_stats else None,
+                "ms_per_step": ms_step, "ms_per_step_unprimed": (dt_unprimed / args.steps * 1e3) if dt_unprimed else None,
+                "vocoder_alone_ms": voc_alone, "frontend_cost_ms": (ms_step - voc_alone) if voc_alone else None,
+                "p50_latency_ms": p50, "p95_latency_ms": lat_stats["p95_ms"] if lat_stats else None,
                 "step_interval_p50_ms": step_stats["p50_ms"] if step_stats else None, "step_interval_p95_ms": step_stats["p95_ms"] if step_stats else None,
                 "step_gflop_algorithmic": flops_step / 1e9, "step_tflops": step_tflops,
                 "step_mfma_frac": step_tflops / PEAK_F32_MFMA_TFLOPS, "step_mfma_frac_basis": "whole step's algorithmic FLOP/s over the f32 MFMA dense peak (157.3): the decoder and Emformer compute on it in both forms",
@@ -494,24 +520,32 @@ def main():
                 "matrix_kernels": [{"kernel": kn, "launches_per_step": n_ / nprof, "us_per_launch": ms_ * 1e3 / n_, "ms_per_step": ms_ / nprof,
                                     "tflops": fl_ / (ms_ * 1e-3) / 1e12, "peak": kernel_peak(kn)[0], "frac": fl_ / (ms_ * 1e-3) / 1e12 / kernel_peak(kn)[0],
                                     "frac_of_f32_mfma_peak": fl_ / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS} for kn, ms_, fl_, n_ in kernels]}
+        # the dominant kernel's fraction per channel width (its instantiations differ by an order of magnitude in tile shape): scalars
+        for width in (128, 64, 32):
+            sel = [(ms_, fl_) for kn, ms_, fl_, n_ in kernels if kn.startswith(name + "<%d," % width)]
+            if sel:
+                roof["dominant_frac_c%d" % width] = sum(f for _, f in sel) / (sum(m for m, _ in sel) * 1e-3) / 1e12 / k_peak
         # batch=1 latency configuration (BASELINE.json configs[1]) beside the throughput one
         if args.workload == "b64" and not args.streams and not args.no_b1:
-            e1, ch1 = make_engine(ctx, 1, first_stream=100000, arith=args.arith)
-            c1 = torch.empty(1, seg, dtype=torch.int32, device="cuda")
-            m1 = torch.empty(1, seg, 80, device="cuda")
-            w1 = torch.empty(1, seg * hop, device="cuda")
-            l1 = []
-            for k in range(10 + args.latency_steps):
-                torch.cuda.synchronize()
-                a = time.perf_counter()
-                e1.st.step(e1.slots, ch1[k % len(ch1)], emit=seg, codes=c1, mel_out=m1, wav_out=w1)
-                torch.cuda.synchronize()
-                if k >= 10:
-                    l1.append((time.perf_counter() - a) * 1e3)
-            b1 = {"workload": WORKLOADS["b1"]["desc"], "p50_latency_ms": statistics.median(l1),
-                  "chunks_per_s": 1e3 / statistics.median(l1)}
-            roof["latency_b1_ms"] = b1["p50_latency_ms"]
-            e1.st.close()
+            def small_batch_latency(nb):
+                e1, ch1 = make_engine(ctx, nb, first_stream=100000, arith=args.arith)
+                c1 = torch.empty(nb, seg, dtype=torch.int32, device="cuda")
+                m1 = torch.empty(nb, seg, 80, device="cuda")
+                w1 = torch.empty(nb, seg * hop, device="cuda")
+                l1 = []
+                for k in range(10 + args.latency_steps):
+                    torch.cuda.synchronize()
+                    a = time.perf_counter()
+                    e1.st.step(e1.slots, ch1[k % len(ch1)], emit=seg, codes=c1, mel_out=m1, wav_out=w1)
+                    torch.cuda.synchronize()
+                    if k >= 10:
+                        l1.append((time.perf_counter() - a) * 1e3)
+                e1.st.close()
+                return statistics.median(l1)
+            l1 = small_batch_latency(1)
+            b1 = {"workload": WORKLOADS["b1"]["desc"], "p50_latency_ms": l1, "chunks_per_s": 1e3 / l1}
+            roof["latency_b1_ms"] = l1
+            roof["latency_b4_ms"] = small_batch_latency(4)      # the same blocking step for 4 streams (small-batch path)
         # the step before the path: GPU mel front-end rate for B x 3 s of audio (not part of `value`)
         try:
             w = torch.rand(B, 48000, device="cuda") * 2 - 1

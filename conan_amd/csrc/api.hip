@@ -154,6 +154,10 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
         throw Error(CONAN_ERR_UNSUPPORTED, "arith = limb: this context holds no bf16-limb weights (no HiFi-GAN model, or a vocoder configuration without limb kernels)");
       s->arith_auto = arith == CONAN_ARITH_AUTO;
       s->rb_limb = arith == CONAN_ARITH_LIMB || (arith == CONAN_ARITH_AUTO && ctx->has_limb_weights && getenv("CONAN_RB_NOLIMB") == nullptr);
+      // small stream-sets (one mel row tile per step) run the vocoder step as one persistent launch on the f32 MFMA (voc_chain.hip)
+      // unless the caller asked for the limb arithmetic: AUTO resolves to F32 there (conan_streams_arith says so)
+      s->voc_chain = s->chain_eligible(arith == CONAN_ARITH_LIMB);
+      if (s->voc_chain) s->rb_limb = false;
       { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
       { const char* e = getenv("CONAN_DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
       { const char* e = getenv("CONAN_MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -106,6 +107,14 @@ struct conan_ctx {
   void finalize_hifigan();
   void finalize_conan();
   void finalize_emformer();
+  // fragment-major copies of the vocoder's conv weights for voc_chain.hip, made on the device from the conv_mfma layout the first
+  // time a small stream-set asks for them (most contexts never do: 120 MB)
+  std::map<std::string, float*> chain_w;
+  std::mutex chain_mu;
+  const float* chain_weight(const std::string& conv_name);
+  // the persistent chain launches of a context never overlap on the device (each needs its whole grid resident): every launch
+  // waits for the event recorded behind the one before
+  hipEvent_t chain_done = nullptr;
   // mel front-end (frontend.hip): tables are built on first use per configuration; one workspace, regrown when a call needs more
   float* fe_ws = nullptr; size_t fe_ws_floats = 0;
   void wav2mel(const conan_mel_cfg& m, const float* wav, int n, int samples, float* mel_out, hipStream_t st);

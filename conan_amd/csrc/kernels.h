@@ -31,17 +31,25 @@ enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4
 //   guard[0]     error code, device memory (agent scope): 0 = healthy
 //   guard[2..3]  address of the host-mapped word the code is copied to
 // The clock is read only every 256th poll iteration, and not at all by waits that end earlier.
+// What counts against the budget is the time the waiter spent POLLING, not wall time: s_memrealtime keeps running while a queue's
+// waves are descheduled (context-save preemption when several processes oversubscribe the hardware queues, a debugger halt), and a
+// waiter restored together with its partner would otherwise see the whole pause as "spent" before the partner had a chance to
+// arrive.  Two consecutive clock reads are 256 polls apart (~0.1-0.5 ms); a gap above kSpinGapTicks (1 ms) between them is taken
+// for a deschedule and counts as 1 ms only (never as nothing: polls slowed down by a congested memory system must still run the
+// budget down, a wait without an end takes the box with it).
 constexpr unsigned long long kSpinBudgetTicks = 5000000ull;
-enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4 };
-struct SpinGuard { unsigned long long t0 = 0; unsigned it = 0; };
+constexpr unsigned long long kSpinGapTicks = 100000ull;
+enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4, WAIT_VOC_PHASE = 5 };
+struct SpinGuard { unsigned long long last = 0, acc = 0; unsigned it = 0; };
 #if defined(__HIPCC__)
 // true: give up (budget spent, or another wait of this stream-set already failed)
 __device__ __forceinline__ bool spin_expired(SpinGuard& g, unsigned* guard, unsigned code) {
   if ((++g.it & 255u) != 0u || guard == nullptr) return false;
   if (__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
   const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-  if (g.t0 == 0) { g.t0 = now; return false; }
-  if (now - g.t0 < kSpinBudgetTicks) return false;
+  if (g.last != 0) { const unsigned long long d = now - g.last; g.acc += d < kSpinGapTicks ? d : kSpinGapTicks; }
+  g.last = now;
+  if (g.acc < kSpinBudgetTicks) return false;
   __hip_atomic_store(guard, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned* host = *reinterpret_cast<unsigned* const*>(guard + 2);
   if (host) __hip_atomic_store(host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -437,6 +445,59 @@ struct MegaLaunch {
   int wide_regs;          // 1: the 128-register build (bf16-limb stream-sets), 0: the 80-register build
 };
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st);
+
+// The vocoder step of a SMALL stream-set (slots x frames <= 16 mel rows) as ONE persistent launch (voc_chain.hip): conv_pre ->
+// 4 x (upsampler + MRF stage) -> conv_post (HifiGanGenerator.forward, hifigan_causal.py:314-333) walked as a list of PHASES; a
+// phase is one conv layer of all branches, cut into jobs (problem, row tile, column group) that the grid's workgroups deal among
+// themselves; dependent phases are separated by an arrival counter.  Activations cross workgroups as agent-scope write-through
+// stores / sc1 loads (no fence), weights are fragment-major and prefetched into registers BEFORE the wait for the previous phase.
+constexpr int VC_MAX_PHASES = 40;
+struct VCProb {
+  TRef xnew[3];         // input rows of THIS step (tau >= 0): one tensor, or nsrc raw branch outputs whose leaky_relu(mean) is the input
+  TRef xhist;           // input rows of earlier steps (tau < 0): a ring; with store_new the rows formed from xnew are appended to it
+  TRef y;               // output ring
+  TRef res;             // residual operand (has_res)
+  const float* w;       // fragment-major [ncts][k + 1 taps (last zero)][KQ][64 lanes][4] (+ slack: the register ring reads ahead)
+  const float* bias;    // [>= ncts * 16], packed column order
+  int nsrc, store_new, has_res, in_lrelu;
+  int io_in;            // 1: xnew[0].base comes from the launch arguments (the step's mel chunk)
+  int tap;              // index into VCIO::tap of a linear copy [n][rows out][Cy] of the stored rows, -1: none
+  int Cin, Cout, k, dil, KQ, ncts;
+  int out_act; float in_slope, out_slope, mean_slope;
+  int shuffle_r, Cq;    // pixel shuffle: packed column c -> output row t * r + c / Cq, channel c % Cq
+  int tap_new;          // index into VCIO::tap of a linear copy [n][T][Cin] of the rows formed from xnew (store_new), -1: none
+  int pad_;
+};
+struct VCPhase {
+  int type;             // 0: convolution on the f32 MFMA, 1: conv_post (VALU dot product + tanh)
+  int nprob, n, T;      // problems (branches), slots, conv rows per slot and step
+  int NRT, NCT, KS;     // per job: row tiles of 16 rows, column tiles of 16 per workgroup, K slices per column tile (NCT * KS = 8 waves)
+  int tiles_per_slot;   // T >= 16: a job's rows are 16 * NRT consecutive rows of one slot
+  int spt;              // T < 16: a job's rows are ALL rows of spt consecutive slots (spt * T <= 16); 0 otherwise
+  int tiles;            // row tiles per problem
+  int ncg;              // column groups per (problem, row tile) = ncts / NCT
+  int njobs;
+  int magic_c4;         // floor(2^32 / (Cin / 4)) + 1
+  int kpost;            // conv_post: taps
+  float bpost;          // conv_post: bias
+  int pad_;
+  const float* wpost;   // conv_post: [k][C]
+  VCProb p[3];
+};
+constexpr int VC_MAX_TAPS = 20;
+struct VCIO { const float* mel; float* wav; float* pre; float* tap[VC_MAX_TAPS]; };
+struct VCLaunch {
+  const VCPhase* prog; int nphases, grid, lds_bytes;
+  const int* slots; int* pos; int n, adv;   // pos[slots[q]] += adv by the last workgroup to finish
+  unsigned* bar;                            // (VC_MAX_PHASES + 1) arrival counters, 16 words apart, zero before the first launch
+  unsigned* guard;
+  VCIO io;
+};
+void launch_voc_chain(const VCLaunch& l, hipStream_t st);
+int voc_chain_max_grid(int lds_bytes, int num_cu);     // workgroups that can be resident at once
+// fragment-major repack of a conv_mfma weight ([Cout_pad/64][k][Cin_alloc/4][64][4]) for voc_chain: returns floats written
+size_t voc_chain_weight_floats(int Cout, int Cin, int k);
+void launch_voc_chain_repack(float* dst, const float* w, int Cout, int Cout_pad, int Cin, int Cin_alloc, int k, hipStream_t st);
 
 struct ArgmaxArgs { const float* x; int* idx; int rows, C; };
 void launch_argmax(const ArgmaxArgs& a, hipStream_t st);

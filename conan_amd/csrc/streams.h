@@ -198,6 +198,7 @@ struct conan_streams {
     for (auto& e : clock_ev) (void)hipEventDestroy(e);
     for (auto& m : mega_cache) { if (m.copied) (void)hipEventDestroy(m.copied); if (m.pinned) (void)hipHostFree(m.pinned); if (m.dev) (void)hipFree(m.dev); }
     for (auto& e : tl_ev) (void)hipEventDestroy(e);
+    for (auto& v : vc_progs) if (v.dev) (void)hipFree(v.dev);
   }
 
   void build_vocoder();
@@ -262,10 +263,40 @@ struct conan_streams {
   void op_advance(int* pos, int n, int delta, hipStream_t st);
 
   void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps = nullptr);
+  // --- small stream-sets (max_slots x max_frames <= 16 mel rows): the vocoder step as ONE persistent launch (voc_chain.hip,
+  // voc_chain_host.hip).  Chosen at creation (chain_eligible); such a stream-set has no other vocoder plan.
+  bool voc_chain = false;
+  unsigned* vc_bar = nullptr;                    // per-phase arrival counters
+  struct VCProgram { int n = 0, frames = 0, nphases = 0, lds_bytes = 0, grid = 0; double flops = 0.0; cnk::VCPhase* dev = nullptr; };
+  std::vector<VCProgram> vc_progs;               // one per (slots, frames) seen so far
+  bool chain_eligible(bool limb_requested) const;
+  bool chain_build(int n, int frames, std::vector<cnk::VCPhase>& out, int* lds_bytes, int* grid) const;
+  const VCProgram& chain_program(int n, int frames);
+  void chain_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps);
   void emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st);
   void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st, const DecExtra* extra = nullptr);
   void set_reference(const int32_t* slots, int n, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st);
   void conv_blocks_noncausal(const std::string& name, int nblocks, int k, int C, Lin* x, Lin& ln, Lin& h, Lin& blkm, const TRef& npm,
                              const int* lens, int n, int T, int& cur, hipStream_t st);
 };
+
+// every launch of the matrix kernels goes through here: between conan_profile_begin / _end it is bracketed by HIP
+// events on its launch stream and booked under the kernel's name with its algorithmic FLOPs
+template <typename F>
+inline void conan_streams::profiled(const std::string& name, double flops, hipStream_t st, F&& launch) {
+  if (!prof_on) { launch(); return; }
+  if (prof_used == prof_ev.size()) {
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    prof_ev.push_back({a, b});
+  }
+  auto& ev = prof_ev[prof_used++];
+  HIP_CHECK(hipEventRecord(ev.first, st));
+  launch();
+  HIP_CHECK(hipEventRecord(ev.second, st));
+  prof_flops += flops;
+  prof_launches += 1;
+  prof_rec.push_back({name, flops});
+}
+
 

@@ -134,25 +134,6 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
   profiled(cnk::conv_cfg_name(cfg), fl, st, [&] { cnk::launch_conv(g, nprob, cfg, st, cus_all); });
 }
 
-// every launch of the matrix kernels goes through here: between conan_profile_begin / _end it is bracketed by HIP
-// events on its launch stream and booked under the kernel's name with its algorithmic FLOPs
-template <typename F>
-void conan_streams::profiled(const std::string& name, double flops, hipStream_t st, F&& launch) {
-  if (!prof_on) { launch(); return; }
-  if (prof_used == prof_ev.size()) {
-    hipEvent_t a, b;
-    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-    prof_ev.push_back({a, b});
-  }
-  auto& ev = prof_ev[prof_used++];
-  HIP_CHECK(hipEventRecord(ev.first, st));
-  launch();
-  HIP_CHECK(hipEventRecord(ev.second, st));
-  prof_flops += flops;
-  prof_launches += 1;
-  prof_rec.push_back({name, flops});
-}
-
 cnk::RowConvArgs conan_streams::mk_rc(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, int dil) const {
   cnk::RowConvArgs a; memset(&a, 0, sizeof(a));
   a.x = x; a.hist = ch::null_ref(); a.y = y; a.res = ch::null_ref(); a.m1 = ch::null_ref(); a.m2 = ch::null_ref();
@@ -356,7 +337,8 @@ void conan_streams::build_vocoder() {
     // stages; at C = 32 a tile is short enough that the single pass wins even for one stream: 0.99 -> 0.95 ms per chunk)
     // (limb stream-sets: from 4 slots - measured per chunk at 4 / 6 streams 0.591 / 0.676 ms fused against 0.603 / 0.714 ms with the
     // two-launch plan in the wide stages, blocking p50 0.98 / 1.14 against 1.03 / 1.19 ms; at 1-3 streams the two-launch plan is as fast or faster)
-    s.fused = c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && (max_slots >= (rb_limb ? 4 : 8) || ch_ <= 32 || getenv("CONAN_RB_FUSED") != nullptr);
+    // (chain stream-sets - voc_chain.hip: one persistent launch per step - keep the two-launch plan's rings, without the activated twins)
+    s.fused = !voc_chain && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && (max_slots >= (rb_limb ? 4 : 8) || ch_ <= 32 || getenv("CONAN_RB_FUSED") != nullptr);
     for (int b = 0; b < c.voc_num_resblocks && s.fused; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d)
         s.fused = s.fused && cnk::resblock_fused_supported(ch_, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
@@ -372,7 +354,7 @@ void conan_streams::build_vocoder() {
     // slots the stage keeps conv_mfma's two-launch plan with its split-K tails: the grouped limb launches would be 2-5 % faster per
     // pipelined step there and 5-9 % slower per blocking step.  CONAN_RB_PAIR=1 keeps the pair kernel.
     const bool limb_groups = rb_limb && max_slots >= 16 && getenv("CONAN_RB_PAIR") == nullptr;
-    if (!s.fused && !limb_groups && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
+    if (!s.fused && !voc_chain && !limb_groups && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
         c.voc_num_resblocks <= kMaxBranches && max_slots >= (getenv("CONAN_RP_MIN_SLOTS") ? atoi(getenv("CONAN_RP_MIN_SLOTS")) : 16) && max_frames * rate <= 32) {
       s.pair = true;
       for (int b = 0; b < c.voc_num_resblocks; ++b)
@@ -387,7 +369,7 @@ void conan_streams::build_vocoder() {
     s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
     // LeakyReLU'd twins of `up` and of the resblock outputs that feed another c1: the producer's epilogue writes both
     // (ConvArgs::y2_base), c1 reads the activated copy, the residual add reads the raw one
-    if (!s.fused) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
+    if (!s.fused && !voc_chain) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
     s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks); s.xa.resize(c.voc_num_resblocks);
     for (int b = 0; b < c.voc_num_resblocks; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d) {
@@ -395,7 +377,7 @@ void conan_streams::build_vocoder() {
         if (!s.fused) s.xt[b].push_back(mk_ring(ch_, rate, k - 1, &voc_state));
         const int h = (d + 1 < c.voc_rb_num_dil) ? (k - 1) * (c.voc_rb_dilations[b][d + 1] + (s.fused ? 1 : 0)) : next_pad;
         s.xo[b].push_back(mk_ring(ch_, rate, h, &voc_state));
-        if (!s.fused && d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
+        if (!s.fused && !voc_chain && d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
       }
     if (s.pair) {
       s.xh.resize(c.voc_num_resblocks);
@@ -408,6 +390,7 @@ void conan_streams::build_vocoder() {
       }
     }
   }
+  if (voc_chain) vc_bar = reinterpret_cast<unsigned*>(alloc(16 * (size_t)(cnk::VC_MAX_PHASES + 2)));
 }
 
 void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps) {
@@ -423,6 +406,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
                                        " needs conan_streams_reset(CONAN_MODEL_HIFIGAN) before every vocoder step (whole-utterance or windowed forward only)");
     voc_fresh[h_slots[i]] = 0;
   }
+  if (voc_chain) { chain_step(n, frames, mel_dev, wav_out, pre_tanh, st, taps); return; }      // small stream-sets: the whole step in one persistent launch
   {  // mel chunk -> ring (conv_pre needs 6 frames of left context)
     cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.x = ch::lin_ref(const_cast<float*>(mel_dev), frames, c.num_mels); ca.y = v_mel.ref();

@@ -132,6 +132,7 @@ class AudioGatherRing:
         else:
             self.comm = _HostStream()
             self.done = [_HostStream() for _ in range(ngroups)]
+        self.recorded = [False] * ngroups   # done[g] has been recorded at least once (an unrecorded event is no fence)
         self.submitted = 0            # gathers enqueued
         self.last_gathered = None     # last step whose audio has been handed to a gather
         self.last_sent = None         # the local tensor of that gather (a group of step buffers)
@@ -140,7 +141,8 @@ class AudioGatherRing:
     def acquire(self, j, fence=False):
         k = j % self.nb
         first = j % self.every == 0                       # the step that re-opens a group is the one that may collide with its gather
-        pending = self.active and j >= self.nb and first
+        # (a group whose gather was skipped - no submit() for it - has no recorded event: nothing to wait for)
+        pending = self.active and j >= self.nb and first and self.recorded[k // self.every]
         if fence:       # the event recorded right behind the gather that read this group (NOT the side stream's tail: a later gather's
                         # join is already enqueued there, and it waits for the newest step)
             return self.bufs[k], (self.done[k // self.every] if (pending and self.cuda) else None)
@@ -149,9 +151,13 @@ class AudioGatherRing:
         return self.bufs[k]
 
     def _gather(self, j, join, wait_current):
-        """One collective for the steps self._next .. j (all in one group)."""
+        """One collective for the steps self._next .. j (all in one group).  Only THEIR buffers travel: a flush() in the middle
+        of a group must not read the buffers of the group's later steps, which may be written while the collective runs, and a
+        group's remainder after a flush travels without the buffers the flush already sent."""
         g = (j % self.nb) // self.every
-        grp = self.pool[g * self.every:(g + 1) * self.every]
+        lo, hi = max(0, self._next - (j - j % self.every)), j % self.every + 1
+        grp = self.pool[g * self.every + lo:g * self.every + hi]
+        dst = None if self._g is None else [b[lo:hi] for b in self._g]
         cur = torch.cuda.current_stream() if self.cuda else None
         ctxm = torch.cuda.stream(self.comm) if self.cuda else self.comm
         with ctxm:
@@ -159,12 +165,15 @@ class AudioGatherRing:
                 self.comm.wait_stream(cur)
             if join is not None:
                 join()
-            out = gather_audio_equal(grp, self.world, self.rank, self._g)
+            out = gather_audio_equal(grp, self.world, self.rank, dst)
             if self.on_gathered is not None and self.rank == 0:
                 src = out if self.world > 1 else [grp]
                 for js in range(self._next, j + 1):
-                    self.on_gathered(js, [b[js % self.every] for b in src])
+                    self.on_gathered(js, [b[js % self.every - lo] for b in src])
             self.done[g].record(self.comm) if self.cuda else None
+            self.recorded[g] = True
+        if dst is not None:
+            self.gbufs = [b[0] if self.every == 1 else b for b in dst]        # what rank 0 gathered last, per rank
         self.submitted += 1
         self.last_gathered, self.last_sent, self._next = j, grp, j + 1
 

@@ -105,6 +105,64 @@ def test_bench_gather_choreography(world, every):
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
+def _midflush_worker(rank, world, port, q):
+    """A flush() in the MIDDLE of a group, the run then continues: the flush must send only the steps that have
+    run - the group's later buffers may be written while the collective reads - and the group's remainder must travel without
+    the steps the flush already delivered.  Step j of rank r writes 1000 r + j; the buffers of steps that have not run hold -1."""
+    from conan_amd.engine import AudioGatherRing
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen, sizes = [], []
+
+    def on_gathered(j, bufs):
+        seen.append((j, [float(b[0, 0]) for b in bufs]))
+
+    ring = AudioGatherRing(lambda: torch.zeros(3, 16), world, rank, on_gathered=on_gathered, every=4)
+    ring.pool.fill_(-1.0)
+    steps = 14
+    for j in range(steps):
+        buf, fence = ring.acquire(j, fence=True)
+        assert fence is None
+        buf.fill_(1000.0 * rank + j)
+        ring.submit(j)
+        if j in (1, 9):                       # mid-group flushes (steps 0-1 and 8-9 travel early)
+            ring.flush(j)
+            sizes.append(tuple(ring.last_sent.shape))
+            assert float(ring.last_sent.min()) >= 0.0      # nothing of a step that has not run
+    ring.flush(steps - 1)
+    ring.drain()
+    dist.barrier()
+    dist.destroy_process_group()
+    ok = sizes == [(2, 3, 16), (2, 3, 16)] and ring.submitted == 6 and ring.last_gathered == steps - 1
+    if rank == 0:
+        ok = ok and [s[0] for s in seen] == list(range(steps)) and all(v == [1000.0 * r + j for r in range(world)] for j, v in seen)
+    q.put((rank, bool(ok)))
+
+
+def test_gather_ring_flush_inside_a_group_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_midflush_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gather_ring_fence_only_for_recorded_groups():
+    """acquire(fence=True) must not hand out the event of a group whose gather never ran (submit() skipped): an unrecorded
+    event is a null handle for conan_streams_output_fence_event."""
+    from conan_amd.engine import AudioGatherRing
+    ring = AudioGatherRing(lambda: torch.zeros(2, 8), 1, 0, always=True, every=4)
+    for j in range(12):
+        buf, fence = ring.acquire(j, fence=True)          # no submit() at all
+        assert fence is None
+    assert ring.recorded == [False, False]
+
+
 def _check_worker(rank, world, port, q):
     """bench.py's rank bookkeeping on a host group: per-rank clocks and devices by all_gather, and the check that what
     rank 0 gathered for the last step is what every rank produced (integer checksums of the fp32 bit patterns)."""
