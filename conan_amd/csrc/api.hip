@@ -165,6 +165,8 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
       { const char* e = getenv("CONAN_FRONT_CUSTRIDE"); if (e && atoi(e) >= 2) s->use_mega = false; }
       { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
+      s->mega_x = reinterpret_cast<unsigned*>(s->alloc(256));
+      { const char* e = getenv("CONAN_MEGA_SINGLE"); if (e && e[0] == '0') s->mega_single = false; }
       {  // guard block of the bounded waits: [0] code, [2..3] device address of the host-mapped copy
         HIP_CHECK(hipHostMalloc((void**)&s->h_guard, 64, hipHostMallocMapped));
         memset(s->h_guard, 0, 64);

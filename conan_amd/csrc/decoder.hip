@@ -74,6 +74,9 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
     }
     std::vector<cnk::MegaOp> ops;
     mega_rec = &ops; mega_rec_ok = true; mega_rec_lds = 0; mega_rec_flops = 0.0;
+    // members a fused feed-forward's hidden columns are split over: the group's workgroups, or - a single row tile, whose group forms
+    // at run time (xcd mode) - one virtual member per 64 hidden columns
+    mega_ffn_gs = n * T <= 16 ? std::max(1, (int)ctx->conv("conan.align.0.ff1").Cout / 64) : mega_gs;
     try {
       if (ex.codes_dst) {      // the caller's copy of the step's codes: independent of everything else
         cnk::MegaOp op; memset(&op, 0, sizeof(op));
@@ -110,14 +113,20 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
       }
       const int njobs = (n * T + 15) / 16;
       e->njobs = njobs; e->kw4 = 0; e->n = n; e->T = T;
-      if (njobs == 1) { e->groups = 1; e->group_size = std::max(1, std::min(mega_grid, maxs)); }
+      // A single tile (<= 16 rows: one to four streams): xcd mode - one workgroup per CU is launched (enough dynamic LDS that two do
+      // not share a CU), the ~32 that land on workgroup 0's XCD walk the program as ONE group whose hand-offs stay in that XCD's L2
+      // (plain stores, L1-bypassing loads, flag barriers: ~1 us per operator instead of ~5 through memory), the others leave at once.
+      e->xcd = njobs == 1;
+      if (njobs == 1) { e->groups = 1; e->group_size = ctx->num_cu; }
       else { e->group_size = mega_gs; e->groups = std::max(1, std::min(njobs, mega_grid / mega_gs)); }
       e->nops = (int)ops.size(); e->barriers = nb; e->flops = mega_rec_flops;
-      e->lds_bytes = mega_rec_lds * 4;
+      e->lds_bytes = e->xcd ? std::max(mega_rec_lds * 4, 84 * 1024) : mega_rec_lds * 4;
       // the arrival-counter barriers need every workgroup of the grid resident at once: never launch more than the device can hold
       // (a quarter of the CUs is kept as margin for what else is resident); such a step keeps its separate launches
       const long long cap = (long long)cnk::decoder_mega_blocks_per_cu(e->lds_bytes, rb_limb) * (ctx->num_cu - ctx->num_cu / 4);
-      if ((long long)e->groups * e->group_size > cap) e->ok = false;
+      // (xcd mode: only the elected XCD's workgroups stay, the others leave at once - nothing waits for the whole grid to be resident)
+      if (!e->xcd && (long long)e->groups * e->group_size > cap) e->ok = false;
+      if (e->xcd && e->lds_bytes > 126 * 1024) e->ok = false;
     }
     if (e->ok) {
       HIP_CHECK(hipEventSynchronize(e->copied));            // (the entry's previous upload, if any, has long completed)
@@ -140,10 +149,10 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   DecExtra ex; if (extra) ex = *extra;
   // (a job is a 16-row tile taken through the whole operator list by its own group of workgroups: a stream's frames of the
   // step must all fall into one tile - 16 % frames == 0, or a single tile in all)
-  // A single tile (<= 4 streams) keeps the separate launches: its operators are latency chains that 128 workgroups cannot
-  // shorten, and a grid-wide barrier per operator costs what the launch boundaries do (0.47 against 0.39 ms at one stream).
-  static const bool mega_single = getenv("CONAN_MEGA_SINGLE") != nullptr;
-  const bool tiles_ok = (16 % T == 0 && n * T > 16) || (n * T <= 16 && mega_single);
+  // A single tile (<= 4 streams): round 3 kept the separate launches for it - a grid-wide barrier through memory per operator cost
+  // what the launch boundaries do (0.47 against 0.39 ms at one stream).  Round 5: such steps run the persistent launch in xcd mode
+  // (run_mega), whose barriers and hand-offs stay inside one XCD's L2; mega_single (conan_streams_opts / CONAN_MEGA_SINGLE=0) turns it off.
+  const bool tiles_ok = (16 % T == 0 && n * T > 16) || (n * T <= 16 && T >= 2 && mega_single);
   // (the per-op Emformer plan - memory bank, shapes the fused step does not cover - is ~90 launches whose conv_mfma workgroups
   // need CUs of their own: beside 128 resident decoder workgroups they queue, b128s2mem4 2.13 against 2.00 ms per step)
   const bool emf_ok = !(ctx->cfg.models & CONAN_MODEL_EMFORMER) || emf_fused;
@@ -199,7 +208,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
   bool ffn_parts = false;
   const long long part_stride = (long long)max_slots * max_frames * H;
   auto x_parts = [&](auto& a, const PackedConv& ff2) {
-    a.xp = c_part.base; a.xp_stride = part_stride; a.xparts = mega_gs; a.xp_ld = H; a.xbias = ff2.bias; a.xres = c_a2.ref(); a.has_xres = 1;
+    a.xp = c_part.base; a.xp_stride = part_stride; a.xparts = mega_ffn_gs; a.xp_ld = H; a.xbias = ff2.bias; a.xres = c_a2.ref(); a.has_xres = 1;
   };
   for (int l = 0; l < 2; ++l) {
     const std::string nm = "conan.align." + std::to_string(l);
@@ -221,8 +230,9 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
     ffn_parts = false;
     {
       const PackedConv &f1 = ctx->conv(nm + ".ff1"), &f2 = ctx->conv(nm + ".ff2");
-      if (mega_rec && ffn_fuse_on && n * T > 16 && rowconv_ok(f1, 1, T) && f2.wf && f1.k == 1 && f2.k == 1 && f1.Cout % (64 * mega_gs) == 0 && f1.Cout / mega_gs <= 256 &&
-          f2.Cin == f1.Cout && f2.Cout == H && H % 64 == 0) {
+      // (a single row tile - xcd mode, decoder_mega.hip - splits the hidden columns over Cout / 64 virtual members: mega_ffn_gs)
+      if (mega_rec && ffn_fuse_on && rowconv_ok(f1, 1, T) && f2.wf && f1.k == 1 && f2.k == 1 && f1.Cout % (64 * mega_ffn_gs) == 0 && f1.Cout / mega_ffn_gs <= 256 &&
+          (n * T > 16 || f1.Cout / mega_ffn_gs == 64) && mega_ffn_gs <= 32 && f2.Cin == f1.Cout && f2.Cout == H && H % 64 == 0) {
         cnk::RowConvArgs a = mk_rc(f1, c_a1.ref(), c_ff.ref(), n, T);
         a.ln = 1; a.hist = c_a2.ref(); a.gamma = ctx->vec(nm + ".norm1.g"); a.beta = ctx->vec(nm + ".norm1.b");
         a.out_act = cnk::ACT_RELU;

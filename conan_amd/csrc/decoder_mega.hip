@@ -53,6 +53,17 @@ __device__ __forceinline__ T mg_args(const void* p) {
   return u.v;
 }
 
+// The operators read their arguments through the scalar cache, and every operator's block is cold the first time it is touched: a
+// chain of 4-5 dependent misses (~0.4 us each) at the head of every operator.  One scalar load per 64-byte line of the NEXT operator's
+// block, issued in front of the barrier that ends this one, takes them off the critical path.
+__device__ __forceinline__ void mg_prefetch_args(const MegaOp* op) {
+  mg_cci p = (mg_cci)(op);
+  int x = 0;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(MegaOp) / 4); i += 16) x ^= p[i];
+  asm volatile("" ::"s"(x));
+}
+
 // arrival counter + sc1 polling; `target` is the count at which every participant has arrived
 __device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target, unsigned* guard) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's (write-through) stores have left ...
@@ -68,24 +79,92 @@ __device__ __forceinline__ void mg_barrier(unsigned* ctr, const unsigned target,
   __syncthreads();
 }
 
+// xcd mode (CM = 2): every participant sits on ONE XCD, whose L2 is the point of coherence.  Atomics would still execute at the memory
+// side (a fabric round trip each); flags do not: member `rank` stores the barrier's epoch into its own word of one 128-byte line
+// (plain store -> L2), wave 0 of every member polls all P words with L1-bypassing loads (L2 hits) until none is older.  Epochs grow
+// from launch to launch (the host passes the launch's base), nothing is ever cleared.
+__device__ __forceinline__ void mg_barrier_xcd(unsigned* flags, const unsigned epoch, const int rank, const int P, unsigned* guard) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's stores have reached the L2 ...
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    typedef unsigned __attribute__((address_space(1)))* gu32;
+    if (threadIdx.x == 0) *(volatile gu32)(flags + rank) = epoch;      // ... before the member's flag
+    const int lane = threadIdx.x;
+    SpinGuard sg;
+    for (;;) {
+      const unsigned v = lane < P ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+      if (__all((int)(v - epoch) >= 0)) break;
+      if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;
+    }
+  }
+  __syncthreads();
+}
+
 // gbar: one arrival counter per group, 64 bytes apart (zero at launch, zeroed again by the kernel); bar: the grid's (counts for ever)
 // OCC = waves per SIMD the register allocation is bounded for: 6 (80 registers: a wave fits beside two waves of every vocoder
 // kernel, the f32 ResBlock passes' 216 included; the operators' bodies then spill ~35 registers to scratch - reloaded once per
 // operator, outside the K loops) for exact-f32 stream-sets; 4 (128 registers, no spills) for bf16-limb stream-sets, whose
 // resident kernels (resblock_limb <= 192, conv_limb's streaming shapes <= 192) leave 2 x 192 + 128 = 512 - tests/test_kernel_resources.py.
-template <int OCC>
-__global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS,
+// CM = 2 (xcd mode, a single row tile in the step): the launch is one workgroup per CU; the workgroups that find themselves on the
+// XCD of workgroup 0 (HW_REG_XCC_ID - read, not assumed) form the ONE group that walks the program, the others leave at once.
+// xs: [0] elected XCD (launch sequence << 8 | xcc + 1), [16] participants' rank counter (zero between launches), [32] "decided"
+// counter (counts for ever; xdec_base = its value before this launch), [64 ..) the barrier flags.
+template <int OCC, int CM>
+__global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS_,
                                                               const int* __restrict__ slots, const int* __restrict__ pos, const int n, const int T,
                                                               unsigned* __restrict__ gbar, unsigned* __restrict__ bar, const unsigned bar_base,
-                                                              unsigned long long* __restrict__ dbg, unsigned* __restrict__ guard) {
+                                                              unsigned long long* __restrict__ dbg, unsigned* __restrict__ guard,
+                                                              unsigned* __restrict__ xs, const unsigned xseq, const unsigned xdec_base) {
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   ro::RowTab& tab = *reinterpret_cast<ro::RowTab*>(lds_all);
   float* const lds = lds_all + ro::ROWTAB_FLOATS;
-  const int b = (int)blockIdx.x;
+  int b = (int)blockIdx.x;
 #ifdef MG_PRIO
   __builtin_amdgcn_s_setprio(MG_PRIO);      // developer build
 #endif
-  const int NG = (int)gridDim.x / GS, g = b / GS, sb = b - g * GS;      // groups, this workgroup's group and member index
+  int GS = GS_;
+  unsigned xepoch = xseq << 8;
+  if constexpr (CM == 2) {
+    int* const sh = reinterpret_cast<int*>(lds_all);
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
+      if (b == 0) __hip_atomic_store(xs, (xseq << 8) | (xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned v;
+      SpinGuard sg;
+      while (((v = __hip_atomic_load(xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != xseq) {
+        __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
+        if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;
+      }
+      const bool mine = ((v & 255u) - 1u) == xcc && (v >> 8) == xseq;
+      int rank = -1;
+      if (mine) rank = (int)__hip_atomic_fetch_add(xs + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the rank is taken before this workgroup counts as decided)
+      __hip_atomic_fetch_add(xs + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int P = 0;
+      if (mine) {
+        while ((int)(__hip_atomic_load(xs + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (xdec_base + gridDim.x)) < 0) {
+          __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
+          if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;
+        }
+        P = (int)__hip_atomic_load(xs + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sh[0] = rank; sh[1] = P;
+    }
+    __syncthreads();
+    const int rank = sh[0], P = sh[1];
+    __syncthreads();
+    if (rank < 0 || P <= 0) return;
+    b = rank; GS = P < 64 ? P : 64;
+    if (rank >= GS) return;                  // (never with one workgroup per CU: an XCD has 32)
+    {   // pull the program into this XCD's L2 (the operators read their arguments through the scalar cache where they use them: the
+        // first touch of every operator's block would otherwise be a chain of misses to memory)
+      const int words = nops * (int)(sizeof(MegaOp) / 4);
+      float keep = 0.f;
+      for (int e = (b * 256 + (int)threadIdx.x) * 32; e < words; e += GS * 256 * 32) keep += ro::ldw1(reinterpret_cast<const float*>(prog) + e);
+      ro::mg_keep(keep);
+    }
+  }
+  const int NG = CM == 2 ? 1 : (int)gridDim.x / GS, g = b / GS, sb = b - g * GS;      // groups, this workgroup's group and member index
   // developer stamps (CONAN_MEGA_STAMPS=1): workgroup 0 notes the 100 MHz clock at the start and behind every operator (+ barrier)
   if (dbg && b == 0 && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
   unsigned gtarget = 0;
@@ -104,9 +183,9 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           if (sb < nbx) {      // (members without a strip skip the gather as well)
             float4 bw[8];
             const float warm = ro::mg_wwarm<1>(a, sb);
-            ro::mg_stage<(OCC < 6)>(a, tab, lds, sb, nbx < GS ? nbx : GS);
+            ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
             ro::mg_keep(warm);
-            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<1, false>(a, tab, bx, lds, bw);
+            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<1, false, CM, (OCC < 6)>(a, tab, bx, lds, bw);
           }
         } break;
         case MOP_RC114: {      // 16-column strips, K split over the waves (a single tile in the step)
@@ -114,51 +193,69 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           if (sb < nbx) {
             float4 bw[4];
             const float warm = ro::mg_wwarm<4>(a, sb);
-            ro::mg_stage<(OCC < 6)>(a, tab, lds, sb, nbx < GS ? nbx : GS);
+            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+            ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, nbx < GS ? nbx : GS, (dbg && b == 0) ? dbg + 512 + o * 4 : nullptr);
             ro::mg_keep(warm);
-            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4, false>(a, tab, bx, lds, bw);
+            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4, false, CM, (OCC < 6)>(a, tab, bx, lds, bw);
+            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 2] = __builtin_amdgcn_s_memrealtime();
           }
         } break;
         case MOP_FFN: {        // LayerNorm -> 1x1 -> activation -> 1x1 partial sums, the hidden columns split over the members
           const auto& a = MG_AS4(RowConvArgs, &op->u);
-          ro::mg_stage<(OCC < 6)>(a, tab, lds, sb, GS);
-          ro::mg_ffn<(OCC < 6)>(a, tab, sb, GS, lds);
+          if constexpr (CM == 2) {
+            // xcd mode: the group's size is only known at run time - the hidden columns are split over Cout / 64 VIRTUAL members
+            // (one 64-column strip each: 32 for the aligner's 2048-wide feed-forward), dealt to the workgroups that are there
+            const int VG = a.Cout >> 6;
+            for (int v = sb; v < VG; v += GS) {
+              ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, GS);
+              ro::mg_ffn<(OCC < 6), CM>(a, tab, v, VG, lds);
+            }
+          } else {
+            ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, GS);
+            ro::mg_ffn<(OCC < 6), CM>(a, tab, sb, GS, lds);
+          }
         } break;
         case MOP_ROWLIN: {
           const auto& a = MG_AS4(RowConvArgs, &op->u);
-          for (int bx = sb; bx < nbx; bx += GS) ro::mg_rowlin_strip(a, tab, bx, lds);
+          for (int bx = sb; bx < nbx; bx += GS) ro::mg_rowlin_strip<CM>(a, tab, bx, lds);
         } break;
         case MOP_LN: {
           const auto& a = MG_AS4(LNArgs, &op->u);
-          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_layernorm_row(a, tab, r);      // 16 rows over GS members x 4 waves
+          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_layernorm_row<CM>(a, tab, r);      // 16 rows over GS members x 4 waves
         } break;
         case MOP_XATTN: {
           const auto& a = MG_AS4(XAttnArgs, &op->u);
-          for (int r0 = sb * 2; r0 < ro::RC_TM; r0 += GS * 2) { __syncthreads(); ro::mg_xattn_rows(a, tab, r0, lds); }
+          for (int r0 = sb * 2; r0 < ro::RC_TM; r0 += GS * 2) { __syncthreads(); ro::mg_xattn_rows<CM>(a, tab, r0, lds); }
         } break;
         case MOP_PITCH: {
           const auto& a = MG_AS4(PitchHeadArgs, &op->u);
           const float f0 = __int_as_float(hdr[4]), f1 = __int_as_float(hdr[5]);
-          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_pitch_row(a, tab, f0, f1, r);
+          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_pitch_row<CM>(a, tab, f0, f1, r);
         } break;
         case MOP_EMBED: {
           const auto& a = MG_AS4(EmbedArgs, &op->u);
-          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_embed_row(a, tab, r);
+          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_embed_row<CM>(a, tab, r);
         } break;
         case MOP_COPY32: {
           if (job == g) {         // once per launch: spread over the grid
             const MegaCopy a = mg_args<MegaCopy>(&op->u);
-            for (long long e = (long long)b * 256 + threadIdx.x; e < a.n; e += (long long)gridDim.x * 256) a.dst[e] = a.src[e];
+            for (long long e = (long long)b * 256 + threadIdx.x; e < a.n; e += (long long)(CM == 2 ? GS : (int)gridDim.x) * 256) a.dst[e] = a.src[e];
           }
         } break;
         default: break;           // (MOP_ADVANCE: behind the grid barrier below)
       }
-      if (barrier && type != MOP_ADVANCE) { gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget, guard); }
+      if (o + 1 < nops) mg_prefetch_args(prog + o + 1);
+      if (barrier && type != MOP_ADVANCE) {
+        if constexpr (CM == 2) mg_barrier_xcd(xs + 64, ++xepoch, sb, GS, guard);
+        else { gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget, guard); }
+      }
       if (dbg && b == 0 && threadIdx.x == 0 && job == g) dbg[1 + o] = __builtin_amdgcn_s_memrealtime();
     }
   }
   // every job is done: advance the frame counters (the operators above read them), re-arm the group counters
-  mg_barrier(bar, bar_base + (unsigned)gridDim.x, guard);
+  if constexpr (CM == 2) mg_barrier_xcd(xs + 64, ++xepoch, sb, GS, guard);
+  else mg_barrier(bar, bar_base + (unsigned)gridDim.x, guard);
   if (b == 0) {
     for (int o = 0; o < nops; ++o) {
       mg_cci hdr = (mg_cci)(prog + o);
@@ -167,7 +264,8 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
         for (int q = threadIdx.x; q < a.n; q += 256) a.pos[a.slots ? a.slots[q] : q] += a.delta;
       }
     }
-    for (int q = threadIdx.x; q < NG; q += 256) __hip_atomic_store(gbar + q * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (CM == 2) { if (threadIdx.x == 0) __hip_atomic_store(xs + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (every participant holds its rank by now)
+    else for (int q = threadIdx.x; q < NG; q += 256) __hip_atomic_store(gbar + q * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (dbg && b == 0 && threadIdx.x == 0) dbg[1 + nops] = __builtin_amdgcn_s_memrealtime();
 }
@@ -183,19 +281,24 @@ int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats) {
 // workgroups of the megakernel that one CU can hold at once with `lds_bytes` of dynamic LDS (its barriers need the whole grid resident)
 int decoder_mega_blocks_per_cu(int lds_bytes, bool wide_regs) {
   int nb = 0;
-  const hipError_t e = wide_regs ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<4>, 256, (size_t)lds_bytes)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<6>, 256, (size_t)lds_bytes);
+  const hipError_t e = wide_regs ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<4, 1>, 256, (size_t)lds_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<6, 1>, 256, (size_t)lds_bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nb;
 }
 
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st) {
-  if (m.wide_regs)
-    hipLaunchKernelGGL(decoder_mega_kernel<4>, dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard);
+  if (m.xcd) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_mega_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+    hipLaunchKernelGGL((decoder_mega_kernel<4, 2>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, m.xdec_base);
+  } else if (m.wide_regs)
+    hipLaunchKernelGGL((decoder_mega_kernel<4, 1>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, nullptr, 0u, 0u);
   else
-    hipLaunchKernelGGL(decoder_mega_kernel<6>, dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard);
+    hipLaunchKernelGGL((decoder_mega_kernel<6, 1>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, nullptr, 0u, 0u);
 }
 
 }  // namespace cnk

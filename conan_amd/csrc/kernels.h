@@ -443,6 +443,8 @@ struct MegaLaunch {
   unsigned* gbar; unsigned* bar; unsigned bar_base; unsigned long long* dbg;
   unsigned* guard;        // SpinGuard block of the stream-set (nullptr: unbounded waits)
   int wide_regs;          // 1: the 128-register build (bf16-limb stream-sets), 0: the 80-register build
+  // xcd mode (a single row tile in the step): one workgroup per CU is launched, those on workgroup 0's XCD form the one group
+  int xcd; unsigned* xs; unsigned xseq, xdec_base;
 };
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st);
 
@@ -492,6 +494,7 @@ struct VCLaunch {
   unsigned* bar;                            // (VC_MAX_PHASES + 1) arrival counters, 16 words apart, zero before the first launch
   unsigned* guard;
   VCIO io;
+  unsigned long long* dbg;                  // developer stamps (CONAN_VC_STAMPS=1): [VC_MAX_PHASES][4] + 2, zero before the launch
 };
 void launch_voc_chain(const VCLaunch& l, hipStream_t st);
 int voc_chain_max_grid(int lds_bytes, int num_cu);     // workgroups that can be resident at once

@@ -10,6 +10,8 @@
 //     tools/experiments/uncached_barrier.hip).  Weights, per-utterance caches and the frame counters are read-only inside a
 //     launch and stay plain.
 #pragma once
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace cnk {
@@ -23,11 +25,13 @@ typedef float __attribute__((address_space(1)))* gf1;
 typedef const int __attribute__((address_space(1)))* gci;
 typedef unsigned long long u64;
 
-// activation accesses: plain (stand-alone kernels) or agent-scope (megakernel: write-through stores, L1-bypassing loads)
+// activation accesses: COH = 0 plain (stand-alone kernels); 1 agent-scope (megakernel: write-through stores, L1-bypassing loads);
+// 2 the megakernel with every workgroup on ONE XCD (decoder_mega.hip, xcd mode): that XCD's L2 is the point of coherence, so stores
+// are plain (L1 writes through to L2, the line stays there) and only the loads bypass the reading CU's L1 (sc1: L2-served)
 typedef const u64 __attribute__((address_space(1)))* gcu64;
 typedef u64 __attribute__((address_space(1)))* gu64;
-template <bool COH> __device__ __forceinline__ float4 ld4(const float* p) {
-  if constexpr (COH) {
+template <int COH> __device__ __forceinline__ float4 ld4(const float* p) {
+  if constexpr (COH != 0) {
     const u64 a = __hip_atomic_load((gcu64)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u64 b = __hip_atomic_load((gcu64)(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
@@ -36,20 +40,20 @@ template <bool COH> __device__ __forceinline__ float4 ld4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
   }
 }
-template <bool COH> __device__ __forceinline__ float ld1(const float* p) {
-  if constexpr (COH) return __hip_atomic_load((gcf1)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <int COH> __device__ __forceinline__ float ld1(const float* p) {
+  if constexpr (COH != 0) return __hip_atomic_load((gcf1)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else return *(gcf1)(p);
 }
-template <bool COH> __device__ __forceinline__ void st4(float* p, const float4 v) {
-  if constexpr (COH) {
+template <int COH> __device__ __forceinline__ void st4(float* p, const float4 v) {
+  if constexpr (COH == 1) {
     __hip_atomic_store((gu64)(p), (u64)__float_as_uint(v.x) | ((u64)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((gu64)(p) + 1, (u64)__float_as_uint(v.z) | ((u64)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     *(gf4)(p) = (f32x4){v.x, v.y, v.z, v.w};
   }
 }
-template <bool COH> __device__ __forceinline__ void st1(float* p, const float v) {
-  if constexpr (COH) __hip_atomic_store((gf1)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <int COH> __device__ __forceinline__ void st1(float* p, const float v) {
+  if constexpr (COH == 1) __hip_atomic_store((gf1)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *(gf1)(p) = v;
 }
 // read-only data (weights, biases, per-utterance caches, slot tables, frame counters)
@@ -640,18 +644,35 @@ __device__ __forceinline__ RowId row_id(const RowTab& tb, const int r) {
   return RowId{tb.seg_i[s], tb.seg_t0[s] + (r - tb.seg_r0[s]), tb.seg_slot[s], tb.seg_pos[s]};
 }
 
+// A copy of an argument sub-struct out of the program (constant address space) - ONE clause of scalar loads.  The operators used to
+// read every field where they used it: the compiler then emits one scalar load + s_waitcnt per use, in front of branches - the window
+// gather of a 256 -> 256 1x1 conv was a chain of 21 dependent scalar / LDS round trips (2.5 us) in front of its single load per thread.
+template <class T, class S>
+__device__ __forceinline__ T as_copy(const S& src) {
+  static_assert(sizeof(T) % 4 == 0 && sizeof(T) == sizeof(S), "argument structs are made of 32-bit words");
+  union U { T v; int w[sizeof(T) / 4]; __device__ U() {} } u;
+  const int __attribute__((address_space(4)))* p = (const int __attribute__((address_space(4)))*)(&src);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) u.w[i] = p[i];
+  return u.v;
+}
+
 // gather the tile's input window of operator `a` into LDS (win = lds: [wr_max][Cin + 8]), LayerNorm of the new rows in place;
 // `first` (the member that owns strip 0) appends the normalised rows to the layer's ring and writes the block mask
 // (sb of nact: this member's index among the members that stage this operator - the normalised rows they all compute are
 // appended to the layer's ring / the block mask is written by member row % nact, so that no single member carries the stores)
-template <bool WIDE = false, class A>
-__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const int sb, const int nact) {
+template <bool WIDE = false, int CM = 1, class A>
+__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const int sb, const int nact, unsigned long long* dbgp = nullptr) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));             // (no hoisting of per-lane arithmetic out of this function: the 80-register bound is tight)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Cin = a.Cin, LDX = Cin + 8, C4 = Cin >> 2;
   const int k = a.ktaps, d = a.dil, halo = (k - 1) * d;
+  // (every argument the gather needs, in one batch of scalar loads)
+  const TRef X = as_copy<TRef>(a.x), HS = as_copy<TRef>(a.hist);
+  const int a_ln = a.ln, a_xparts = a.xparts, a_in_lrelu = a.in_lrelu;
+  const float a_in_slope = a.in_slope;
   __syncthreads();                          // every wave is done with the previous operator's window
   if (tid < RC_TM) tb.tab[tid] = tid < tb.nvalid ? tid + tb.row_seg[tid] * halo : 0;
   const int WR = tb.nvalid + tb.nseg * halo;
@@ -661,36 +682,48 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
     for (int q = 1; q < RC_MAXSEG; ++q) s += (w >= tb.seg_r0[q] + q * halo) ? 1 : 0;      // seg_r0 of unused segments is huge
     return s;
   };
-  const int total = WR * C4;
-  constexpr int GB = 8;                                  // 16-byte loads per thread in flight: the whole 32-row window of a k = 5 layer in one round trip
-  for (int e0 = 0; e0 < total; e0 += 256 * GB) {
-    float4 v[GB];
+  // Gather: 8 threads per window row, 32 rows per pass - a thread works out ITS row's source once (segment, time, ring row) and
+  // then fetches the row's 16-byte columns j, j + 8, .. (8 threads = one 128-byte line per step); every load of a pass is in
+  // flight before the first is consumed.  (Round 4 worked the source out per 16-byte element: ~8 x the address arithmetic, with
+  // the segment table's LDS reads in front of every load - 3.7 us of an operator's 7 at one stream.)
+  constexpr int TPR = 8;
+  const int wsub = tid >> 3, j8 = tid & 7;
+  const int nld_all = C4 >> 3;                           // loads per thread and row: 2, 4, 8 or 16 (Cin = 64 .. 512), at most 8 at a time
+  // (the loads of a pass are UNCONDITIONAL, straight-line code: rows beyond the window / rows that come from partial tensors fetch a
+  // valid row and drop it.  Behind a branch or an exec mask hipcc waits for every earlier load before it issues the next pair - 16
+  // serialised L2 round trips, 1.8 us, for a 256-channel row)
+  auto pass = [&](auto nld_c, const int w0, const int u0) __attribute__((always_inline)) {
+    constexpr int NLD = decltype(nld_c)::value;
+    const int w = w0 + wsub;
+    const bool inw = w < WR;
+    const int wc = inw ? w : 0;
+    const int sg = wseg(wc);
+    const int tau = tb.seg_t0[sg] - halo + (wc - (tb.seg_r0[sg] + sg * halo));   // time index within this step (negative: earlier steps)
+    const bool part = a_xparts > 0 && tau >= 0;          // (summed from the partial tensors below)
+    const int s_i = tb.seg_i[sg], s_slot = tb.seg_slot[sg], s_pos = tb.seg_pos[sg];
+    const float* const src_x = row(X, s_i, s_slot, s_pos, tau);
+    const float* const src_h = row(HS, s_i, s_slot, s_pos, tau);
+    const float* src = ((a_ln && tau < 0) ? src_h : src_x) + (j8 + 8 * u0) * 4;      // (ln: rows of earlier steps come out of the layer's ring normalised)
+    float4 v[NLD];
 #pragma unroll
-    for (int u = 0; u < GB; ++u) {
-      const int e = e0 + tid + 256 * u;
-      const int w = e < total ? e / C4 : 0, c4 = e < total ? e - w * C4 : 0;
-      const int sg = wseg(w);
-      const int tau = tb.seg_t0[sg] - halo + (w - (tb.seg_r0[sg] + sg * halo));   // time index within this step (negative: earlier steps)
-      if (a.xparts > 0 && tau >= 0) { v[u] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // (summed from the partial tensors below)
-      const float* src = (a.ln && tau >= 0) ? row(a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau)
-                                            : row(a.ln ? a.hist : a.x, tb.seg_i[sg], tb.seg_slot[sg], tb.seg_pos[sg], tau);
-      v[u] = ld4<true>(src + c4 * 4);
-    }
-    const float isl = a.in_lrelu ? a.in_slope : 1.0f;
+    for (int u = 0; u < NLD; ++u) v[u] = ld4<CM>(src + 32 * u);
+    const float isl = a_in_lrelu ? a_in_slope : 1.0f;
+    float* const dst = win + wc * LDX + (j8 + 8 * u0) * 4;
+    if (inw && !part) {
 #pragma unroll
-    for (int u = 0; u < GB; ++u) {
-      const int e = e0 + tid + 256 * u;
-      float4 q = v[u];
-      q.x *= q.x > 0.f ? 1.0f : isl; q.y *= q.y > 0.f ? 1.0f : isl; q.z *= q.z > 0.f ? 1.0f : isl; q.w *= q.w > 0.f ? 1.0f : isl;
-      if (e < total) {
-        const int w = e / C4, c4 = e - w * C4;
-        bool part = false;
-        if (a.xparts > 0) { const int sg = wseg(w); part = tb.seg_t0[sg] - halo + (w - (tb.seg_r0[sg] + sg * halo)) >= 0; }
-        if (!part) *reinterpret_cast<float4*>(win + w * LDX + c4 * 4) = q;
+      for (int u = 0; u < NLD; ++u) {
+        float4 q = v[u];
+        q.x *= q.x > 0.f ? 1.0f : isl; q.y *= q.y > 0.f ? 1.0f : isl; q.z *= q.z > 0.f ? 1.0f : isl; q.w *= q.w > 0.f ? 1.0f : isl;
+        *reinterpret_cast<float4*>(dst + 32 * u) = q;
       }
     }
+  };
+  for (int w0 = 0; w0 < WR; w0 += 256 / TPR) {
+    if (nld_all >= 8) { for (int u0 = 0; u0 < nld_all; u0 += 8) pass(std::integral_constant<int, 8>{}, w0, u0); }
+    else if (nld_all == 4) pass(std::integral_constant<int, 4>{}, w0, 0);
+    else pass(std::integral_constant<int, 2>{}, w0, 0);
   }
-  if (a.xparts > 0) {
+  if (a_xparts > 0) {
     // the NEW rows of x are the sum of the group members' partial tensors (+ bias, + residual, x masks), summed in member order.
     // Every load of a 16-byte column group - its partials, the residual, the masks - is issued before the first is consumed: one
     // L2 round trip per group.
@@ -709,11 +742,11 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
         id[b] = row_id(tb, rr[b]);
         const long long off = (long long)(id[b].i * a.T + id[b].t) * a.xp_ld + cc[b] * 4;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) pv[b][p] = p < a.xparts ? ld4<true>(a.xp + p * a.xp_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        xr[b] = a.has_xres ? ld4<true>(row(a.xres, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < 8; ++p) pv[b][p] = p < a.xparts ? ld4<CM>(a.xp + p * a.xp_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xr[b] = a.has_xres ? ld4<CM>(row(a.xres, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         mk[b] = 1.f;
-        if (a.has_xm1) mk[b] = ld1<true>(row(a.xm1, id[b].i, id[b].slot, id[b].pos, id[b].t));
-        if (a.has_xm2) mk[b] *= ld1<true>(row(a.xm2, id[b].i, id[b].slot, id[b].pos, id[b].t));
+        if (a.has_xm1) mk[b] = ld1<CM>(row(a.xm1, id[b].i, id[b].slot, id[b].pos, id[b].t));
+        if (a.has_xm2) mk[b] *= ld1<CM>(row(a.xm2, id[b].i, id[b].slot, id[b].pos, id[b].t));
       }
 #pragma unroll
       for (int b = 0; b < EB; ++b) {
@@ -721,9 +754,15 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
         float4 acc = pv[b][0];
 #pragma unroll
         for (int p = 1; p < 8; ++p) if (p < a.xparts) { acc.x += pv[b][p].x; acc.y += pv[b][p].y; acc.z += pv[b][p].z; acc.w += pv[b][p].w; }
-        if (a.xparts > 8) {      // (groups of 16 members - developer switch: the second eight, in member order)
+        if (a.xparts > 8) {      // (more than 8 members - 16-member groups, the 32 virtual members of xcd mode: eight at a time, in member order)
           const long long off = (long long)(id[b].i * a.T + id[b].t) * a.xp_ld + cc[b] * 4;
-          for (int p = 8; p < a.xparts; ++p) { const float4 q = ld4<true>(a.xp + p * a.xp_stride + off); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
+          for (int p0 = 8; p0 < a.xparts; p0 += 8) {
+            float4 q8[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) q8[p] = p0 + p < a.xparts ? ld4<CM>(a.xp + (p0 + p) * a.xp_stride + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) if (p0 + p < a.xparts) { acc.x += q8[p].x; acc.y += q8[p].y; acc.z += q8[p].z; acc.w += q8[p].w; }
+          }
         }
         if (a.xbias) { const float4 q = ldw4(a.xbias + cc[b] * 4); acc.x += q.x; acc.y += q.y; acc.z += q.z; acc.w += q.w; }
         if (a.has_xres) { acc.x += xr[b].x; acc.y += xr[b].y; acc.z += xr[b].z; acc.w += xr[b].w; }
@@ -731,15 +770,19 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
         if (e < nq) {
           *reinterpret_cast<float4*>(win + (rr[b] + (tb.row_seg[rr[b]] + 1) * halo) * LDX + cc[b] * 4) = acc;
           // (the tensor itself, for the operator behind this one that adds it as its residual)
-          if (a.xstore && (rr[b] % nact) == sb) st4<true>(row(a.x, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4, acc);
+          if (a.xstore && (rr[b] % nact) == sb) st4<CM>(row(a.x, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4, acc);
         }
       }
     }
   }
   __syncthreads();
-  if (a.ln) {
+  if (a_ln) {
     // only the tile's own rows are new (rows of earlier steps come out of the ring normalised): tile row r = window row tab[r],
     // 16 lanes per row, the 16 rows in one pass over the 4 waves
+    const float* const a_gamma = a.gamma; const float* const a_beta = a.beta;
+    const float a_eps = a.eps;
+    const int a_has_lnmask = a.has_lnmask, a_has_mask_out = a.has_mask_out;
+    const TRef HL = as_copy<TRef>(a.hist);
     const int sub = lane >> 4, l16 = lane & 15;
     const int r = wave * 4 + sub;
     const bool live = r < tb.nvalid;
@@ -765,24 +808,24 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
-    const float rstd = 1.0f / sqrtf(var / (float)Cin + a.eps);
+    const float rstd = 1.0f / sqrtf(var / (float)Cin + a_eps);
     if (live) {
       const bool mine = (r % nact) == sb;
       float mk = 1.f;
-      if (a.has_lnmask) mk = ld1<true>(row(a.lnmask, id.i, id.slot, id.pos, id.t));
-      float* hrow = row(a.hist, id.i, id.slot, id.pos, id.t);
+      if (a_has_lnmask) { const TRef LM = as_copy<TRef>(a.lnmask); mk = ld1<CM>(row(LM, id.i, id.slot, id.pos, id.t)); }
+      float* hrow = row(HL, id.i, id.slot, id.pos, id.t);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int c = (l16 + 16 * q) * 4;
         if (c < Cin) {
-          const float4 g = ldw4(a.gamma + c), bb = ldw4(a.beta + c);
+          const float4 g = ldw4(a_gamma + c), bb = ldw4(a_beta + c);
           const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
                                        ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
           *reinterpret_cast<float4*>(wrow + c) = o;
-          if (mine) st4<true>(hrow + c, o);
+          if (mine) st4<CM>(hrow + c, o);
         }
       }
-      if (a.has_mask_out && mine && l16 == 0) st1<true>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f);
+      if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
     }
     __syncthreads();
   }
@@ -807,7 +850,7 @@ __device__ __forceinline__ float mg_wwarm(const A& a, const int bx) {
   return ct0 * 16 < a.Cout_pad ? ldw1(wl) : 0.f;
 }
 
-template <int KW, bool PRE, class A>
+template <int KW, bool PRE, int CM = 1, bool PF = false, class A>
 __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win, float4 (&bw)[(KW > 1) ? 4 : 8]) {
   constexpr int RC_D = (KW > 1) ? 4 : 8;
   int tid = threadIdx.x;
@@ -825,6 +868,38 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
   const long long ct_stride = (long long)(k + 1) * KQ * 256;
   const float* wl = a.w + (long long)ct0 * ct_stride + lane * 4;
   const bool active = ct0 * 16 < a.Cout_pad;
+  // The MFMAs are issued transposed (weights as the first operand - the register images are the same either way): a lane's
+  // accumulator then holds 4 consecutive output columns (4 lg ..) of ONE row (lr) instead of one column of 4 rows, and the epilogue's
+  // bias / residual / output accesses are 16 bytes wide.  Every output element is the same sequence of multiply-adds as before.
+  const int col0 = ct0 * 16 + 4 * lg;
+  const bool fin = (KW == 1 || wave == 0) && active && col0 < a.Cout && lr < tb.nvalid;      // this lane stores an output
+  const RowId id = row_id(tb, lr < tb.nvalid ? lr : 0);
+  // (the epilogue's arguments in one batch of scalar loads)
+  float* yptr;          // (the output row's address now - two registers across the K loop instead of the tensor's ten)
+  { const TRef Y = as_copy<TRef>(a.y); yptr = row(Y, id.i, id.slot, id.pos, id.t) + col0; }
+  const float* const a_bias = a.bias; const float* const a_bvec = a.bvec;
+  const long long a_bvs = a.bvec_stride;
+  const int a_has_res = a.has_res, a_has_m1 = a.has_m1, a_has_m2 = a.has_m2, a_act = a.out_act;
+  const float a_scale = a.out_scale, a_oslope = a.out_slope;
+  // PF (the 128-register build): the epilogue's operands are requested in front of the K loop
+  float4 pbias = make_float4(0.f, 0.f, 0.f, 0.f), pbv = pbias, pres = pbias;
+  float pm = 1.f;
+  // (unconditional loads - an absent operand reads the head of the weight tensor and is dropped: behind branches hipcc puts a full
+  // s_waitcnt between two loads, three serialised round trips in every epilogue)
+  auto fetch = [&]() __attribute__((always_inline)) {
+    const float* const dummy = a.w;
+    const float* pb = a_bias ? a_bias + col0 : dummy;
+    const float* pv = a_bvec ? a_bvec + (long long)id.slot * a_bvs + col0 : dummy;
+    const float* pr = dummy; const float* p1 = dummy; const float* p2 = dummy;
+    if (a_has_res) { const TRef RS = as_copy<TRef>(a.res); pr = row(RS, id.i, id.slot, id.pos, id.t) + col0; }
+    if (a_has_m1) { const TRef M1 = as_copy<TRef>(a.m1); p1 = row(M1, id.i, id.slot, id.pos, id.t); }
+    if (a_has_m2) { const TRef M2 = as_copy<TRef>(a.m2); p2 = row(M2, id.i, id.slot, id.pos, id.t); }
+    pbias = ldw4(pb); pbv = ldw4(pv); pres = ld4<CM>(pr);
+    const float m1v = ld1<CM>(p1), m2v = ld1<CM>(p2);
+    if (!a_bias) pbias = make_float4(0.f, 0.f, 0.f, 0.f);
+    pm = (a_has_m1 ? m1v : 1.f) * (a_has_m2 ? m2v : 1.f);
+  };
+  if constexpr (PF) { if (fin) fetch(); }
   f32x4 accs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};     // two interleaved chains (rowconv_tile)
   if (active) {
     if constexpr (!PRE) {
@@ -842,48 +917,44 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
         const float4 afn = *reinterpret_cast<const float4*>(abase + (Gn < g_hi ? jn * tstep + qn * 16 : 0));
         f32x4& p = accs[u & 1];
         f32x4& q = accs[(u & 1) ^ 1];
-        p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bw[u].x, p, 0, 0, 0);
-        q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bw[u].y, q, 0, 0, 0);
-        p = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bw[u].z, p, 0, 0, 0);
-        q = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bw[u].w, q, 0, 0, 0);
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u].x, af.x, p, 0, 0, 0);
+        q = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u].y, af.y, q, 0, 0, 0);
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u].z, af.z, p, 0, 0, 0);
+        q = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u].w, af.w, q, 0, 0, 0);
         bw[u] = ldw4(wl + (long long)(G0 + u + RC_D) * 256);      // (past the last group: the zero tap, in bounds)
         af = afn;
       }
     }
   }
-  bool fin = true;
   f32x4 res = accs[0] + accs[1];
   if constexpr (KW > 1) {
     float* const red = win + a.wr_max * LDX;
     __syncthreads();                       // wave 0 has read the previous strip's partial tiles
     if (wave > 0) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = res;
     __syncthreads();
-    fin = wave == 0;
-    if (fin) {
+    if (wave == 0) {
 #pragma unroll
       for (int w = 1; w < KW; ++w) res += *reinterpret_cast<const f32x4*>(red + ((w - 1) * 64 + lane) * 4);
     }
   }
-  const int col = ct0 * 16 + lr;
-  if (fin && active && col < a.Cout) {
-    const float bias = a.bias ? ldw1(a.bias + col) : 0.f;
-    const float scale = a.out_scale;
-    const int act = a.out_act;
+  if (fin) {
+    if constexpr (!PF) fetch();
+    const float scale = a_scale;
+    const int act = a_act;
+    float o[4];
+    const float bb[4] = {pbias.x, pbias.y, pbias.z, pbias.w}, bv[4] = {pbv.x, pbv.y, pbv.z, pbv.w}, rs[4] = {pres.x, pres.y, pres.z, pres.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int r = 4 * lg + e;
-      if (r >= tb.nvalid) continue;
-      const RowId id = row_id(tb, r);
-      float v = (res[e] + bias) * scale;
+      float v = (res[e] + bb[e]) * scale;
       if (act == ACT_RELU) v = v > 0.f ? v : 0.f;
       else if (act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-      else if (act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
-      if (a.bvec) v += ldw1(a.bvec + (long long)id.slot * a.bvec_stride + col);
-      if (a.has_res) v += ld1<true>(row(a.res, id.i, id.slot, id.pos, id.t) + col);
-      if (a.has_m1) v *= ld1<true>(row(a.m1, id.i, id.slot, id.pos, id.t));
-      if (a.has_m2) v *= ld1<true>(row(a.m2, id.i, id.slot, id.pos, id.t));
-      st1<true>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v);
+      else if (act == ACT_LRELU) v = v > 0.f ? v : v * a_oslope;
+      if (a_bvec) v += bv[e];
+      if (a_has_res) v += rs[e];
+      if (a_has_m1 | a_has_m2) v *= pm;
+      o[e] = v;
     }
+    st4<CM>(yptr, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
@@ -893,7 +964,7 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
 // second, 1x1 conv: the hidden tensor never leaves the CU and the second conv's K loop is split over the group.
 // The member's partial sums [rows][Cout2] go to part[sb]; bias, residual and the norm behind them are applied where the sum is
 // consumed (RowConvArgs / LNArgs: xp ..).  LDS: window [wr_max][Cin + 8] | hidden [16][HC + 8].
-template <bool WIDE = false, class A>
+template <bool WIDE = false, int CM = 1, class A>
 __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int sb, const int GS, float* __restrict__ win) {
   constexpr int RC_D = 8;
   int tid = threadIdx.x;
@@ -1010,7 +1081,7 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
           const int r = 4 * lg + e;
           if (r >= tb.nvalid) continue;
           const RowId id = row_id(tb, r);
-          st1<true>(pbase + (long long)(id.i * a.T + id.t) * a.Cout2 + col, acc0[e] + acc1[e]);
+          st1<CM>(pbase + (long long)(id.i * a.T + id.t) * a.Cout2 + col, acc0[e] + acc1[e]);
         }
       }
     }
@@ -1018,7 +1089,7 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
 }
 
 // one 64-column strip of a 1x1 layer wider than the window (aligner ff2): the rows' channels pass through LDS in chunks of 512
-template <class A>
+template <int CM = 1, class A>
 __device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, const int bx, float* __restrict__ win) {   // win: [16][RL_LDX]
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
@@ -1048,7 +1119,7 @@ __device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, co
       for (int u = 0; u < 4; ++u) {
         const int w = gw + 2 * (4 * h + u);
         const RowId id = row_id(tb, w < tb.nvalid ? w : 0);
-        v[u] = ld4<true>(row(a.x, id.i, id.slot, id.pos, id.t) + gc4 * 4 + c0);
+        v[u] = ld4<CM>(row(a.x, id.i, id.slot, id.pos, id.t) + gc4 * 4 + c0);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int w = gw + 2 * (4 * h + u); *reinterpret_cast<float4*>(win + w * RL_LDX + gc4 * 4) = v[u]; }
@@ -1087,16 +1158,16 @@ __device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, co
       else if (a.out_act == ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
       else if (a.out_act == ACT_LRELU) v = v > 0.f ? v : v * a.out_slope;
       if (a.bvec) v += ldw1(a.bvec + (long long)id.slot * a.bvec_stride + col);
-      if (a.has_res) v += ld1<true>(row(a.res, id.i, id.slot, id.pos, id.t) + col);
-      if (a.has_m1) v *= ld1<true>(row(a.m1, id.i, id.slot, id.pos, id.t));
-      if (a.has_m2) v *= ld1<true>(row(a.m2, id.i, id.slot, id.pos, id.t));
-      st1<true>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v);
+      if (a.has_res) v += ld1<CM>(row(a.res, id.i, id.slot, id.pos, id.t) + col);
+      if (a.has_m1) v *= ld1<CM>(row(a.m1, id.i, id.slot, id.pos, id.t));
+      if (a.has_m2) v *= ld1<CM>(row(a.m2, id.i, id.slot, id.pos, id.t));
+      st1<CM>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v);
     }
   }
 }
 
 // LayerNorm of tile row r (one wave)
-template <class A>
+template <int CM = 1, class A>
 __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, const int r) {
   if (r >= tb.nvalid) return;
   const int lane = threadIdx.x & 63;
@@ -1115,14 +1186,14 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
         float pv[8];
         for (int p0 = 0; p0 < a.xparts; p0 += 8) {
 #pragma unroll
-          for (int p = 0; p < 8; ++p) pv[p] = p0 + p < a.xparts ? ld1<true>(a.xp + (p0 + p) * a.xp_stride + off) : 0.f;
+          for (int p = 0; p < 8; ++p) pv[p] = p0 + p < a.xparts ? ld1<CM>(a.xp + (p0 + p) * a.xp_stride + off) : 0.f;
 #pragma unroll
           for (int p = 0; p < 8; ++p) if (p0 + p < a.xparts) u = p0 + p == 0 ? pv[p] : u + pv[p];
         }
         if (a.xbias) u += ldw1(a.xbias + c);
-        if (a.has_xres) u += ld1<true>(row(a.xres, id.i, id.slot, id.pos, id.t) + c);
-      } else u = ld1<true>(x + c);
-      sa += fabsf(u); if (pre) u += ld1<true>(pre + c);
+        if (a.has_xres) u += ld1<CM>(row(a.xres, id.i, id.slot, id.pos, id.t) + c);
+      } else u = ld1<CM>(x + c);
+      sa += fabsf(u); if (pre) u += ld1<CM>(pre + c);
     }
     v[k] = u; s += u;
   }
@@ -1134,11 +1205,11 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
   q = wave_sum(q);
   const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
   float mk = 1.f;
-  if (a.has_m1) mk *= ld1<true>(row(a.m1, id.i, id.slot, id.pos, id.t));
-  if (a.has_m2) mk *= ld1<true>(row(a.m2, id.i, id.slot, id.pos, id.t));
+  if (a.has_m1) mk *= ld1<CM>(row(a.m1, id.i, id.slot, id.pos, id.t));
+  if (a.has_m2) mk *= ld1<CM>(row(a.m2, id.i, id.slot, id.pos, id.t));
   if (a.has_mask_out) {
     sa = wave_sum(sa);
-    if (lane == 0) st1<true>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f);
+    if (lane == 0) st1<CM>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f);
   }
   float* y = row(a.y, id.i, id.slot, id.pos, id.t);
   const float* post = a.has_post ? row(a.post, id.i, id.slot, id.pos, id.t) : nullptr;
@@ -1148,14 +1219,14 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
     if (c < a.C) {
       float o = (v[k] - mean) * rstd * ldw1(a.gamma + c) + ldw1(a.beta + c);
       if (a.has_m1 | a.has_m2) o *= mk;
-      if (post) o += ld1<true>(post + c);
-      st1<true>(y + c, o);
+      if (post) o += ld1<CM>(post + c);
+      st1<CM>(y + c, o);
     }
   }
 }
 
 // embedding row r of the tile (one wave)
-template <class A>
+template <int CM = 1, class A>
 __device__ __forceinline__ void mg_embed_row(const A& a, const RowTab& tb, const int r) {
   if (r >= tb.nvalid) return;
   const int lane = threadIdx.x & 63;
@@ -1164,14 +1235,14 @@ __device__ __forceinline__ void mg_embed_row(const A& a, const RowTab& tb, const
   idx = idx < 0 ? 0 : (idx >= a.vocab ? a.vocab - 1 : idx);
   float* y = row(a.y, id.i, id.slot, id.pos, id.t);
   const float* e = a.table + (long long)idx * a.C;
-  for (int c = lane; c < a.C; c += 64) st1<true>(y + c, ldw1(e + c));
+  for (int c = lane; c < a.C; c += 64) st1<CM>(y + c, ldw1(e + c));
 }
 
 // cross attention of tile rows r0, r0 + 1 (two heads: waves 0-1 take row r0, waves 2-3 row r0 + 1); LDS: 2 x [sq 1024 | sp 2 x 512]
 // The K / V rows of a slot are read-only for the launch: their loads are batched 8 deep (the serial form - one load, one
 // multiply-add - made this operator 26 us of L2 latency for 38 keys).
 constexpr int XA2_LDS_FLOATS = 1024 + 2 * XA_MAX_S;
-template <class A>
+template <int CM = 1, class A>
 __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, const int r0, float* __restrict__ lds) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int half = wv >> 1, h = wv & 1, ht = threadIdx.x & 127;
@@ -1182,7 +1253,7 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
   const RowId id = row_id(tb, live ? r : 0);
   const int S = ldi(a.slen + id.slot);
   const int dh = a.E / a.H;
-  if (live) { const float* q = row(a.q, id.i, id.slot, id.pos, id.t); for (int c = ht; c < a.E; c += 128) sq[c] = ld1<true>(q + c); }
+  if (live) { const float* q = row(a.q, id.i, id.slot, id.pos, id.t); for (int c = ht; c < a.E; c += 128) sq[c] = ld1<CM>(q + c); }
   __syncthreads();
   const float* kv = a.kv + (long long)id.slot * a.kv_slot_stride;
   const float* km = a.kmask + (long long)id.slot * a.S_max;
@@ -1223,13 +1294,13 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (s0 + u < S) acc += sp[h][s0 + u] * vv[u];       // (the same additions in the same order as the serial loop)
       }
-      st1<true>(o + h * dh + d, acc);
+      st1<CM>(o + h * dh + d, acc);
     }
   }
 }
 
 // uv / f0 head of tile row r (one wave)
-template <class A>
+template <int CM = 1, class A>
 __device__ __forceinline__ void mg_pitch_row(const A& a, const RowTab& tb, const float mel_min, const float mel_den, const int r) {
   if (r >= tb.nvalid) return;
   const int lane = threadIdx.x & 63;
@@ -1239,7 +1310,7 @@ __device__ __forceinline__ void mg_pitch_row(const A& a, const RowTab& tb, const
   float v[4];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; v[k] = c < a.Cp ? ld1<true>(x + c) : 0.f; s += v[k]; }
+  for (int k = 0; k < 4; ++k) { int c = lane + 64 * k; v[k] = c < a.Cp ? ld1<CM>(x + c) : 0.f; s += v[k]; }
   s = wave_sum(s);
   const float mean = s / (float)a.Cp;
   float q = 0.f;
@@ -1268,7 +1339,7 @@ __device__ __forceinline__ void mg_pitch_row(const A& a, const RowTab& tb, const
   const float* pi = row(a.pitch_inp, id.i, id.slot, id.pos, id.t);
   float* di = row(a.dec_inp, id.i, id.slot, id.pos, id.t);
   const float* pe = a.pitch_embed + (long long)bin * a.E;
-  for (int c = lane; c < a.E; c += 64) st1<true>(di + c, ld1<true>(pi + c) + ldw1(pe + c));
+  for (int c = lane; c < a.E; c += 64) st1<CM>(di + c, ld1<CM>(pi + c) + ldw1(pe + c));
 }
 
 }  // namespace ro

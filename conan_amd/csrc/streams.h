@@ -234,6 +234,7 @@ struct conan_streams {
     long long key[6] = {0, 0, 0, 0, 0, 0};
     bool ok = false;
     int nops = 0, groups = 0, group_size = 0, njobs = 0, kw4 = 0, lds_bytes = 0, barriers = 0, n = 0, T = 0;
+    bool xcd = false;                  // a single row tile: the launch's workgroups on ONE XCD form the group (decoder_mega.hip)
     double flops = 0.0;
     cnk::MegaOp* dev = nullptr;        // device copy (capacity kMegaMaxOps)
     cnk::MegaOp* pinned = nullptr;     // host staging of this entry; reused only after `copied` has fired
@@ -246,8 +247,12 @@ struct conan_streams {
   bool use_mega = true;                          // CONAN_DEC_MEGA=0: the decoder step as separate launches
   int mega_grid = 128;                           // CONAN_MEGA_GRID
   int mega_gs = 8;                               // workgroups per group (CONAN_MEGA_GS: 4, 8 or 16)
+  int mega_ffn_gs = 8;                           // members of a fused feed-forward while a program is recorded (run_mega)
   unsigned* mega_bar = nullptr;                  // the grid barrier's arrival counter (counts for ever); the group counters follow it, 16 words apart
   unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished
+  unsigned* mega_x = nullptr;                    // xcd mode: election word, rank counter, "decided" counter, barrier flags (decoder_mega.hip)
+  unsigned mega_xseq = 0, mega_xdec = 0;         // launches in xcd mode so far (24 bits), the decided counter's value once they have all finished
+  bool mega_single = true;                       // single-tile steps take the persistent launch (xcd mode); CONAN_MEGA_SINGLE=0: separate launches
   unsigned long long* mega_dbg = nullptr;        // CONAN_MEGA_STAMPS=1: per-operator clock stamps of the last launch (printed at destruction)
   int mega_dbg_prog = -1;                        // index into mega_cache (the vector may reallocate)
   std::vector<cnk::MegaOp>* mega_rec = nullptr;  // != nullptr: decoder_ops() records its operators instead of launching them

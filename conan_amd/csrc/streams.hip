@@ -154,9 +154,10 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     op.type = v == 3 ? cnk::MOP_ROWLIN : (v == 2 ? cnk::MOP_RC114 : cnk::MOP_RC111);
     if (a.w2) {        // fused conv -> 1x1 conv: behind the window, the member's 16 x (Cout / 8 + 8) hidden tile - or, with a single 64-column
                        // hidden strip per member (the decoder's conv blocks), in the window's place once every wave has read it out
-      if (v != 0 || (a.ktaps * (a.Cin >> 4)) % 8 != 0) { mega_rec_ok = false; return; }
+      // (v == 2: a single row tile - the plan of the plain conv would split K over the waves; the fused operator has its own geometry)
+      if ((v != 0 && v != 2) || (a.ktaps * (a.Cin >> 4)) % 8 != 0) { mega_rec_ok = false; return; }
       op.type = cnk::MOP_FFN;
-      const int hc = a.Cout / mega_gs;
+      const int hc = a.Cout / mega_ffn_gs;
       op.u.rc.hid_overlay = hc == 64 ? 1 : 0;
       ldsf = op.u.rc.hid_overlay ? std::max(op.u.rc.wr_max * (a.Cin + 8), 16 * (hc + 8)) : op.u.rc.wr_max * (a.Cin + 8) + 16 * (hc + 8);
       mega_rec_flops += 2.0 * (double)a.n * a.T * a.Cout * a.Cout2;
@@ -224,7 +225,7 @@ void conan_streams::mega_print_stamps() {
   if (!mega_dbg || mega_dbg_prog < 0 || mega_dbg_prog >= (int)mega_cache.size()) return;
   (void)hipDeviceSynchronize();
   const MegaProgram& e = mega_cache[mega_dbg_prog];
-  std::vector<unsigned long long> h(e.nops + 2);
+  std::vector<unsigned long long> h(512 + 4 * kMegaMaxOps);
   if (hipMemcpy(h.data(), mega_dbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
   static const char* names[] = {"rowconv<1,1,1>", "rowconv<1,1,4>", "rowlin", "layernorm", "xattn", "pitch_head", "embed", "copy32", "advance", "ffn"};
   constexpr int nnames = (int)(sizeof(names) / sizeof(names[0]));
@@ -234,20 +235,33 @@ void conan_streams::mega_print_stamps() {
     const cnk::MegaOp& op = e.pinned[o];
     fprintf(stderr, "  op %2d %-15s strips %4d  barrier %d  %7.2f us", o, (op.type >= 0 && op.type < nnames) ? names[op.type] : "?", op.nbx, op.barrier, (h[o + 1] - h[o]) / 100.0);
     if (op.type <= cnk::MOP_ROWLIN) fprintf(stderr, "   Cin %4d Cout %4d k %d ln %d", op.u.rc.Cin, op.u.rc.Cout, op.u.rc.ktaps, op.u.rc.ln);
+    if (op.type == cnk::MOP_RC114 && h[128 + o * 4]) fprintf(stderr, "   [args+warm %.2f stage %.2f strips %.2f barrier %.2f]", (h[128 + o * 4] - h[o]) / 100.0, (h[128 + o * 4 + 1] - h[128 + o * 4]) / 100.0,
+                                                               (h[128 + o * 4 + 2] - h[128 + o * 4 + 1]) / 100.0, (h[o + 1] - h[128 + o * 4 + 2]) / 100.0);
+    if (op.type == cnk::MOP_RC114 && h[512 + o * 4]) fprintf(stderr, " {stage: sync %.2f issue %.2f return+lds %.2f sync %.2f rest %.2f}", (h[512 + o * 4] - h[128 + o * 4]) / 100.0, (h[512 + o * 4 + 1] - h[512 + o * 4]) / 100.0,
+                                                               (h[512 + o * 4 + 2] - h[512 + o * 4 + 1]) / 100.0, (h[512 + o * 4 + 3] - h[512 + o * 4 + 2]) / 100.0, (h[128 + o * 4 + 1] - h[512 + o * 4 + 3]) / 100.0);
     fprintf(stderr, "\n");
   }
 }
 
 void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   static const bool stamps = getenv("CONAN_MEGA_STAMPS") != nullptr;
-  if (stamps && !mega_dbg) mega_dbg = reinterpret_cast<unsigned long long*>(alloc(2 * (kMegaMaxOps + 4)));
+  if (stamps && !mega_dbg) mega_dbg = reinterpret_cast<unsigned long long*>(alloc(2 * (512 + 4 * kMegaMaxOps)));
   if (stamps) mega_dbg_prog = (int)(&e - mega_cache.data());
   cnk::MegaLaunch m; memset(&m, 0, sizeof(m));
   m.prog = e.dev; m.nops = e.nops; m.njobs = e.njobs; m.groups = e.groups; m.group_size = e.group_size; m.kw4 = e.kw4; m.lds_bytes = e.lds_bytes;
   m.slots = d_slots; m.pos = pos_dec; m.n = e.n; m.T = e.T;
   m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg; m.guard = d_guard; m.wide_regs = rb_limb ? 1 : 0;
+  m.xcd = e.xcd ? 1 : 0;
+  if (e.xcd) {
+    mega_xseq = (mega_xseq + 1u) & 0xffffffu; if (mega_xseq == 0u) mega_xseq = 1u;
+    m.xs = mega_x; m.xseq = mega_xseq; m.xdec_base = mega_xdec;
+    if (test_fault == 1) { m.xdec_base += 1u; test_fault = 0; }     // test hook: the election waits for one workgroup too many
+    profiled("cnk::decoder_mega_kernel<4, 2>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
+    mega_xdec += (unsigned)(e.groups * e.group_size);
+    return;
+  }
   if (test_fault == 1) { m.bar_base += 1u; test_fault = 0; }       // test hook: the grid barrier waits for one arrival too many
-  profiled(rb_limb ? "cnk::decoder_mega_kernel<4>" : "cnk::decoder_mega_kernel<6>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
+  profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 1>" : "cnk::decoder_mega_kernel<6, 1>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
 }
 
@@ -738,7 +752,7 @@ void conan_streams::build_decoder() {
   c_pin = mk_lin(F, H); c_q = mk_lin(F, H); c_att = mk_lin(F, H); c_a1 = mk_lin(F, H); c_a2 = mk_lin(F, H);
   c_ff = mk_lin(F, ffn); c_uv5 = mk_lin(F, uvh); c_x[0] = mk_lin(F, H); c_x[1] = mk_lin(F, H); c_h = mk_lin(F, 2 * H);
   c_post = mk_lin(F, H); c_mask_blk = mk_lin(F, 1); c_mask_blk2 = mk_lin(F, 1); c_mask_out = mk_lin(F, 1); c_mel = mk_lin(F, c.num_mels);
-  c_part = mk_lin(F, 16 * H);       // decoder megakernel: the 8 group members' partial sums of a fused feed-forward, [member][row][H]
+  c_part = mk_lin(F, 32 * H);       // decoder megakernel: the group members' (8; xcd mode: 32 virtual ones) partial sums of a fused feed-forward, [member][row][H]
   c_part2 = mk_lin(F, 16 * H);      // ... and a second set: consecutive fused conv blocks write one while the members still read the other
   S_max = (max_ref + 3) / 4;
   if (S_max > 512) throw Error(CONAN_ERR_UNSUPPORTED, "max_ref_frames > 2048");

@@ -22,13 +22,16 @@ const float* conan_ctx::chain_weight(const std::string& name) {
   return d;
 }
 
-// A stream-set takes the chain when it is small (one mel row tile), the vocoder is the shuffle-upsampler / ResBlock1 generator the
-// kernel covers, and the caller did not ask for the bf16-limb arithmetic (the chain computes on the f32 MFMA).  CONAN_VOC_CHAIN=0
-// keeps the launch plans (A/B runs).
+// A stream-set CAN take the chain when it is small (one mel row tile), the vocoder is the shuffle-upsampler / ResBlock1 generator the
+// kernel covers, and the caller did not ask for the bf16-limb arithmetic (the chain computes on the f32 MFMA).
+// MEASURED (round 5, MI355X, DESIGN.md §4 "voc_chain"): parity-green (9e-7 against the launch plans, ragged steps included) but NOT
+// faster - 0.40-0.42 ms per one-stream step against 0.35 ms of the 28 launches, 0.70 against 0.44 ms at four streams: 30 dependent
+// phases of ~13 us (hand-off through memory 3 + gather 2 + the job's MFMAs, 2.8 us at one CU for a k = 11 tile, + slice sums and
+// stores 1.6 + skew) cost what the launches do.  So the launch plans stay the default; CONAN_VOC_CHAIN=1 selects the chain.
 bool conan_streams::chain_eligible(bool limb_requested) const {
   const conan_cfg& c = ctx->cfg;
   if (!(c.models & CONAN_MODEL_HIFIGAN) || limb_requested) return false;
-  { const char* e = getenv("CONAN_VOC_CHAIN"); if (e && e[0] == '0') return false; }
+  { const char* e = getenv("CONAN_VOC_CHAIN"); if (!(e && e[0] == '1')) return false; }
   if ((long long)max_slots * max_frames > kChainRows || max_slots > 16) return false;
   if (c.voc_upsample != 0 || c.voc_resblock == 2 || c.voc_num_resblocks > kMaxBranches) return false;
   if (2 + c.voc_num_ups * (1 + 2 * c.voc_rb_num_dil) > cnk::VC_MAX_PHASES || 1 + 2 * c.voc_num_ups > cnk::VC_MAX_TAPS) return false;
@@ -66,12 +69,12 @@ bool plan_phase(int n, int T, int Cin, int ncts, int nprob, int kmax, int halo_m
     for (int NCT : {1, 2, 4, 8}) {
       if (NCT > ncts || ncts % NCT) continue;
       const int KS = 8 / NCT;
-      const int lds = kChainHdrFloats + std::max(WR * LDX, KS > 1 ? 2048 * NRT : 0);
+      const int lds = kChainHdrFloats + WR * LDX + (KS > 1 ? 2048 * NRT : 0);
       if ((size_t)lds * 4 > (size_t)kChainLdsMax) continue;
       const long long njobs = (long long)nprob * tiles * (ncts / NCT);
       const double rounds = std::ceil((double)njobs / G);
       const double groups = (double)kmax * KQ / KS;                         // K groups per wave (the longest branch)
-      const double cost = rounds * (2.0 + groups * NRT * 0.06 + WR * LDX * 4.0 / 1024.0 / 30.0);
+      const double cost = rounds * (4.0 + groups * NRT * 0.06 + WR * LDX * 4.0 / 1024.0 / 30.0);
       if (cost < best) { best = cost; found = true; *out = Geo{NRT, NCT, KS, spt, tps, tiles, ncts / NCT, (int)njobs, lds}; }
     }
   }
@@ -209,6 +212,14 @@ void conan_streams::chain_step(int n, int frames, const float* mel_dev, float* w
     l.io.tap[0] = taps->conv_pre_act;
     for (int i = 0; i < c.voc_num_ups; ++i) { l.io.tap[1 + i] = taps->ups[i]; l.io.tap[1 + c.voc_num_ups + i] = taps->stage_out[i]; }
   }
+  static const bool stamps = getenv("CONAN_VC_STAMPS") != nullptr;
+  static unsigned long long* dbg = nullptr;
+  const size_t dbg_words = (size_t)kChainGridMax * cnk::VC_MAX_PHASES * 4 + kChainGridMax + 1;
+  if (stamps) {
+    if (!dbg) HIP_CHECK(hipMalloc((void**)&dbg, dbg_words * 8));
+    HIP_CHECK(hipMemsetAsync(dbg, 0, dbg_words * 8, st));
+    l.dbg = dbg;
+  }
   profiled("cnk::voc_chain_kernel", pr.flops, st, [&] {
     // one chain launch of this context at a time on the device: each needs its whole grid resident
     std::lock_guard<std::mutex> lock(ctx->chain_mu);
@@ -217,4 +228,31 @@ void conan_streams::chain_step(int n, int frames, const float* mel_dev, float* w
     cnk::launch_voc_chain(l, st);
     HIP_CHECK(hipEventRecord(ctx->chain_done, st));
   });
+  if (stamps) {
+    static int calls = 0;
+    if (++calls == 40) {      // (a warm launch)
+      HIP_CHECK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h(dbg_words);
+      HIP_CHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<cnk::VCPhase> ph(pr.nphases);
+      HIP_CHECK(hipMemcpy(ph.data(), pr.dev, sizeof(cnk::VCPhase) * pr.nphases, hipMemcpyDeviceToHost));
+      const int G = pr.grid;
+      const size_t tail = (size_t)G * cnk::VC_MAX_PHASES * 4;
+      unsigned long long t0 = ~0ull;
+      for (int b = 0; b < G; ++b) t0 = std::min(t0, h[tail + b]);
+      fprintf(stderr, "[voc_chain] n %d frames %d grid %d lds %d B: %.2f us in all (first workgroup's start -> the last one's end)\n", n, frames, G, pr.lds_bytes, (h[tail + G] - t0) / 100.0);
+      double prev = 0.0;
+      for (int p = 0; p < pr.nphases; ++p) {
+        double v[4] = {0, 0, 0, 0}, first_wait = 1e30;
+        for (int b = 0; b < G; ++b)
+          for (int q = 0; q < 4; ++q) {
+            const unsigned long long x = h[((size_t)b * cnk::VC_MAX_PHASES + p) * 4 + q];
+            if (x) { v[q] = std::max(v[q], (x - t0) / 100.0); if (q == 0) first_wait = std::min(first_wait, (x - t0) / 100.0); }
+          }
+        fprintf(stderr, "  phase %2d type %d T %5d Cin %3d Cout %4d k %2d nprob %d NRT %d NCT %d KS %d jobs %4d: wait passed %7.2f .. %7.2f gathered %7.2f K loops %7.2f stores issued %7.2f  (+%.2f)\n", p, ph[p].type, ph[p].T,
+                ph[p].p[0].Cin, ph[p].p[0].Cout, ph[p].p[0].k, ph[p].nprob, ph[p].NRT, ph[p].NCT, ph[p].KS, ph[p].njobs, first_wait, v[0], v[1], v[2], v[3], v[3] - prev);
+        if (v[3] > 0) prev = v[3];
+      }
+    }
+  }
 }

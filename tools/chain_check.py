@@ -13,7 +13,7 @@ from conan_amd.runtime import Context
 
 
 def run(S, steps, chain, frames_list):
-    os.environ["CONAN_VOC_CHAIN"] = "1" if chain else "0"
+    os.environ["CONAN_VOC_CHAIN"] = "1" if chain else "0"      # (the chain is opt-in: the launch plans are faster, see voc_chain_host.hip)
     vhp = configs.hifigan_hparams()
     ctx = Context(None, vhp, 0, False, False, True)
     ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
