@@ -94,7 +94,7 @@ __device__ __forceinline__ void mg_barrier_xcd(unsigned* flags, const unsigned e
     for (;;) {
       const unsigned v = lane < P ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
       if (__all((int)(v - epoch) >= 0)) break;
-      if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;
+      if (spin_expired(sg, guard, WAIT_MEGA_FLAGS)) break;
     }
   }
   __syncthreads();
@@ -107,8 +107,7 @@ __device__ __forceinline__ void mg_barrier_xcd(unsigned* flags, const unsigned e
 // resident kernels (resblock_limb <= 192, conv_limb's streaming shapes <= 192) leave 2 x 192 + 128 = 512 - tests/test_kernel_resources.py.
 // CM = 2 (xcd mode, a single row tile in the step): the launch is one workgroup per CU; the workgroups that find themselves on the
 // XCD of workgroup 0 (HW_REG_XCC_ID - read, not assumed) form the ONE group that walks the program, the others leave at once.
-// xs: [0] elected XCD (launch sequence << 8 | xcc + 1), [16] participants' rank counter (zero between launches), [32] "decided"
-// counter (counts for ever; xdec_base = its value before this launch), [64 ..) the barrier flags.
+// xs: [0] election word, [16 .. 48) two sets of per-XCD arrival counters, [64 ..) the barrier flags.
 template <int OCC, int CM>
 __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS_,
                                                               const int* __restrict__ slots, const int* __restrict__ pos, const int n, const int T,
@@ -125,37 +124,46 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
   int GS = GS_;
   unsigned xepoch = xseq << 8;
   if constexpr (CM == 2) {
+    // Quorum election.  Every workgroup registers with its XCD (arrival rank r on that XCD's counter).  The XCD whose count first
+    // reaches 32 - or, after ~4 us, the first XCD with at least 8 - is claimed (one compare-and-swap on the election word, which
+    // carries the launch's sequence number, the XCD and the member count P); its arrivals 0 .. P - 1 are the group, everybody else
+    // leaves.  Nothing waits for workgroups that have not started: a CU held by another launch's spinning workgroups (another
+    // stream-set's xcd group occupies a whole XCD; workgroups are bound to XCDs round-robin) only makes THAT XCD lose the election.
+    // Counters: two sets of 16, used alternately; the group's rank 0 zeroes the other set at the end (its last users - the launch
+    // before - are all gone).  The election word goes from (xseq - 1) << 12 ("done") to xseq << 12 | P << 4 | xcc and back to "done".
     int* const sh = reinterpret_cast<int*>(lds_all);
     if (threadIdx.x == 0) {
       const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
-      if (b == 0) __hip_atomic_store(xs, (xseq << 8) | (xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* const cnt = xs + 16 + (xseq & 1u) * 16;
+      const unsigned r = __hip_atomic_fetch_add(cnt + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned idle = ((xseq - 1u) & 0xfffffu) << 12, tag = (xseq & 0xfffffu) << 12;
+      if (r + 1u == 32u) {       // this arrival completes the XCD: claim it
+        unsigned exp = idle;
+        __hip_atomic_compare_exchange_strong(xs, &exp, tag | (32u << 4) | xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       unsigned v;
       SpinGuard sg;
-      while (((v = __hip_atomic_load(xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != xseq) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (((v = __hip_atomic_load(xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ~0xfffu) != tag) {
         __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
-        if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;
-      }
-      const bool mine = ((v & 255u) - 1u) == xcc && (v >> 8) == xseq;
-      int rank = -1;
-      if (mine) rank = (int)__hip_atomic_fetch_add(xs + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the rank is taken before this workgroup counts as decided)
-      __hip_atomic_fetch_add(xs + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int P = 0;
-      if (mine) {
-        while ((int)(__hip_atomic_load(xs + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (xdec_base + gridDim.x)) < 0) {
-          __builtin_amdgcn_s_sleep(MG_POLL_SLEEP);
-          if (spin_expired(sg, guard, WAIT_MEGA_BARRIER)) break;
+        if (r == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 400ull) {      // the XCD's first arrival: after 4 us a smaller group will do
+          const unsigned c = __hip_atomic_load(cnt + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (c >= 8u) {
+            unsigned exp = idle;
+            __hip_atomic_compare_exchange_strong(xs, &exp, tag | ((c < 32u ? c : 32u) << 4) | xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
-        P = (int)__hip_atomic_load(xs + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spin_expired(sg, guard, WAIT_MEGA_ELECT)) break;
       }
-      sh[0] = rank; sh[1] = P;
+      const unsigned P = (v >> 4) & 255u;
+      const bool mine = (v & ~0xfffu) == tag && (v & 15u) == xcc && r < P;
+      sh[0] = mine ? (int)r : -1; sh[1] = (int)P;
     }
     __syncthreads();
     const int rank = sh[0], P = sh[1];
     __syncthreads();
     if (rank < 0 || P <= 0) return;
-    b = rank; GS = P < 64 ? P : 64;
-    if (rank >= GS) return;                  // (never with one workgroup per CU: an XCD has 32)
+    b = rank; GS = P;
     {   // pull the program into this XCD's L2 (the operators read their arguments through the scalar cache where they use them: the
         // first touch of every operator's block would otherwise be a chain of misses to memory)
       const int words = nops * (int)(sizeof(MegaOp) / 4);
@@ -264,7 +272,10 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
         for (int q = threadIdx.x; q < a.n; q += 256) a.pos[a.slots ? a.slots[q] : q] += a.delta;
       }
     }
-    if constexpr (CM == 2) { if (threadIdx.x == 0) __hip_atomic_store(xs + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (every participant holds its rank by now)
+    if constexpr (CM == 2) {      // the other counter set (the launch before's: all its workgroups are gone) and the election word
+      if (threadIdx.x < 16) __hip_atomic_store(xs + 16 + ((xseq + 1u) & 1u) * 16 + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) __hip_atomic_store(xs, (xseq & 0xfffffu) << 12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     else for (int q = threadIdx.x; q < NG; q += 256) __hip_atomic_store(gbar + q * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (dbg && b == 0 && threadIdx.x == 0) dbg[1 + nops] = __builtin_amdgcn_s_memrealtime();

@@ -39,7 +39,7 @@ enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4
 // budget down, a wait without an end takes the box with it).
 constexpr unsigned long long kSpinBudgetTicks = 5000000ull;
 constexpr unsigned long long kSpinGapTicks = 100000ull;
-enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4, WAIT_VOC_PHASE = 5 };
+enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4, WAIT_VOC_PHASE = 5, WAIT_MEGA_ELECT = 6, WAIT_MEGA_DECIDED = 7, WAIT_MEGA_FLAGS = 8 };
 struct SpinGuard { unsigned long long last = 0, acc = 0; unsigned it = 0; };
 #if defined(__HIPCC__)
 // true: give up (budget spent, or another wait of this stream-set already failed)

@@ -99,8 +99,9 @@ struct conan_streams {
     if (!h_guard) return;
     const unsigned code = *(volatile const unsigned*)h_guard;
     if (code == 0) return;
-    static const char* what[] = {"?", "decoder_mega_kernel group / grid barrier", "emformer_fused_kernel cluster exchange", "resblock_pair_kernel partner flag", "resblock_pair_kernel tile mailbox"};
-    throw ch::Error(CONAN_ERR_HIP, std::string("a cross-workgroup wait gave up after its 50 ms budget (") + what[code < 5 ? code : 0] +
+    static const char* what[] = {"?", "decoder_mega_kernel group / grid barrier", "emformer_fused_kernel cluster exchange", "resblock_pair_kernel partner flag", "resblock_pair_kernel tile mailbox",
+                                 "voc_chain_kernel phase counter", "decoder_mega_kernel xcd election", "decoder_mega_kernel xcd roll call", "decoder_mega_kernel xcd flag barrier"};
+    throw ch::Error(CONAN_ERR_HIP, std::string("a cross-workgroup wait gave up after its 50 ms budget (") + what[code < 9 ? code : 0] +
                                        "): results since then are invalid and this stream-set is unusable - destroy it and create a new one");
   }
 

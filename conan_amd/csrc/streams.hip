@@ -253,9 +253,9 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg; m.guard = d_guard; m.wide_regs = rb_limb ? 1 : 0;
   m.xcd = e.xcd ? 1 : 0;
   if (e.xcd) {
-    mega_xseq = (mega_xseq + 1u) & 0xffffffu; if (mega_xseq == 0u) mega_xseq = 1u;
+    mega_xseq = mega_xseq + 1u;       // (20 bits of it travel in the election word; consecutive launches differ)
     m.xs = mega_x; m.xseq = mega_xseq; m.xdec_base = mega_xdec;
-    if (test_fault == 1) { m.xdec_base += 1u; test_fault = 0; }     // test hook: the election waits for one workgroup too many
+    if (test_fault == 1) { m.xseq += 7u; mega_xseq += 7u; test_fault = 0; }     // test hook: the election word is not in the state this launch expects - nobody can claim
     profiled("cnk::decoder_mega_kernel<4, 2>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
     mega_xdec += (unsigned)(e.groups * e.group_size);
     return;
