@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           const auto& a = MG_AS4(RowConvArgs, &op->u);
           if (sb < nbx) {      // (members without a strip skip the gather as well)
             float4 bw[8];
+            // (the 8-deep ring of this form held across the gather costs the 128-register build 20 spilled registers: L2 warm-up only)
             const float warm = ro::mg_wwarm<1>(a, sb);
             ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
             ro::mg_keep(warm);
@@ -200,12 +201,20 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           const auto& a = MG_AS4(RowConvArgs, &op->u);
           if (sb < nbx) {
             float4 bw[4];
-            const float warm = ro::mg_wwarm<4>(a, sb);
             if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-            ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, nbx < GS ? nbx : GS, (dbg && b == 0) ? dbg + 512 + o * 4 : nullptr);
-            ro::mg_keep(warm);
-            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-            for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4, false, CM, (OCC < 6)>(a, tab, bx, lds, bw);
+            if constexpr (OCC < 6) {
+              ro::mg_wpre<4>(a, sb, bw);
+              ro::mg_stage<true, CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
+              if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+              ro::mg_strip<4, true, CM, true>(a, tab, sb, lds, bw);
+              for (int bx = sb + GS; bx < nbx; bx += GS) ro::mg_strip<4, false, CM, true>(a, tab, bx, lds, bw);
+            } else {
+              const float warm = ro::mg_wwarm<4>(a, sb);
+              ro::mg_stage<false, CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
+              ro::mg_keep(warm);
+              if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+              for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<4, false, CM, false>(a, tab, bx, lds, bw);
+            }
             if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 2] = __builtin_amdgcn_s_memrealtime();
           }
         } break;
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
         } break;
         case MOP_LN: {
           const auto& a = MG_AS4(LNArgs, &op->u);
-          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_layernorm_row<CM>(a, tab, r);      // 16 rows over GS members x 4 waves
+          for (int r = sb * 4 + (int)(threadIdx.x >> 6); r < ro::RC_TM; r += GS * 4) ro::mg_layernorm_row<CM, (OCC < 6)>(a, tab, r);      // 16 rows over GS members x 4 waves
         } break;
         case MOP_XATTN: {
           const auto& a = MG_AS4(XAttnArgs, &op->u);

@@ -788,45 +788,96 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
     const bool live = r < tb.nvalid;
     const RowId id = row_id(tb, live ? r : 0);
     float* wrow = win + (live ? r + (tb.row_seg[r] + 1) * halo : 0) * LDX;      // (tab[r] is the row's OLDEST tap; its own row is halo rows on)
-    float4 v[8];                                          // Cin <= 512: 8 float4 per lane
-    float sum = 0.f, sa = 0.f;
+    // (NQ = Cin / 64 16-byte columns per lane; gamma / beta / the mask are fetched unconditionally and FIRST - inside `if (c < Cin)`
+    // branches hipcc serialises them with full waits, 2.3 us of an operator's 10)
+    auto norm = [&](auto nq_c) __attribute__((always_inline)) {
+      constexpr int NQ = decltype(nq_c)::value;
+      float4 g[NQ], bb[NQ], v[NQ];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = (l16 + 16 * q) * 4;
-      v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
-      sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
-    const float mean = sum / (float)Cin;
-    float var = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int c = (l16 + 16 * q) * 4;
-      if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
-    const float rstd = 1.0f / sqrtf(var / (float)Cin + a_eps);
-    if (live) {
-      const bool mine = (r % nact) == sb;
+      for (int q = 0; q < NQ; ++q) { g[q] = ldw4(a_gamma + (l16 + 16 * q) * 4); bb[q] = ldw4(a_beta + (l16 + 16 * q) * 4); }
       float mk = 1.f;
-      if (a_has_lnmask) { const TRef LM = as_copy<TRef>(a.lnmask); mk = ld1<CM>(row(LM, id.i, id.slot, id.pos, id.t)); }
-      float* hrow = row(HL, id.i, id.slot, id.pos, id.t);
+      {
+        const float* pm = a_gamma;
+        if (a_has_lnmask) { const TRef LM = as_copy<TRef>(a.lnmask); pm = row(LM, id.i, id.slot, id.pos, id.t); }
+        const float mv = ld1<CM>(pm);
+        if (a_has_lnmask) mk = mv;
+      }
+      float sum = 0.f, sa = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = (l16 + 16 * q) * 4;
-        if (c < Cin) {
-          const float4 g = ldw4(a_gamma + c), bb = ldw4(a_beta + c);
-          const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
-                                       ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
+      for (int q = 0; q < NQ; ++q) {
+        v[q] = live ? *reinterpret_cast<const float4*>(wrow + (l16 + 16 * q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
+      const float mean = sum / (float)Cin;
+      float var = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+      const float rstd = 1.0f / sqrtf(var / (float)Cin + a_eps);
+      if (live) {
+        const bool mine = (r % nact) == sb;
+        float* hrow = row(HL, id.i, id.slot, id.pos, id.t);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int c = (l16 + 16 * q) * 4;
+          const float4 o = make_float4(((v[q].x - mean) * rstd * g[q].x + bb[q].x) * mk, ((v[q].y - mean) * rstd * g[q].y + bb[q].y) * mk,
+                                       ((v[q].z - mean) * rstd * g[q].z + bb[q].z) * mk, ((v[q].w - mean) * rstd * g[q].w + bb[q].w) * mk);
           *reinterpret_cast<float4*>(wrow + c) = o;
           if (mine) st4<CM>(hrow + c, o);
         }
+        if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
       }
-      if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
-    }
+    };
+    // (the generic form - any Cin up to 512, gamma / beta fetched column by column - where the registers of the form above are not
+    // there: the 80-register build, and 512-channel inputs)
+    auto norm_any = [&]() __attribute__((always_inline)) {
+      float4 v[8];
+      float sum = 0.f, sa = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        v[q] = (live && c < Cin) ? *reinterpret_cast<const float4*>(wrow + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        sa += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sa += __shfl_xor(sa, o); }
+      const float mean = sum / (float)Cin;
+      float var = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = (l16 + 16 * q) * 4;
+        if (c < Cin) { const float d0 = v[q].x - mean, d1 = v[q].y - mean, d2 = v[q].z - mean, d3 = v[q].w - mean; var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+      const float rstd = 1.0f / sqrtf(var / (float)Cin + a_eps);
+      if (live) {
+        const bool mine = (r % nact) == sb;
+        float mk = 1.f;
+        if (a_has_lnmask) { const TRef LM = as_copy<TRef>(a.lnmask); mk = ld1<CM>(row(LM, id.i, id.slot, id.pos, id.t)); }
+        float* hrow = row(HL, id.i, id.slot, id.pos, id.t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = (l16 + 16 * q) * 4;
+          if (c < Cin) {
+            const float4 g = ldw4(a_gamma + c), bb = ldw4(a_beta + c);
+            const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
+                                         ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
+            *reinterpret_cast<float4*>(wrow + c) = o;
+            if (mine) st4<CM>(hrow + c, o);
+          }
+        }
+        if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
+      }
+    };
+    const int nq = Cin >> 6;       // (Cin = 64 .. 512, a power of two: rowconv_supported)
+    if (WIDE && nq == 4) norm(std::integral_constant<int, 4>{});
+    else norm_any();
     __syncthreads();
   }
 }
@@ -848,6 +899,23 @@ __device__ __forceinline__ float mg_wwarm(const A& a, const int bx) {
   const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
   const float* wl = a.w + (long long)ct0 * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
   return ct0 * 16 < a.Cout_pad ? ldw1(wl) : 0.f;
+}
+
+// the wave's first weight fragments of strip bx, requested in front of the window gather (the 128-register build): every operator's
+// weights are cold - in xcd mode one XCD streams the whole model through its 4 MB L2 - and the stream's first round trip to memory
+// otherwise follows the gather's instead of overlapping it
+template <int KW, class A>
+__device__ __forceinline__ void mg_wpre(const A& a, const int bx, float4 (&bw)[(KW > 1) ? 4 : 8]) {
+  constexpr int RC_D = (KW > 1) ? 4 : 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
+  const int ct0 = KW > 1 ? bx : bx * 4 + wave;
+  const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
+  // (column tiles past the padded width: the tensor's first tile - in bounds, unused)
+  const float* wl = a.w + (long long)(ct0 * 16 < a.Cout_pad ? ct0 : 0) * ((long long)(a.ktaps + 1) * KQ * 256) + lane * 4;
+#pragma unroll
+  for (int u = 0; u < RC_D; ++u) bw[u] = ldw4(wl + (long long)(g_lo + u) * 256);
 }
 
 template <int KW, bool PRE, int CM = 1, bool PF = false, class A>
@@ -1167,9 +1235,96 @@ __device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, co
 }
 
 // LayerNorm of tile row r (one wave)
-template <int CM = 1, class A>
+// C = 256 or 512: a lane holds 4 consecutive channels per 256 - every access 16 bytes wide, every load unconditional and in flight
+// before the first is consumed (partial tensors: eight at a time, summed in member order)
+template <int NV, int CM, class A>
+__device__ __forceinline__ void mg_layernorm_row_v(const A& a, const RowTab& tb, const int r) {
+  const int lane = threadIdx.x & 63;
+  const RowId id = row_id(tb, r);
+  const int C = NV * 256;
+  const int xparts = a.xparts, has_pre = a.has_pre, has_post = a.has_post, has_m1 = a.has_m1, has_m2 = a.has_m2, has_mask_out = a.has_mask_out, has_xres = a.has_xres;
+  const float* const gamma = a.gamma; const float* const beta = a.beta; const float* const xbias = a.xbias;
+  const float eps = a.eps;
+  const TRef Y = as_copy<TRef>(a.y);
+  float4 g[NV], bb[NV], v[NV], pre[NV], post[NV];
+#pragma unroll
+  for (int m = 0; m < NV; ++m) { g[m] = ldw4(gamma + lane * 4 + 256 * m); bb[m] = ldw4(beta + lane * 4 + 256 * m); }
+  const float* dummy = gamma;
+  const float* ppre = dummy; const float* ppost = dummy; const float* pm1 = dummy; const float* pm2 = dummy;
+  if (has_pre) { const TRef R = as_copy<TRef>(a.pre); ppre = row(R, id.i, id.slot, id.pos, id.t); }
+  if (has_post) { const TRef R = as_copy<TRef>(a.post); ppost = row(R, id.i, id.slot, id.pos, id.t); }
+  if (has_m1) { const TRef R = as_copy<TRef>(a.m1); pm1 = row(R, id.i, id.slot, id.pos, id.t); }
+  if (has_m2) { const TRef R = as_copy<TRef>(a.m2); pm2 = row(R, id.i, id.slot, id.pos, id.t); }
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    pre[m] = ld4<CM>(has_pre ? ppre + lane * 4 + 256 * m : dummy);
+    post[m] = ld4<CM>(has_post ? ppost + lane * 4 + 256 * m : dummy);
+  }
+  const float m1v = ld1<CM>(pm1), m2v = ld1<CM>(pm2);
+  if (xparts > 0) {       // x = the sum of the group members' partial tensors (+ bias, + residual), in member order
+    const float* const xp = a.xp; const long long xps = a.xp_stride;
+    const long long off = (long long)(id.i * a.T + id.t) * a.xp_ld + lane * 4;
+    const float* pres = dummy;
+    if (has_xres) { const TRef R = as_copy<TRef>(a.xres); pres = row(R, id.i, id.slot, id.pos, id.t); }
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const float4 xr = ld4<CM>(has_xres ? pres + lane * 4 + 256 * m : dummy);
+      const float4 xb = ldw4(xbias ? xbias + lane * 4 + 256 * m : dummy);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p0 = 0; p0 < xparts; p0 += 8) {
+        float4 q8[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) q8[p] = ld4<CM>(xp + (long long)(p0 + p < xparts ? p0 + p : 0) * xps + off + 256 * m);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) if (p0 + p < xparts) {
+          if (p0 + p == 0) acc = q8[p];
+          else { acc.x += q8[p].x; acc.y += q8[p].y; acc.z += q8[p].z; acc.w += q8[p].w; }
+        }
+      }
+      if (xbias) { acc.x += xb.x; acc.y += xb.y; acc.z += xb.z; acc.w += xb.w; }
+      if (has_xres) { acc.x += xr.x; acc.y += xr.y; acc.z += xr.z; acc.w += xr.w; }
+      v[m] = acc;
+    }
+  } else {
+    const TRef X = as_copy<TRef>(a.x);
+    const float* x = row(X, id.i, id.slot, id.pos, id.t);
+#pragma unroll
+    for (int m = 0; m < NV; ++m) v[m] = ld4<CM>(x + lane * 4 + 256 * m);
+  }
+  float s = 0.f, sa = 0.f;
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    sa += (fabsf(v[m].x) + fabsf(v[m].y)) + (fabsf(v[m].z) + fabsf(v[m].w));
+    if (has_pre) { v[m].x += pre[m].x; v[m].y += pre[m].y; v[m].z += pre[m].z; v[m].w += pre[m].w; }
+    s += (v[m].x + v[m].y) + (v[m].z + v[m].w);
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int m = 0; m < NV; ++m) { const float d0 = v[m].x - mean, d1 = v[m].y - mean, d2 = v[m].z - mean, d3 = v[m].w - mean; q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+  const float mk = (has_m1 ? m1v : 1.f) * (has_m2 ? m2v : 1.f);
+  if (has_mask_out) {
+    sa = wave_sum(sa);
+    if (lane == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
+  }
+  float* y = row(Y, id.i, id.slot, id.pos, id.t);
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    float4 o = make_float4((v[m].x - mean) * rstd * g[m].x + bb[m].x, (v[m].y - mean) * rstd * g[m].y + bb[m].y,
+                           (v[m].z - mean) * rstd * g[m].z + bb[m].z, (v[m].w - mean) * rstd * g[m].w + bb[m].w);
+    if (has_m1 | has_m2) { o.x *= mk; o.y *= mk; o.z *= mk; o.w *= mk; }
+    if (has_post) { o.x += post[m].x; o.y += post[m].y; o.z += post[m].z; o.w += post[m].w; }
+    st4<CM>(y + lane * 4 + 256 * m, o);
+  }
+}
+
+template <int CM = 1, bool WIDE = false, class A>
 __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, const int r) {
   if (r >= tb.nvalid) return;
+  if constexpr (WIDE) { if (a.C == 256) { mg_layernorm_row_v<1, CM>(a, tb, r); return; } }      // (the 128-register build)
   const int lane = threadIdx.x & 63;
   const RowId id = row_id(tb, r);
   const float* x = row(a.x, id.i, id.slot, id.pos, id.t);
@@ -1265,8 +1420,9 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
       float sc = 0.f;
       for (int d0 = 0; d0 < dh / 4; d0 += 8) {
         float4 k4[8];
+        // (unconditional: past the head's last column the first one once more, dropped below - a load inside a branch waits for every load before it)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) k4[u] = d0 + u < dh / 4 ? ldw4(kp + 4 * (d0 + u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 8; ++u) k4[u] = ldw4(kp + 4 * (d0 + u < dh / 4 ? d0 + u : 0));
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (d0 + u < dh / 4) { const float4 q4 = qp[d0 + u]; sc += q4.x * k4[u].x + q4.y * k4[u].y + q4.z * k4[u].z + q4.w * k4[u].w; }
       }
@@ -1290,7 +1446,7 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
       for (int s0 = 0; s0 < S; s0 += 8) {
         float vv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vv[u] = s0 + u < S ? ldw1(vp + (long long)(s0 + u) * 2 * a.E) : 0.f;
+        for (int u = 0; u < 8; ++u) vv[u] = ldw1(vp + (long long)(s0 + u < S ? s0 + u : 0) * 2 * a.E);      // (unconditional, see above)
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (s0 + u < S) acc += sp[h][s0 + u] * vv[u];       // (the same additions in the same order as the serial loop)
       }

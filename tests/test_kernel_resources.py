@@ -75,10 +75,12 @@ def test_co_residency_budgets(tmp_path):
     # (round 5: the operators fetch their arguments in one batch of scalar loads per phase instead of one load + wait per use - 14 % off
     # the decoder step at 64 streams; the SGPRs that batch occupies push four vector registers of per-operator state to scratch, written
     # and read once per operator, outside the gather and K loops)
-    assert mega_w["spill"] <= 8 and mega_w["scratch"] <= 64, mega_w
+    # (the K-split single-tile operators - never executed by this build's grids, but part of the same function - hold their 4-deep
+    # weight ring across the window gather: a few more)
+    assert mega_w["spill"] <= 12 and mega_w["scratch"] <= 72, mega_w
     # xcd mode (single-tile steps: the group forms at run time on one XCD, decoder_mega.hip) runs the same 128-register build
     mega_x = _find(ks, "decoder_mega_kernelILi4ELi2E")
-    assert gran(mega_x["vgpr"] + mega_x["agpr"]) <= 128 and mega_x["lds"] == 0 and mega_x["spill"] <= 8 and mega_x["scratch"] <= 64, mega_x
+    assert gran(mega_x["vgpr"] + mega_x["agpr"]) <= 128 and mega_x["lds"] == 0 and mega_x["spill"] <= 12 and mega_x["scratch"] <= 72, mega_x
     mega_lds = (96 + 32 * 264) * 4            # row table + the k = 5, 256-channel window (= the fused feed-forward's window + hidden tile)
     pair = _find(ks, "resblock_pair_kernelILi2E")
     assert pair["spill"] == 0 and pair["scratch"] == 0
