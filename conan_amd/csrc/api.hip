@@ -124,11 +124,12 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
                               conan_streams** out) {
   return guarded([&] {
     if (!ctx || !out) throw Error(CONAN_ERR_INVALID, "null argument");
-    int arith = CONAN_ARITH_AUTO;
+    int arith = CONAN_ARITH_AUTO, flags = 0;
     if (opts) {
       if (opts->abi_version != CONAN_HIP_ABI_VERSION) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.abi_version mismatch");
       for (int r : opts->reserved) if (r != 0) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.reserved must be 0");
-      arith = opts->arith;
+      arith = opts->arith; flags = opts->flags;
+      if (flags & ~(CONAN_STREAMS_FUSED_DECODER_BLOCKS | CONAN_STREAMS_SEPARATE_SMALL_STEPS | CONAN_STREAMS_VOCODER_CHAIN)) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.flags: unknown bits");
       if (arith != CONAN_ARITH_AUTO && arith != CONAN_ARITH_F32 && arith != CONAN_ARITH_LIMB) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.arith: 0 (auto), 1 (f32) or 2 (limb)");
     }
     if (!ctx->finalized) throw Error(CONAN_ERR_STATE, "conan_ctx_finalize must run before conan_streams_create");
@@ -156,6 +157,12 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
       s->rb_limb = arith == CONAN_ARITH_LIMB || (arith == CONAN_ARITH_AUTO && ctx->has_limb_weights && getenv("CONAN_RB_NOLIMB") == nullptr);
       // small stream-sets (one mel row tile per step) run the vocoder step as one persistent launch on the f32 MFMA (voc_chain.hip)
       // unless the caller asked for the limb arithmetic: AUTO resolves to F32 there (conan_streams_arith says so)
+      // deployment flags (conan_streams_opts.flags); the environment variables of earlier rounds stay as developer overrides
+      s->opt_flags = flags;
+      if (getenv("CONAN_MEGA_BLK")) s->opt_flags |= CONAN_STREAMS_FUSED_DECODER_BLOCKS;
+      { const char* e = getenv("CONAN_MEGA_SINGLE"); if (e && e[0] == '0') s->opt_flags |= CONAN_STREAMS_SEPARATE_SMALL_STEPS; }
+      { const char* e = getenv("CONAN_VOC_CHAIN"); if (e && e[0] == '1') s->opt_flags |= CONAN_STREAMS_VOCODER_CHAIN; }
+      s->mega_single = !(s->opt_flags & CONAN_STREAMS_SEPARATE_SMALL_STEPS);
       s->voc_chain = s->chain_eligible(arith == CONAN_ARITH_LIMB);
       if (s->voc_chain) s->rb_limb = false;
       { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
@@ -166,7 +173,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
       { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
       s->mega_x = reinterpret_cast<unsigned*>(s->alloc(256));
-      { const char* e = getenv("CONAN_MEGA_SINGLE"); if (e && e[0] == '0') s->mega_single = false; }
+
       {  // guard block of the bounded waits: [0] code, [2..3] device address of the host-mapped copy
         HIP_CHECK(hipHostMalloc((void**)&s->h_guard, 64, hipHostMallocMapped));
         memset(s->h_guard, 0, 64);

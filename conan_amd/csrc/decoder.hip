@@ -302,7 +302,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
   // job and sub-layer through sc1 loads: +100 MB of HBM fetches per step, 253 against 150 MB for the launch), which the vocoder's
   // kernels feel.  Throughput is the headline, so the fused form is OFF unless CONAN_MEGA_BLK=1 (developer switch, read per
   // recording; tests/test_gpu_round4.py runs it against the separate launches).
-  const bool blk_fuse_on = getenv("CONAN_MEGA_BLK") != nullptr;
+  const bool blk_fuse_on = (opt_flags & CONAN_STREAMS_FUSED_DECODER_BLOCKS) != 0;
   struct BlkParts { bool on = false; const float* xp = nullptr; const float* bias = nullptr; TRef xres, m1, m2; int has_m2 = 0; } bp;
   int pset = 0;
   auto blk_consume = [&](cnk::RowConvArgs& a, bool store) {

@@ -253,6 +253,7 @@ struct conan_streams {
   unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished
   unsigned* mega_x = nullptr;                    // xcd mode: election word, rank counter, "decided" counter, barrier flags (decoder_mega.hip)
   unsigned mega_xseq = 0, mega_xdec = 0;         // launches in xcd mode so far (24 bits), the decided counter's value once they have all finished
+  int opt_flags = 0;                             // conan_streams_opts.flags (+ the developer environment overrides)
   bool mega_single = true;                       // single-tile steps take the persistent launch (xcd mode); CONAN_MEGA_SINGLE=0: separate launches
   unsigned long long* mega_dbg = nullptr;        // CONAN_MEGA_STAMPS=1: per-operator clock stamps of the last launch (printed at destruction)
   int mega_dbg_prog = -1;                        // index into mega_cache (the vector may reallocate)

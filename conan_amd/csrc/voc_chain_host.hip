@@ -27,11 +27,12 @@ const float* conan_ctx::chain_weight(const std::string& name) {
 // MEASURED (round 5, MI355X, DESIGN.md §4 "voc_chain"): parity-green (9e-7 against the launch plans, ragged steps included) but NOT
 // faster - 0.40-0.42 ms per one-stream step against 0.35 ms of the 28 launches, 0.70 against 0.44 ms at four streams: 30 dependent
 // phases of ~13 us (hand-off through memory 3 + gather 2 + the job's MFMAs, 2.8 us at one CU for a k = 11 tile, + slice sums and
-// stores 1.6 + skew) cost what the launches do.  So the launch plans stay the default; CONAN_VOC_CHAIN=1 selects the chain.
+// stores 1.6 + skew) cost what the launches do.  So the launch plans stay the default; conan_streams_opts.flags
+// CONAN_STREAMS_VOCODER_CHAIN (developer override CONAN_VOC_CHAIN=1) selects the chain.
 bool conan_streams::chain_eligible(bool limb_requested) const {
   const conan_cfg& c = ctx->cfg;
   if (!(c.models & CONAN_MODEL_HIFIGAN) || limb_requested) return false;
-  { const char* e = getenv("CONAN_VOC_CHAIN"); if (!(e && e[0] == '1')) return false; }
+  if (!(opt_flags & CONAN_STREAMS_VOCODER_CHAIN)) return false;
   if ((long long)max_slots * max_frames > kChainRows || max_slots > 16) return false;
   if (c.voc_upsample != 0 || c.voc_resblock == 2 || c.voc_num_resblocks > kMaxBranches) return false;
   if (2 + c.voc_num_ups * (1 + 2 * c.voc_rb_num_dil) > cnk::VC_MAX_PHASES || 1 + 2 * c.voc_num_ups > cnk::VC_MAX_TAPS) return false;

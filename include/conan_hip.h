@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 6
+#define CONAN_HIP_ABI_VERSION 7
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -131,10 +131,23 @@ int conan_streams_destroy(conan_streams* s);
  *                     (ResBlock1 stages; upsamplers whose tiles fill the chip), F32 elsewhere (ResBlock2, decoder, Emformer).
  * The choice is a property of the stream-set, fixed at creation, reported by conan_streams_arith(). */
 typedef enum conan_arith { CONAN_ARITH_AUTO = 0, CONAN_ARITH_F32 = 1, CONAN_ARITH_LIMB = 2 } conan_arith;
+/* Deployment choices of a stream-set (conan_streams_opts.flags; ABI 7 - until round 4 environment variables):
+ *   CONAN_STREAMS_FUSED_DECODER_BLOCKS  the decoder's conv blocks [LN -> k5 conv -> GELU] -> [1x1 conv + residual] as ONE operator each
+ *                                       of the persistent decoder launch: 2 % less blocking latency at 64 streams, 1.4 % MORE time per
+ *                                       pipelined step (every group member reads eight partial tensors) - for latency-bound serving;
+ *   CONAN_STREAMS_SEPARATE_SMALL_STEPS  decoder steps of a single row tile (slots x frames <= 16: one to four streams) as ~38
+ *                                       separate launches instead of the persistent launch in xcd mode (0.41 against
+ *                                       0.28 ms per one-stream step) - an A/B switch, and a way out on parts whose workgroup -> XCD
+ *                                       placement gives an XCD fewer than 8 workgroups of a 256-workgroup launch;
+ *   CONAN_STREAMS_VOCODER_CHAIN         the vocoder step of a small stream-set (slots x frames <= 16) as one persistent launch
+ *                                       (voc_chain.hip) - parity-green but measured SLOWER than the launch plans (0.40 against 0.35 ms
+ *                                       at one stream), hence opt-in; f32 arithmetic only (ignored when arith = LIMB). */
+enum { CONAN_STREAMS_FUSED_DECODER_BLOCKS = 1, CONAN_STREAMS_SEPARATE_SMALL_STEPS = 2, CONAN_STREAMS_VOCODER_CHAIN = 4 };
 typedef struct conan_streams_opts {
   int32_t abi_version;   /* must be CONAN_HIP_ABI_VERSION */
   int32_t arith;         /* conan_arith */
-  int32_t reserved[6];   /* must be 0 */
+  int32_t flags;         /* bitwise or of CONAN_STREAMS_* (0: the defaults) */
+  int32_t reserved[5];   /* must be 0 */
 } conan_streams_opts;
 /* conan_streams_create with options (opts == NULL: all defaults, i.e. conan_streams_create). */
 int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, const conan_streams_opts* opts,

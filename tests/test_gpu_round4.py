@@ -106,7 +106,8 @@ def test_arith_option_through_the_c_abi():
     assert ctx.lib.conan_streams_arith(h) == _lib.ARITH_LIMB
     ctx.lib.conan_streams_destroy(h)
     for opts, code in ((_lib.StreamsOpts(_lib.ABI_VERSION, 7), _lib.ERR_INVALID), (_lib.StreamsOpts(_lib.ABI_VERSION - 1, 0), _lib.ERR_INVALID),
-                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, (C.c_int32 * 6)(0, 0, 1, 0, 0, 0)), _lib.ERR_INVALID)):
+                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 0, (C.c_int32 * 5)(0, 0, 1, 0, 0)), _lib.ERR_INVALID),
+                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 64), _lib.ERR_INVALID)):      # (an unknown flag bit)
         assert ctx.lib.conan_streams_create_opts(ctx.h, 2, 4, 16, C.byref(opts), C.byref(h)) == code
     with pytest.raises(ValueError):
         ctx.streams(2, arith="bf16")

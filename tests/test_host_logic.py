@@ -284,7 +284,8 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
                    '         sizeof(conan_streams_opts), sizeof(void*));\n'
                    '  printf("%d %d %d %d\\n", CONAN_HIP_ABI_VERSION, CONAN_ARITH_AUTO, CONAN_ARITH_F32, CONAN_ARITH_LIMB);\n'
                    '  printf("%d %d %d %d %d %d %d\\n", CONAN_OK, CONAN_ERR_INVALID, CONAN_ERR_MISSING, CONAN_ERR_SHAPE, CONAN_ERR_HIP, CONAN_ERR_STATE, CONAN_ERR_UNSUPPORTED);\n'
-                   '  printf("%d %d %d %d\\n", CONAN_MAX_UPS, CONAN_MAX_RESBLOCKS, CONAN_MAX_DILATIONS, CONAN_MAX_DEC_BLOCKS);\n  return 0;\n}\n')
+                   '  printf("%d %d %d %d\\n", CONAN_MAX_UPS, CONAN_MAX_RESBLOCKS, CONAN_MAX_DILATIONS, CONAN_MAX_DEC_BLOCKS);\n'
+                   '  printf("%d %d %d\\n", CONAN_STREAMS_FUSED_DECODER_BLOCKS, CONAN_STREAMS_SEPARATE_SMALL_STEPS, CONAN_STREAMS_VOCODER_CHAIN);\n  return 0;\n}\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.dirname(_lib.HEADER_PATH), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
@@ -293,5 +294,6 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
     assert [int(x) for x in out[1].split()] == [_lib.ABI_VERSION, _lib.ARITH_AUTO, _lib.ARITH_F32, _lib.ARITH_LIMB]
     assert [int(x) for x in out[2].split()] == [_lib.OK, _lib.ERR_INVALID, _lib.ERR_MISSING, _lib.ERR_SHAPE, _lib.ERR_HIP, _lib.ERR_STATE, _lib.ERR_UNSUPPORTED]
     assert [int(x) for x in out[3].split()] == [_lib.MAX_UPS, _lib.MAX_RESBLOCKS, _lib.MAX_DILATIONS, _lib.MAX_DEC_BLOCKS]
+    assert [int(x) for x in out[4].split()] == [_lib.STREAMS_FUSED_DECODER_BLOCKS, _lib.STREAMS_SEPARATE_SMALL_STEPS, _lib.STREAMS_VOCODER_CHAIN]
     # every entry point the header declares has a prototype in the binding, and the other way round
     assert sorted(_lib._PROTOS) == _lib.declared_symbols()
