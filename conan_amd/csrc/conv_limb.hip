@@ -103,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
       const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil, S = TM / Tt, wr = S * wrs;
       const int m0 = mt * TM, i0 = m0 / T, ta = m0 - i0 * T;
+      const int nsl = CL_SEL(q, n);
       const bool ring = CL_SEL(q, x.mode) == 0;
       const float* xb = CL_SEL(q, x.base);
       const int xC = CL_SEL(q, x.C), xmask = ring ? CL_SEL(q, x.lmask) : -1, xrate = CL_SEL(q, x.rate), xoff = CL_SEL(q, x.off) - CL_SEL(q, pad_left);
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         roff[u] = -1; loff[u] = 0;
         if (idx < total) {
           const int w = idx >> 3, c4 = idx & 7, s = w / wrs, o = w - s * wrs;
-          const int i = i0 + s, slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
+          // (a last tile with fewer slots than it has room for - an odd number of streams in 2-slot tiles - stages its last slot twice)
+          const int i = min(i0 + s, nsl - 1), slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
           const int row = ((ring ? pv * xrate : 0) + xoff + ta + o) & xmask;
           roff[u] = (int)((long long)(ring ? slot : i) * xss) + row * xC + c4 * 4;
           loff[u] = w * CL_RS + c4 * 4;
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
     const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil;
     const int m0 = mt * TM, n0 = nt * TN;
+    const int nsl = CL_SEL(q, n), Mrows = nsl * T;
     const int nblk = Cin / 32, NB = nblk * k;
     const int ct0 = n0 / 16 + wc * NCW;
     const long long ct_stride = (long long)NB * 1536;            // elements per column tile
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const int* pos = CL_SEL(q, pos);
 #pragma unroll
       for (int r = 0; r < NRW; ++r) {
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T;
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = min(m / T, nsl - 1);      // (rows past the launch's last slot: computed, never stored)
         eslot[r] = slots ? *(gci)(slots + i) : i;
       }
 #pragma unroll
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         pre_b[c] = (bias && cc < Cout) ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < NRW; ++r) {
-          const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
+          const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = min(m / T, nsl - 1), t = m - (m / T) * T;
           const int rrow = ((rring ? epos[r] * rrate : 0) + roffs + t) & rmask;
           pre_r[r][c] = (hres && cc < Cout) ? cl_gload(rb + (long long)(rring ? eslot[r] : i) * rss + (long long)rrow * rC + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -354,12 +357,12 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const float y2s = CL_SEL(q, y2_slope);
 #pragma unroll
       for (int r = 0; r < NRW; ++r) {
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = min(m / T, nsl - 1), t = m - (m / T) * T;
         const int slot = eslot[r], pv = epos[r];
 #pragma unroll
         for (int c = 0; c < NCW; ++c) {
           const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
-          if (cc < Cout) {
+          if (cc < Cout && m < Mrows) {
             f32x4 o = acc[r][c] + pre_b[c];
             if (oact == ACT_LRELU) {
 #pragma unroll
@@ -437,11 +440,14 @@ void launch_cl(const ConvLimbGroup& g, int grid, size_t lds_bytes, hipStream_t s
   hipLaunchKernelGGL((conv_limb_kernel<NRW, NCW, RW, CW>), dim3(grid), dim3(512), lds_bytes, st, g);
 }
 
-bool shape_fits(const CLShape& s, const ConvArgs& a) {
+bool shape_fits(const CLShape& s, const ConvArgs& a, bool ragged_ok) {
   const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
   const long long M = (long long)a.n * a.T;
-  if (M % TM) return false;
-  if (a.T < TM ? (TM % a.T) != 0 : (a.T % TM) != 0) return false;
+  // (tiles of whole slots - T < TM - may end in a tile with fewer slots than it has room for: the grouped launches of the C = 256
+  // stage at an odd number of streams, which otherwise fell back to conv_mfma's small-M plan; a single problem - ups.1 - keeps the
+  // rule that its rows divide into tiles: ragged 160-row tiles measured 104 us against 70 us of its f32 launch.  Tiles inside a slot
+  // must divide it.)
+  if (a.T < TM ? ((TM % a.T) != 0 || (!ragged_ok && (M % TM) != 0)) : ((a.T % TM) != 0 || (M % TM) != 0)) return false;
   const int cols = ((a.Cout + 15) / 16) * 16;
   return cols % TN == 0;
 }
@@ -471,11 +477,11 @@ int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu) {
     double units = 0, umax = 0;
     long long tiles = 0;
     for (int q = 0; q < nprob && ok; ++q) {
-      ok = shape_fits(s, p[q]);
+      ok = shape_fits(s, p[q], nprob > 1);
       if (!ok) break;
       const int Tt = std::min(p[q].T, TM), wr = (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil);
       if (wr > 32 * CL_NIT || (size_t)2 * 3 * wr * CL_LDB * 2 > 126 * 1024) { ok = false; break; }
-      const long long t = ((long long)p[q].n * p[q].T / TM) * ((((p[q].Cout + 15) / 16) * 16) / TN);
+      const long long t = (((long long)p[q].n * p[q].T + TM - 1) / TM) * ((((p[q].Cout + 15) / 16) * 16) / TN);
       const double u = (double)p[q].ktaps * p[q].Cin * TM * TN;
       tiles += t; units += u * t; umax = std::max(umax, u);
     }
@@ -528,7 +534,7 @@ static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) 
     struct Tl { int q, mt, nt; double cost; };
     std::vector<Tl> tl;
     for (int q = 0; q < g.nprob; ++q) {
-      const int mts = (int)((long long)g.p[q].n * g.p[q].T / TM), nts = (((g.p[q].Cout + 15) / 16) * 16) / TN;
+      const int mts = (int)(((long long)g.p[q].n * g.p[q].T + TM - 1) / TM), nts = (((g.p[q].Cout + 15) / 16) * 16) / TN;
       // n-tile outermost: workgroups that run at the same time then share their weight columns' rows ... the m tiles of one
       // n tile are adjacent in the list
       for (int nt = 0; nt < nts; ++nt)
