@@ -138,7 +138,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
     conan_streams* s = new conan_streams();
     try {
       s->ctx = ctx; s->max_slots = max_slots; s->max_frames = std::max(max_frames, ctx->cfg.emf_segment); s->max_ref = std::max(4, max_ref_frames);
-      s->d_slots = (int*)s->alloc(max_slots); s->d_ident = (int*)s->alloc(max_slots); s->d_zero = (int*)s->alloc(max_slots);
+      s->d_slots = (int*)s->alloc(max_slots + 1); s->d_ident = (int*)s->alloc(max_slots + 1); s->d_zero = (int*)s->alloc(max_slots);
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
       s->sk_slab_floats = 8ll << 20; s->sk_max_tiles = 4096;
@@ -172,7 +172,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
       { const char* e = getenv("CONAN_FRONT_CUSTRIDE"); if (e && atoi(e) >= 2) s->use_mega = false; }
       { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
-      s->mega_x = reinterpret_cast<unsigned*>(s->alloc(256));
+      s->mega_x = reinterpret_cast<unsigned*>(s->alloc(256 + 32 * 64));
 
       {  // guard block of the bounded waits: [0] code, [2..3] device address of the host-mapped copy
         HIP_CHECK(hipHostMalloc((void**)&s->h_guard, 64, hipHostMallocMapped));
@@ -183,7 +183,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
         HIP_CHECK(hipMemcpy(s->d_guard + 2, &hdev, sizeof(hdev), hipMemcpyHostToDevice));
       }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
-      s->pin.init((size_t)max_slots);
+      s->pin.init((size_t)max_slots + 1);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
       std::vector<int> id(max_slots);
       for (int i = 0; i < max_slots; ++i) id[i] = i;

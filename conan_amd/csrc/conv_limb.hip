@@ -103,7 +103,6 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
       const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil, S = TM / Tt, wr = S * wrs;
       const int m0 = mt * TM, i0 = m0 / T, ta = m0 - i0 * T;
-      const int nsl = CL_SEL(q, n);
       const bool ring = CL_SEL(q, x.mode) == 0;
       const float* xb = CL_SEL(q, x.base);
       const int xC = CL_SEL(q, x.C), xmask = ring ? CL_SEL(q, x.lmask) : -1, xrate = CL_SEL(q, x.rate), xoff = CL_SEL(q, x.off) - CL_SEL(q, pad_left);
@@ -122,8 +121,9 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         roff[u] = -1; loff[u] = 0;
         if (idx < total) {
           const int w = idx >> 3, c4 = idx & 7, s = w / wrs, o = w - s * wrs;
-          // (a last tile with fewer slots than it has room for - an odd number of streams in 2-slot tiles - stages its last slot twice)
-          const int i = min(i0 + s, nsl - 1), slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
+          // (a last tile with fewer slots than it has room for - an odd number of streams in 2-slot tiles - reads slot-table entry n:
+          // the host keeps a copy of the last slot there, conan_streams::set_slots)
+          const int i = i0 + s, slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
           const int row = ((ring ? pv * xrate : 0) + xoff + ta + o) & xmask;
           roff[u] = (int)((long long)(ring ? slot : i) * xss) + row * xC + c4 * 4;
           loff[u] = w * CL_RS + c4 * 4;
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
     const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil;
     const int m0 = mt * TM, n0 = nt * TN;
-    const int nsl = CL_SEL(q, n), Mrows = nsl * T;
     const int nblk = Cin / 32, NB = nblk * k;
     const int ct0 = n0 / 16 + wc * NCW;
     const long long ct_stride = (long long)NB * 1536;            // elements per column tile
@@ -210,11 +209,17 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const int* pos = CL_SEL(q, pos);
 #pragma unroll
       for (int r = 0; r < NRW; ++r) {
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = min(m / T, nsl - 1);      // (rows past the launch's last slot: computed, never stored)
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T;      // (rows past the launch's last slot - slot-table entry n, a copy of the last one: computed, never stored)
         eslot[r] = slots ? *(gci)(slots + i) : i;
       }
 #pragma unroll
-      for (int r = 0; r < NRW; ++r) epos[r] = pos ? *(gci)(pos + eslot[r]) : 0;
+      for (int r = 0; r < NRW; ++r) {
+        // (a row past the launch's last slot - a ragged last tile - carries the sign bit in its frame counter: ring rows are masked, so
+        // every address formed from it stays in bounds, and the epilogue stores nothing for it.  No register of its own: this build is
+        // at its 192-register budget beside the decoder megakernel.)
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr;
+        epos[r] = (pos ? *(gci)(pos + eslot[r]) : 0) | (m / T < CL_SEL(q, n) ? 0 : (int)0x80000000);
+      }
     }
     // weight blocks in flight: four with one column tile per wave (a block is 6 * NRW MFMAs = 0.2 us of work there - two blocks
     // ahead is less than an L2 round trip under load), two with two
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         pre_b[c] = (bias && cc < Cout) ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < NRW; ++r) {
-          const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = min(m / T, nsl - 1), t = m - (m / T) * T;
+          const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
           const int rrow = ((rring ? epos[r] * rrate : 0) + roffs + t) & rmask;
           pre_r[r][c] = (hres && cc < Cout) ? cl_gload(rb + (long long)(rring ? eslot[r] : i) * rss + (long long)rrow * rC + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -357,12 +362,12 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
       const float y2s = CL_SEL(q, y2_slope);
 #pragma unroll
       for (int r = 0; r < NRW; ++r) {
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = min(m / T, nsl - 1), t = m - (m / T) * T;
+        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
         const int slot = eslot[r], pv = epos[r];
 #pragma unroll
         for (int c = 0; c < NCW; ++c) {
           const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
-          if (cc < Cout && m < Mrows) {
+          if (cc < Cout && pv >= 0) {
             f32x4 o = acc[r][c] + pre_b[c];
             if (oact == ACT_LRELU) {
 #pragma unroll

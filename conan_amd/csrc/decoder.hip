@@ -118,7 +118,13 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
       // (plain stores, L1-bypassing loads, flag barriers: ~1 us per operator instead of ~5 through memory), the others leave at once.
       e->xcd = njobs == 1;
       if (njobs == 1) { e->groups = 1; e->group_size = ctx->num_cu; }
-      else { e->group_size = mega_gs; e->groups = std::max(1, std::min(njobs, mega_grid / mega_gs)); }
+      else {
+        e->group_size = mega_gs; e->groups = std::max(1, std::min(njobs, mega_grid / mega_gs));
+        // (group-fastest layout: with a group count that is a multiple of 8 a group's members share an XCD - decoder_mega.hip, CM = 3;
+        // groups beyond the job count have no tile and only join the launch's last barrier)
+        const int padded = (e->groups + 7) / 8 * 8;
+        if (padded * mega_gs <= std::max(mega_grid, 64) && padded <= 32) e->groups = padded;
+      }
       e->nops = (int)ops.size(); e->barriers = nb; e->flops = mega_rec_flops;
       e->lds_bytes = e->xcd ? std::max(mega_rec_lds * 4, 84 * 1024) : mega_rec_lds * 4;
       // the arrival-counter barriers need every workgroup of the grid resident at once: never launch more than the device can hold

@@ -107,7 +107,8 @@ __device__ __forceinline__ void mg_barrier_xcd(unsigned* flags, const unsigned e
 // resident kernels (resblock_limb <= 192, conv_limb's streaming shapes <= 192) leave 2 x 192 + 128 = 512 - tests/test_kernel_resources.py.
 // CM = 2 (xcd mode, a single row tile in the step): the launch is one workgroup per CU; the workgroups that find themselves on the
 // XCD of workgroup 0 (HW_REG_XCC_ID - read, not assumed) form the ONE group that walks the program, the others leave at once.
-// xs: [0] election word, [16 .. 48) two sets of per-XCD arrival counters, [64 ..) the barrier flags.
+// xs: [0] election word, [16 .. 48) two sets of per-XCD arrival counters, [64 .. 128) the xcd group's barrier flags; CM = 3:
+// [128 .. 192) the groups' XCC masks, [256 ..) 32 flag words per group.
 template <int OCC, int CM>
 __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __restrict__ prog, const int nops, const int njobs, const int GS_,
                                                               const int* __restrict__ slots, const int* __restrict__ pos, const int n, const int T,
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
   __builtin_amdgcn_s_setprio(MG_PRIO);      // developer build
 #endif
   int GS = GS_;
-  unsigned xepoch = xseq << 8;
+  unsigned xepoch = xseq << 12;      // (barrier epochs: up to 4096 per launch, growing from launch to launch)
   if constexpr (CM == 2) {
     // Quorum election.  Every workgroup registers with its XCD (arrival rank r on that XCD's counter).  The XCD whose count first
     // reaches 32 - or, after ~4 us, the first XCD with at least 8 - is claimed (one compare-and-swap on the election word, which
@@ -172,10 +173,34 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
       ro::mg_keep(keep);
     }
   }
-  const int NG = CM == 2 ? 1 : (int)gridDim.x / GS, g = b / GS, sb = b - g * GS;      // groups, this workgroup's group and member index
+  // groups, this workgroup's group and member index.  CM = 3 (several row tiles): groups are laid out GROUP-fastest - workgroup b is
+  // member b / NG of group b % NG - so that with the dispatcher's round-robin over the 8 XCDs and a group count that is a multiple of
+  // 8 (the host pads it) all members of a group land on ONE XCD.  That is checked, not assumed: every member ORs its XCC id into the
+  // group's mask word; one bit set -> the group's activations stay in that XCD's L2 (plain stores, flag barriers: tab.l2 = 1),
+  // otherwise the group keeps the agent-scope protocol (write-through stores, counter barriers).
+  const int NG = CM == 2 ? 1 : (int)gridDim.x / GS;
+  const int g = CM == 3 ? b % NG : b / GS, sb = CM == 3 ? b / NG : b - g * GS;
+  if (threadIdx.x == 0) tab.l2 = CM == 2 ? 1 : 0;
   // developer stamps (CONAN_MEGA_STAMPS=1): workgroup 0 notes the 100 MHz clock at the start and behind every operator (+ barrier)
   if (dbg && b == 0 && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
   unsigned gtarget = 0;
+  int l2 = CM == 2 ? 1 : 0;
+  if constexpr (CM == 3) {
+    if (g < njobs) {
+      if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
+        __hip_atomic_fetch_or(xs + 128 + g, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget, guard);
+      if (threadIdx.x == 0) {
+        const unsigned m = __hip_atomic_load(xs + 128 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tab.l2 = (m & (m - 1u)) == 0u ? 1 : 0;
+      }
+      __syncthreads();
+      l2 = tab.l2;
+      if (dbg && sb == 0 && threadIdx.x == 0) dbg[700 + g] = 0x100u | (unsigned)l2 | (__hip_atomic_load(xs + 128 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16);
+    }
+  }
   for (int job = g; job < njobs; job += NG) {
     // row table of the job's tile: stream / frame / slot / frame counter of its rows (the same for every operator)
     __syncthreads();
@@ -191,10 +216,22 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           if (sb < nbx) {      // (members without a strip skip the gather as well)
             float4 bw[8];
             // (the 8-deep ring of this form held across the gather costs the 128-register build 20 spilled registers: L2 warm-up only)
-            const float warm = ro::mg_wwarm<1>(a, sb);
-            ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
-            ro::mg_keep(warm);
+            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+            if constexpr (OCC < 6) {
+              // (warm-up loads IN FRONT of the gather: vector-memory loads return in order, so the gather's L2 hits then wait for these
+              // misses - ~2 us in the stage - but the K loop runs out of a warm L2: 0.434 ms per 64-stream step against 0.451 with the
+              // warm-up behind the gather's loads and 0.459 with a single warm-up line)
+              const ro::Warm10 warm = ro::mg_wwarm_all<1>(a, sb);
+              ro::mg_stage<true, CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
+              ro::mg_keep(warm);
+            } else {
+              const float warm = ro::mg_wwarm<1>(a, sb);
+              ro::mg_stage<false, CM>(a, tab, lds, sb, nbx < GS ? nbx : GS);
+              ro::mg_keep(warm);
+            }
+            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 1] = __builtin_amdgcn_s_memrealtime();
             for (int bx = sb; bx < nbx; bx += GS) ro::mg_strip<1, false, CM, (OCC < 6)>(a, tab, bx, lds, bw);
+            if (dbg && b == 0 && threadIdx.x == 0) dbg[128 + o * 4 + 2] = __builtin_amdgcn_s_memrealtime();
           }
         } break;
         case MOP_RC114: {      // 16-column strips, K split over the waves (a single tile in the step)
@@ -265,6 +302,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
       if (o + 1 < nops) mg_prefetch_args(prog + o + 1);
       if (barrier && type != MOP_ADVANCE) {
         if constexpr (CM == 2) mg_barrier_xcd(xs + 64, ++xepoch, sb, GS, guard);
+        else if (CM == 3 && l2) mg_barrier_xcd(xs + 256 + g * 32, ++xepoch, sb, GS, guard);
         else { gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget, guard); }
       }
       if (dbg && b == 0 && threadIdx.x == 0 && job == g) dbg[1 + o] = __builtin_amdgcn_s_memrealtime();
@@ -285,7 +323,10 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
       if (threadIdx.x < 16) __hip_atomic_store(xs + 16 + ((xseq + 1u) & 1u) * 16 + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (threadIdx.x == 0) __hip_atomic_store(xs, (xseq & 0xfffffu) << 12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    else for (int q = threadIdx.x; q < NG; q += 256) __hip_atomic_store(gbar + q * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else for (int q = threadIdx.x; q < NG; q += 256) {
+      __hip_atomic_store(gbar + q * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (CM == 3) __hip_atomic_store(xs + 128 + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the groups' XCC masks
+    }
   }
   if (dbg && b == 0 && threadIdx.x == 0) dbg[1 + nops] = __builtin_amdgcn_s_memrealtime();
 }
@@ -301,8 +342,8 @@ int decoder_mega_lds_floats(const MegaOp& op, int rc_lds_floats) {
 // workgroups of the megakernel that one CU can hold at once with `lds_bytes` of dynamic LDS (its barriers need the whole grid resident)
 int decoder_mega_blocks_per_cu(int lds_bytes, bool wide_regs) {
   int nb = 0;
-  const hipError_t e = wide_regs ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<4, 1>, 256, (size_t)lds_bytes)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<6, 1>, 256, (size_t)lds_bytes);
+  const hipError_t e = wide_regs ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<4, 3>, 256, (size_t)lds_bytes)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, decoder_mega_kernel<6, 3>, 256, (size_t)lds_bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nb;
 }
@@ -314,11 +355,11 @@ void launch_decoder_mega(const MegaLaunch& m, hipStream_t st) {
     hipLaunchKernelGGL((decoder_mega_kernel<4, 2>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
                        m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, m.xdec_base);
   } else if (m.wide_regs)
-    hipLaunchKernelGGL((decoder_mega_kernel<4, 1>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, nullptr, 0u, 0u);
+    hipLaunchKernelGGL((decoder_mega_kernel<4, 3>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, 0u);
   else
-    hipLaunchKernelGGL((decoder_mega_kernel<6, 1>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, nullptr, 0u, 0u);
+    hipLaunchKernelGGL((decoder_mega_kernel<6, 3>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, 0u);
 }
 
 }  // namespace cnk

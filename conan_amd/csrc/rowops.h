@@ -44,16 +44,19 @@ template <int COH> __device__ __forceinline__ float ld1(const float* p) {
   if constexpr (COH != 0) return __hip_atomic_load((gcf1)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else return *(gcf1)(p);
 }
-template <int COH> __device__ __forceinline__ void st4(float* p, const float4 v) {
-  if constexpr (COH == 1) {
+// (COH = 3: the megakernel's groups decide at run time - l2 != 0: every member of the group sits on one XCD, stores as in mode 2)
+template <int COH> __device__ __forceinline__ void st4(float* p, const float4 v, const int l2 = 0) {
+  if constexpr (COH == 3) { if (l2) st4<2>(p, v); else st4<1>(p, v); }
+  else if constexpr (COH == 1) {
     __hip_atomic_store((gu64)(p), (u64)__float_as_uint(v.x) | ((u64)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((gu64)(p) + 1, (u64)__float_as_uint(v.z) | ((u64)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     *(gf4)(p) = (f32x4){v.x, v.y, v.z, v.w};
   }
 }
-template <int COH> __device__ __forceinline__ void st1(float* p, const float v) {
-  if constexpr (COH == 1) __hip_atomic_store((gf1)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <int COH> __device__ __forceinline__ void st1(float* p, const float v, const int l2 = 0) {
+  if constexpr (COH == 3) { if (l2) st1<2>(p, v); else st1<1>(p, v); }
+  else if constexpr (COH == 1) __hip_atomic_store((gf1)(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *(gf1)(p) = v;
 }
 // read-only data (weights, biases, per-utterance caches, slot tables, frame counters)
@@ -612,6 +615,7 @@ struct RowTab {
   int row_seg[RC_TM];                     // segment of tile row r
   int seg_i[RC_MAXSEG + 1], seg_t0[RC_MAXSEG + 1], seg_r0[RC_MAXSEG + 1], seg_slot[RC_MAXSEG + 1], seg_pos[RC_MAXSEG + 1];
   int tab[RC_TM];                         // per operator: window row of tile row r at tap 0
+  int l2;                                 // the group's members sit on ONE XCD (decoder_mega.hip: activations stay in its L2 - plain stores, flag barriers)
 };
 constexpr int ROWTAB_FLOATS = 96;
 static_assert(sizeof(RowTab) <= ROWTAB_FLOATS * 4, "row table");
@@ -661,8 +665,11 @@ __device__ __forceinline__ T as_copy(const S& src) {
 // `first` (the member that owns strip 0) appends the normalised rows to the layer's ring and writes the block mask
 // (sb of nact: this member's index among the members that stage this operator - the normalised rows they all compute are
 // appended to the layer's ring / the block mask is written by member row % nact, so that no single member carries the stores)
-template <bool WIDE = false, int CM = 1, class A>
-__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const int sb, const int nact, unsigned long long* dbgp = nullptr) {
+struct NoWarm { __device__ __forceinline__ void operator()() const {} };
+// `warm`: called once, right BEHIND the first pass's loads and in front of their use - L2 warm-up loads of the operator's weights.
+// (Vector-memory loads return in order: warm-up loads issued in front of the gather made its L2 hits wait for their misses.)
+template <bool WIDE = false, int CM = 1, class A, class WF = NoWarm>
+__device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restrict__ win, const int sb, const int nact, WF&& warm = WF{}) {
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));             // (no hoisting of per-lane arithmetic out of this function: the 80-register bound is tight)
   const int lane = tid & 63;
@@ -707,6 +714,7 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
     float4 v[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) v[u] = ld4<CM>(src + 32 * u);
+    if (w0 == 0 && u0 == 0) warm();
     const float isl = a_in_lrelu ? a_in_slope : 1.0f;
     float* const dst = win + wc * LDX + (j8 + 8 * u0) * 4;
     if (inw && !part) {
@@ -770,7 +778,7 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
         if (e < nq) {
           *reinterpret_cast<float4*>(win + (rr[b] + (tb.row_seg[rr[b]] + 1) * halo) * LDX + cc[b] * 4) = acc;
           // (the tensor itself, for the operator behind this one that adds it as its residual)
-          if (a.xstore && (rr[b] % nact) == sb) st4<CM>(row(a.x, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4, acc);
+          if (a.xstore && (rr[b] % nact) == sb) st4<CM>(row(a.x, id[b].i, id[b].slot, id[b].pos, id[b].t) + cc[b] * 4, acc, tb.l2);
         }
       }
     }
@@ -827,9 +835,9 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
           const float4 o = make_float4(((v[q].x - mean) * rstd * g[q].x + bb[q].x) * mk, ((v[q].y - mean) * rstd * g[q].y + bb[q].y) * mk,
                                        ((v[q].z - mean) * rstd * g[q].z + bb[q].z) * mk, ((v[q].w - mean) * rstd * g[q].w + bb[q].w) * mk);
           *reinterpret_cast<float4*>(wrow + c) = o;
-          if (mine) st4<CM>(hrow + c, o);
+          if (mine) st4<CM>(hrow + c, o, tb.l2);
         }
-        if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
+        if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f, tb.l2); }
       }
     };
     // (the generic form - any Cin up to 512, gamma / beta fetched column by column - where the registers of the form above are not
@@ -869,10 +877,10 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
             const float4 o = make_float4(((v[q].x - mean) * rstd * g.x + bb.x) * mk, ((v[q].y - mean) * rstd * g.y + bb.y) * mk,
                                          ((v[q].z - mean) * rstd * g.z + bb.z) * mk, ((v[q].w - mean) * rstd * g.w + bb.w) * mk);
             *reinterpret_cast<float4*>(wrow + c) = o;
-            if (mine) st4<CM>(hrow + c, o);
+            if (mine) st4<CM>(hrow + c, o, tb.l2);
           }
         }
-        if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
+        if (a_has_mask_out && mine && l16 == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f, tb.l2); }
       }
     };
     const int nq = Cin >> 6;       // (Cin = 64 .. 512, a power of two: rowconv_supported)
@@ -890,6 +898,11 @@ __device__ __forceinline__ void mg_stage(const A& a, RowTab& tb, float* __restri
 // The loaded word is returned and must be kept alive (mg_keep) past the point where the weights are used: the register of a
 // load the compiler believes dead is reused while the load is still in flight.
 __device__ __forceinline__ void mg_keep(const float t) { asm volatile("" ::"v"(t)); }
+// (ten warm-up words: kept apart - summing them would wait for all ten round trips right where they were issued)
+struct Warm10 { float w[10]; };
+__device__ __forceinline__ void mg_keep(const Warm10& t) {
+  asm volatile("" ::"v"(t.w[0]), "v"(t.w[1]), "v"(t.w[2]), "v"(t.w[3]), "v"(t.w[4]), "v"(t.w[5]), "v"(t.w[6]), "v"(t.w[7]), "v"(t.w[8]), "v"(t.w[9]));
+}
 template <int KW, class A>
 __device__ __forceinline__ float mg_wwarm(const A& a, const int bx) {
   const int lane = threadIdx.x & 63;
@@ -899,6 +912,22 @@ __device__ __forceinline__ float mg_wwarm(const A& a, const int bx) {
   const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
   const float* wl = a.w + (long long)ct0 * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
   return ct0 * 16 < a.Cout_pad ? ldw1(wl) : 0.f;
+}
+// the WHOLE stream of the wave's strip (<= 80 KB: ten loads of one dword per 128-byte line) - with a group on one XCD that XCD
+// streams every layer's weights through its 4 MB L2 once per step, nothing is warm from the step before
+template <int KW, class A>
+__device__ __forceinline__ Warm10 mg_wwarm_all(const A& a, const int bx) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
+  const int ct0 = KW > 1 ? bx : bx * 4 + wave;
+  const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
+  const float* wl = a.w + (long long)(ct0 * 16 < a.Cout_pad ? ct0 : 0) * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
+  const int ng = KW > 1 ? NG / KW : NG;
+  Warm10 r;
+#pragma unroll
+  for (int u = 0; u < 10; ++u) r.w[u] = ldw1(wl + (long long)(8 * u < ng ? 8 * u : 0) * 256);
+  return r;
 }
 
 // the wave's first weight fragments of strip bx, requested in front of the window gather (the 128-register build): every operator's
@@ -1022,7 +1051,7 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
       if (a_has_m1 | a_has_m2) v *= pm;
       o[e] = v;
     }
-    st4<CM>(yptr, make_float4(o[0], o[1], o[2], o[3]));
+    st4<CM>(yptr, make_float4(o[0], o[1], o[2], o[3]), tb.l2);
   }
 }
 
@@ -1149,7 +1178,7 @@ __device__ __forceinline__ void mg_ffn(const A& a, const RowTab& tb, const int s
           const int r = 4 * lg + e;
           if (r >= tb.nvalid) continue;
           const RowId id = row_id(tb, r);
-          st1<CM>(pbase + (long long)(id.i * a.T + id.t) * a.Cout2 + col, acc0[e] + acc1[e]);
+          st1<CM>(pbase + (long long)(id.i * a.T + id.t) * a.Cout2 + col, acc0[e] + acc1[e], tb.l2);
         }
       }
     }
@@ -1229,7 +1258,7 @@ __device__ __forceinline__ void mg_rowlin_strip(const A& a, const RowTab& tb, co
       if (a.has_res) v += ld1<CM>(row(a.res, id.i, id.slot, id.pos, id.t) + col);
       if (a.has_m1) v *= ld1<CM>(row(a.m1, id.i, id.slot, id.pos, id.t));
       if (a.has_m2) v *= ld1<CM>(row(a.m2, id.i, id.slot, id.pos, id.t));
-      st1<CM>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v);
+      st1<CM>(row(a.y, id.i, id.slot, id.pos, id.t) + col, v, tb.l2);
     }
   }
 }
@@ -1308,7 +1337,7 @@ __device__ __forceinline__ void mg_layernorm_row_v(const A& a, const RowTab& tb,
   const float mk = (has_m1 ? m1v : 1.f) * (has_m2 ? m2v : 1.f);
   if (has_mask_out) {
     sa = wave_sum(sa);
-    if (lane == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f); }
+    if (lane == 0) { const TRef MO = as_copy<TRef>(a.mask_out); st1<CM>(row(MO, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f, tb.l2); }
   }
   float* y = row(Y, id.i, id.slot, id.pos, id.t);
 #pragma unroll
@@ -1317,7 +1346,7 @@ __device__ __forceinline__ void mg_layernorm_row_v(const A& a, const RowTab& tb,
                            (v[m].z - mean) * rstd * g[m].z + bb[m].z, (v[m].w - mean) * rstd * g[m].w + bb[m].w);
     if (has_m1 | has_m2) { o.x *= mk; o.y *= mk; o.z *= mk; o.w *= mk; }
     if (has_post) { o.x += post[m].x; o.y += post[m].y; o.z += post[m].z; o.w += post[m].w; }
-    st4<CM>(y + lane * 4 + 256 * m, o);
+    st4<CM>(y + lane * 4 + 256 * m, o, tb.l2);
   }
 }
 
@@ -1364,7 +1393,7 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
   if (a.has_m2) mk *= ld1<CM>(row(a.m2, id.i, id.slot, id.pos, id.t));
   if (a.has_mask_out) {
     sa = wave_sum(sa);
-    if (lane == 0) st1<CM>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f);
+    if (lane == 0) st1<CM>(row(a.mask_out, id.i, id.slot, id.pos, id.t), sa > 0.f ? 1.f : 0.f, tb.l2);
   }
   float* y = row(a.y, id.i, id.slot, id.pos, id.t);
   const float* post = a.has_post ? row(a.post, id.i, id.slot, id.pos, id.t) : nullptr;
@@ -1375,7 +1404,7 @@ __device__ __forceinline__ void mg_layernorm_row(const A& a, const RowTab& tb, c
       float o = (v[k] - mean) * rstd * ldw1(a.gamma + c) + ldw1(a.beta + c);
       if (a.has_m1 | a.has_m2) o *= mk;
       if (post) o += ld1<CM>(post + c);
-      st1<CM>(y + c, o);
+      st1<CM>(y + c, o, tb.l2);
     }
   }
 }
@@ -1390,7 +1419,7 @@ __device__ __forceinline__ void mg_embed_row(const A& a, const RowTab& tb, const
   idx = idx < 0 ? 0 : (idx >= a.vocab ? a.vocab - 1 : idx);
   float* y = row(a.y, id.i, id.slot, id.pos, id.t);
   const float* e = a.table + (long long)idx * a.C;
-  for (int c = lane; c < a.C; c += 64) st1<CM>(y + c, ldw1(e + c));
+  for (int c = lane; c < a.C; c += 64) st1<CM>(y + c, ldw1(e + c), tb.l2);
 }
 
 // cross attention of tile rows r0, r0 + 1 (two heads: waves 0-1 take row r0, waves 2-3 row r0 + 1); LDS: 2 x [sq 1024 | sp 2 x 512]
@@ -1450,7 +1479,7 @@ __device__ __forceinline__ void mg_xattn_rows(const A& a, const RowTab& tb, cons
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (s0 + u < S) acc += sp[h][s0 + u] * vv[u];       // (the same additions in the same order as the serial loop)
       }
-      st1<CM>(o + h * dh + d, acc);
+      st1<CM>(o + h * dh + d, acc, tb.l2);
     }
   }
 }
@@ -1495,7 +1524,7 @@ __device__ __forceinline__ void mg_pitch_row(const A& a, const RowTab& tb, const
   const float* pi = row(a.pitch_inp, id.i, id.slot, id.pos, id.t);
   float* di = row(a.dec_inp, id.i, id.slot, id.pos, id.t);
   const float* pe = a.pitch_embed + (long long)bin * a.E;
-  for (int c = lane; c < a.E; c += 64) st1<CM>(di + c, ld1<CM>(pi + c) + ldw1(pe + c));
+  for (int c = lane; c < a.E; c += 64) st1<CM>(di + c, ld1<CM>(pi + c) + ldw1(pe + c), tb.l2);
 }
 
 }  // namespace ro

@@ -252,6 +252,7 @@ struct conan_streams {
   unsigned* mega_bar = nullptr;                  // the grid barrier's arrival counter (counts for ever); the group counters follow it, 16 words apart
   unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished
   unsigned* mega_x = nullptr;                    // xcd mode: election word, rank counter, "decided" counter, barrier flags (decoder_mega.hip)
+  unsigned mega_gseq = 0;                        // multi-tile launches so far (epochs of their groups' flag barriers)
   unsigned mega_xseq = 0, mega_xdec = 0;         // launches in xcd mode so far (24 bits), the decided counter's value once they have all finished
   int opt_flags = 0;                             // conan_streams_opts.flags (+ the developer environment overrides)
   bool mega_single = true;                       // single-tile steps take the persistent launch (xcd mode); CONAN_MEGA_SINGLE=0: separate launches

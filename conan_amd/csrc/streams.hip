@@ -231,11 +231,16 @@ void conan_streams::mega_print_stamps() {
   constexpr int nnames = (int)(sizeof(names) / sizeof(names[0]));
   fprintf(stderr, "[decoder_mega] last launch: %d groups x %d workgroups, %d jobs, %d operators, %d group barriers, %.1f us in all (workgroup 0; first job per operator below)\n",
           e.groups, e.group_size, e.njobs, e.nops, e.barriers, (h[e.nops + 1] - h[0]) / 100.0);
+  if (!e.xcd) {
+    fprintf(stderr, "  groups on one XCD (l2 mode) / XCC masks:");
+    for (int g2 = 0; g2 < e.groups && g2 < 32; ++g2) if (h[700 + g2]) fprintf(stderr, " %d:%llu/%02llx", g2, h[700 + g2] & 1ull, (h[700 + g2] >> 16) & 0xffull);
+    fprintf(stderr, "\n");
+  }
   for (int o = 0; o < e.nops; ++o) {
     const cnk::MegaOp& op = e.pinned[o];
     fprintf(stderr, "  op %2d %-15s strips %4d  barrier %d  %7.2f us", o, (op.type >= 0 && op.type < nnames) ? names[op.type] : "?", op.nbx, op.barrier, (h[o + 1] - h[o]) / 100.0);
     if (op.type <= cnk::MOP_ROWLIN) fprintf(stderr, "   Cin %4d Cout %4d k %d ln %d", op.u.rc.Cin, op.u.rc.Cout, op.u.rc.ktaps, op.u.rc.ln);
-    if (op.type == cnk::MOP_RC114 && h[128 + o * 4]) fprintf(stderr, "   [args+warm %.2f stage %.2f strips %.2f barrier %.2f]", (h[128 + o * 4] - h[o]) / 100.0, (h[128 + o * 4 + 1] - h[128 + o * 4]) / 100.0,
+    if ((op.type == cnk::MOP_RC114 || op.type == cnk::MOP_RC111) && h[128 + o * 4]) fprintf(stderr, "   [args+warm %.2f stage %.2f strips %.2f barrier %.2f]", (h[128 + o * 4] - h[o]) / 100.0, (h[128 + o * 4 + 1] - h[128 + o * 4]) / 100.0,
                                                                (h[128 + o * 4 + 2] - h[128 + o * 4 + 1]) / 100.0, (h[o + 1] - h[128 + o * 4 + 2]) / 100.0);
     if (op.type == cnk::MOP_RC114 && h[512 + o * 4]) fprintf(stderr, " {stage: sync %.2f issue %.2f return+lds %.2f sync %.2f rest %.2f}", (h[512 + o * 4] - h[128 + o * 4]) / 100.0, (h[512 + o * 4 + 1] - h[512 + o * 4]) / 100.0,
                                                                (h[512 + o * 4 + 2] - h[512 + o * 4 + 1]) / 100.0, (h[512 + o * 4 + 3] - h[512 + o * 4 + 2]) / 100.0, (h[128 + o * 4 + 1] - h[512 + o * 4 + 3]) / 100.0);
@@ -261,7 +266,9 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
     return;
   }
   if (test_fault == 1) { m.bar_base += 1u; test_fault = 0; }       // test hook: the grid barrier waits for one arrival too many
-  profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 1>" : "cnk::decoder_mega_kernel<6, 1>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
+  mega_gseq = mega_gseq + 1u;             // (its own sequence: the xcd mode's election word tracks mega_xseq launch by launch)
+  m.xs = mega_x; m.xseq = mega_gseq;      // (the flag barriers of groups that sit on one XCD count in epochs of this sequence number)
+  profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 3>" : "cnk::decoder_mega_kernel<6, 3>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
 }
 
@@ -279,7 +286,9 @@ void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
     slot_seen[slots[i]] = slot_gen;
   }
   h_slots.assign(slots, slots + n);
-  pin.upload(d_slots, h_slots.data(), (size_t)n, st);
+  // (entry n = a copy of the last slot: conv_limb's 2-slot tiles read one slot past an odd count)
+  std::vector<int> up(h_slots); up.push_back(h_slots.back());
+  pin.upload(d_slots, up.data(), (size_t)n + 1, st);
 }
 
 // ------------------------------------------------------------------------------------------------ pipelined stepping

@@ -91,6 +91,28 @@ def test_xcd_mode_is_bit_reproducible_and_survives_concurrent_stream_sets():
     ctx.close()
 
 
+def test_single_tile_and_multi_tile_steps_interleave():
+    """One stream-set of 2 slots stepping 2, 16, 4, 8, 16, 2 frames after a reset each (windowed serving): 2 x 16 frames are two row
+    tiles - the multi-tile launch, groups of 8 - the others one tile - xcd mode.  The two forms keep their own launch sequences (the xcd
+    election word must be found in the state the last xcd launch left it in); every step equals the separate launches."""
+    ctx, chp, _ = _ctx(hifigan=False)
+    ids = [0, 1]
+    ref = torch.from_numpy(synth.mel(40, 60, 2)).cuda()
+    codes = torch.from_numpy(synth.codes(16, 2, seed=9)).int().cuda()
+    a = ctx.streams(2, max_frames=16, max_ref_frames=64)
+    b = ctx.streams(2, max_frames=16, max_ref_frames=64, flags=_lib.STREAMS_SEPARATE_SMALL_STEPS)
+    for st in (a, b):
+        st.reset(ids); st.set_reference(ids, ref)
+    for T in (2, 16, 4, 8, 16, 2):
+        for st in (a, b):
+            st.reset(ids, which=2)
+        c = codes[:, :T].contiguous()
+        np.testing.assert_allclose(a.decoder_step(ids, c).cpu().numpy(), b.decoder_step(ids, c).cpu().numpy(), atol=2e-5, rtol=1e-5)
+    names = kernels_of(a, lambda: a.decoder_step(ids, codes[:, :16].contiguous()))
+    assert any("decoder_mega_kernel<4, 3>" in k or "decoder_mega_kernel<6, 3>" in k for k in names), sorted(names)
+    a.close(); b.close(); ctx.close()
+
+
 def test_xcd_mode_election_fault_is_reported():
     """conan_streams_test_fault(1) on a single-tile stream-set: the election word is not in the state the launch expects, nobody can
     claim an XCD - every workgroup gives up after the 50 ms budget, the launch ends, the next entry point returns CONAN_ERR_HIP, and a

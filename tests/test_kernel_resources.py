@@ -67,20 +67,20 @@ def test_co_residency_budgets(tmp_path):
     # outside the K loops).
     # Two builds: <6> (80 registers) runs beside exact-f32 stream-sets' kernels, <4> (128 registers, no register spills) beside the
     # bf16-limb ones, which hold at most 192.
-    mega = _find(ks, "decoder_mega_kernelILi6ELi1E")
+    mega = _find(ks, "decoder_mega_kernelILi6ELi3E")
     assert gran(mega["vgpr"] + mega["agpr"]) <= 80 and mega["lds"] == 0
     assert mega["spill"] <= 40 and mega["scratch"] <= 160, mega
-    mega_w = _find(ks, "decoder_mega_kernelILi4ELi1E")
+    mega_w = _find(ks, "decoder_mega_kernelILi4ELi3E")
     assert gran(mega_w["vgpr"] + mega_w["agpr"]) <= 128 and mega_w["lds"] == 0
     # (round 5: the operators fetch their arguments in one batch of scalar loads per phase instead of one load + wait per use - 14 % off
     # the decoder step at 64 streams; the SGPRs that batch occupies push four vector registers of per-operator state to scratch, written
     # and read once per operator, outside the gather and K loops)
     # (the K-split single-tile operators - never executed by this build's grids, but part of the same function - hold their 4-deep
     # weight ring across the window gather: a few more)
-    assert mega_w["spill"] <= 12 and mega_w["scratch"] <= 72, mega_w
+    assert mega_w["spill"] <= 20 and mega_w["scratch"] <= 96, mega_w
     # xcd mode (single-tile steps: the group forms at run time on one XCD, decoder_mega.hip) runs the same 128-register build
     mega_x = _find(ks, "decoder_mega_kernelILi4ELi2E")
-    assert gran(mega_x["vgpr"] + mega_x["agpr"]) <= 128 and mega_x["lds"] == 0 and mega_x["spill"] <= 12 and mega_x["scratch"] <= 72, mega_x
+    assert gran(mega_x["vgpr"] + mega_x["agpr"]) <= 128 and mega_x["lds"] == 0 and mega_x["spill"] <= 20 and mega_x["scratch"] <= 96, mega_x
     mega_lds = (96 + 32 * 264) * 4            # row table + the k = 5, 256-channel window (= the fused feed-forward's window + hidden tile)
     pair = _find(ks, "resblock_pair_kernelILi2E")
     assert pair["spill"] == 0 and pair["scratch"] == 0
