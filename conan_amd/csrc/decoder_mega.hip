@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
       gtarget += (unsigned)GS; mg_barrier(gbar + g * 16, gtarget, guard);
       if (threadIdx.x == 0) {
         const unsigned m = __hip_atomic_load(xs + 128 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tab.l2 = (m & (m - 1u)) == 0u ? 1 : 0;
+        tab.l2 = ((m & (m - 1u)) == 0u && xdec_base == 0u) ? 1 : 0;      // (xdec_base != 0: developer switch CONAN_MEGA_NOL2 - the agent-scope protocol everywhere)
       }
       __syncthreads();
       l2 = tab.l2;
@@ -356,10 +356,10 @@ void launch_decoder_mega(const MegaLaunch& m, hipStream_t st) {
                        m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, m.xdec_base);
   } else if (m.wide_regs)
     hipLaunchKernelGGL((decoder_mega_kernel<4, 3>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, 0u);
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, m.xdec_base);
   else
     hipLaunchKernelGGL((decoder_mega_kernel<6, 3>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
-                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, 0u);
+                       m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, m.xdec_base);
 }
 
 }  // namespace cnk
