@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
   // group's mask word; one bit set -> the group's activations stay in that XCD's L2 (plain stores, flag barriers: tab.l2 = 1),
   // otherwise the group keeps the agent-scope protocol (write-through stores, counter barriers).
   const int NG = CM == 2 ? 1 : (int)gridDim.x / GS;
-  const int g = CM == 3 ? b % NG : b / GS, sb = CM == 3 ? b / NG : b - g * GS;
+  const bool gfast = CM == 3 && !(xdec_base & 2u);      // (xdec_base bit 1: member-fastest - member s of every group on XCD s)
+  const int g = gfast ? b % NG : b / GS, sb = gfast ? b / NG : b - g * GS;
   if (threadIdx.x == 0) tab.l2 = CM == 2 ? 1 : 0;
   // developer stamps (CONAN_MEGA_STAMPS=1): workgroup 0 notes the 100 MHz clock at the start and behind every operator (+ barrier)
   if (dbg && b == 0 && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();

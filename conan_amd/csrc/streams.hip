@@ -268,7 +268,9 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   if (test_fault == 1) { m.bar_base += 1u; test_fault = 0; }       // test hook: the grid barrier waits for one arrival too many
   mega_gseq = mega_gseq + 1u;             // (its own sequence: the xcd mode's election word tracks mega_xseq launch by launch)
   m.xs = mega_x; m.xseq = mega_gseq;      // (the flag barriers of groups that sit on one XCD count in epochs of this sequence number)
-  { static const bool nol2 = getenv("CONAN_MEGA_NOL2") != nullptr; m.xdec_base = nol2 ? 1u : 0u; }
+  { static const bool nol2 = getenv("CONAN_MEGA_NOL2") != nullptr;
+    static const bool mfast = getenv("CONAN_MEGA_LAYOUT") != nullptr && getenv("CONAN_MEGA_LAYOUT")[0] == 'm';
+    m.xdec_base = (nol2 ? 1u : 0u) | (mfast ? 2u : 0u); }
   profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 3>" : "cnk::decoder_mega_kernel<6, 3>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
 }
