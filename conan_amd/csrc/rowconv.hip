@@ -89,7 +89,8 @@ int rowconv_variant(const RowConvArgs& a) {
   if (a.Cin > 512) return 3;
   const int mt = (a.n * a.T + RC_TM - 1) / RC_TM;
   // a single row tile (<= 16 rows in the launch): K split over the waves of a block, one 16-column strip per block
-  if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 16) == 0 && !no_ksplit) return 2;
+  // (the waves take runs of 4 K groups: rc_krange - uneven when the group count is not a multiple of 16, e.g. 128 channels x 5 taps)
+  if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 4) == 0 && !no_ksplit) return 2;
   // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
   static const int wide_min = getenv("CONAN_RC_WIDE_MIN") ? atoi(getenv("CONAN_RC_WIDE_MIN")) : 1024;    // developer switch
   return (a.Cout_pad >= wide_min && a.Cout_pad % 256 == 0) ? 1 : 0;

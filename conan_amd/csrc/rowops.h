@@ -16,6 +16,17 @@
 
 namespace cnk {
 namespace ro {
+// K groups of wave `wave` when a strip's K loop is split over the KW waves of a block (a single row tile in the step): runs of a
+// multiple of RC_D = 4 groups, the last waves' runs shorter (or empty) when NG is not a multiple of 16 - NG % 16 == 0 gives the even split
+template <int KW>
+__device__ __forceinline__ void rc_krange(const int NG, const int wave, int& g_lo, int& g_hi) {
+  if constexpr (KW == 1) { g_lo = 0; g_hi = NG; }
+  else {
+    const int per = ((NG + 4 * KW - 1) / (4 * KW)) * 4;
+    g_lo = per * wave < NG ? per * wave : NG;
+    g_hi = g_lo + per < NG ? g_lo + per : NG;
+  }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gcf4;
@@ -220,7 +231,8 @@ __device__ __forceinline__ void rowconv_tile(const A& a, const int bx, const int
   const int KQ = Cin >> 4;                              // 16-deep K groups per tap (power of two)
   const int NG = k * KQ;
   const int ct0 = KW > 1 ? ntile : (ntile * 4 + wave) * NCW;
-  const int g_lo = KW > 1 ? (NG / KW) * wave : 0, g_hi = KW > 1 ? g_lo + NG / KW : NG;    // NG % (KW * RC_D) == 0 (host)
+  int g_lo, g_hi;
+  rc_krange<KW>(NG, wave, g_lo, g_hi);
   const int lr = lane & 15, lg = lane >> 4;
   const float* abase[NRW];
 #pragma unroll
@@ -250,7 +262,7 @@ __device__ __forceinline__ void rowconv_tile(const A& a, const int bx, const int
     const int tstep = d * LDX;
     float4 af[NRW];
 #pragma unroll
-    for (int r = 0; r < NRW; ++r) af[r] = *reinterpret_cast<const float4*>(abase[r] + (g_lo >> kqs) * tstep + (g_lo & kqm) * 16);
+    for (int r = 0; r < NRW; ++r) af[r] = *reinterpret_cast<const float4*>(abase[r] + (g_lo < g_hi ? (g_lo >> kqs) * tstep + (g_lo & kqm) * 16 : 0));
     for (int G0 = g_lo; G0 < g_hi; G0 += RC_D) {
 #pragma unroll
       for (int u = 0; u < RC_D; ++u) {
@@ -909,7 +921,8 @@ __device__ __forceinline__ float mg_wwarm(const A& a, const int bx) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
   const int ct0 = KW > 1 ? bx : bx * 4 + wave;
-  const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
+  int g_lo, g_hi;
+  rc_krange<KW>(NG, wave, g_lo, g_hi);
   const float* wl = a.w + (long long)ct0 * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
   return ct0 * 16 < a.Cout_pad ? ldw1(wl) : 0.f;
 }
@@ -921,9 +934,10 @@ __device__ __forceinline__ Warm10 mg_wwarm_all(const A& a, const int bx) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
   const int ct0 = KW > 1 ? bx : bx * 4 + wave;
-  const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
+  int g_lo, g_hi;
+  rc_krange<KW>(NG, wave, g_lo, g_hi);
   const float* wl = a.w + (long long)(ct0 * 16 < a.Cout_pad ? ct0 : 0) * ((long long)(a.ktaps + 1) * KQ * 256) + (long long)g_lo * 256 + lane * 32;
-  const int ng = KW > 1 ? NG / KW : NG;
+  const int ng = g_hi - g_lo;
   Warm10 r;
 #pragma unroll
   for (int u = 0; u < 10; ++u) r.w[u] = ldw1(wl + (long long)(8 * u < ng ? 8 * u : 0) * 256);
@@ -940,7 +954,8 @@ __device__ __forceinline__ void mg_wpre(const A& a, const int bx, float4 (&bw)[(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int KQ = a.Cin >> 4, NG = a.ktaps * KQ;
   const int ct0 = KW > 1 ? bx : bx * 4 + wave;
-  const int g_lo = KW > 1 ? (NG / KW) * wave : 0;
+  int g_lo, g_hi;
+  rc_krange<KW>(NG, wave, g_lo, g_hi);
   // (column tiles past the padded width: the tensor's first tile - in bounds, unused)
   const float* wl = a.w + (long long)(ct0 * 16 < a.Cout_pad ? ct0 : 0) * ((long long)(a.ktaps + 1) * KQ * 256) + lane * 4;
 #pragma unroll
@@ -959,7 +974,8 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
   const int KQ = Cin >> 4;
   const int NG = k * KQ;
   const int ct0 = KW > 1 ? bx : bx * 4 + wave;
-  const int g_lo = KW > 1 ? (NG / KW) * wave : 0, g_hi = KW > 1 ? g_lo + NG / KW : NG;
+  int g_lo, g_hi;
+  rc_krange<KW>(NG, wave, g_lo, g_hi);
   const int lr = lane & 15, lg = lane >> 4;
   const float* const abase = win + tb.tab[lr] * LDX + 4 * lg;
   const long long ct_stride = (long long)(k + 1) * KQ * 256;
@@ -1005,7 +1021,7 @@ __device__ __forceinline__ void mg_strip(const A& a, const RowTab& tb, const int
     }
     const int kqm = KQ - 1, kqs = 31 - __builtin_clz(KQ);
     const int tstep = d * LDX;
-    float4 af = *reinterpret_cast<const float4*>(abase + (g_lo >> kqs) * tstep + (g_lo & kqm) * 16);
+    float4 af = *reinterpret_cast<const float4*>(abase + (g_lo < g_hi ? (g_lo >> kqs) * tstep + (g_lo & kqm) * 16 : 0));
     for (int G0 = g_lo; G0 < g_hi; G0 += RC_D) {
 #pragma unroll
       for (int u = 0; u < RC_D; ++u) {
