@@ -264,6 +264,119 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
 
+  // Small-M shapes (one 32 x 32 tile per wave group: latency-bound launches of 10 us): the operands are requested in FRONT of the K
+  // loop by the wave that will run the epilogue - the matrix waves issue no vector loads in the loop, so nothing waits for them -
+  // instead of behind the split-K hand-off, where each `if (has_res)` / `if (bias)` block was a round trip of its own.
+  constexpr bool EPF = (TM == 32);
+  int pf_ri[4], pf_rt[4], pf_rslot[4], pf_rpos[4], pf_co4 = 0; unsigned pf_ok = 0; float pf_mk[4]; float4 pf_rv[4], pf_bq;
+  if constexpr (EPF) {
+    static_assert(TM != 32 || (RM == 1 && RN == 1), "one tile per wave");
+    if (wk == 0) {
+#include "conv_mfma_epi.inc"
+  // the epilogue's per-row and per-column operands (row -> stream / time / slot / frame counter, masks; residual, style vector, bias)
+  auto row_ops = [&](const int rm, int (&ri)[4], int (&rt)[4], int (&rslot)[4], int (&rpos)[4], unsigned& okbits, float (&mkv)[4]) __attribute__((always_inline)) {
+    const int er = lane >> 3;
+      // (1) the lane's 4 rows: tile row er + 8g -> (batch index, time, slot, position)
+      okbits = 0;
+      if (fast) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int ml = (wm * RM + rm) * 32 + er + 8 * gq;
+          const int tt = t0 + ml;
+          const bool w = tt >= T;
+          ri[gq] = w ? i1 : i0; rt[gq] = w ? tt - T : tt; rslot[gq] = w ? slotB : slotA; rpos[gq] = w ? posB : posA;
+          okbits |= ((m0 + ml) < Mtot ? 1u : 0u) << gq;
+        }
+      } else {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int m = m0 + (wm * RM + rm) * 32 + er + 8 * gq;
+          const int i = m / T;
+          rt[gq] = m - i * T;
+          okbits |= (m < Mtot ? 1u : 0u) << gq;
+          ri[gq] = i < nslot ? i : nslot - 1;
+        }
+        if (slots) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rslot[gq] = slots[ri[gq]];
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rslot[gq] = ri[gq];
+        }
+        if (posp) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rpos[gq] = posp[rslot[gq]];
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rpos[gq] = 0;
+        }
+      }
+      if (lens) {
+        int rl[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) rl[gq] = lens[ri[gq]];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) if (rt[gq] >= rl[gq]) okbits &= ~(1u << gq);
+      }
+      mkv[0] = mkv[1] = mkv[2] = mkv[3] = 1.f;
+      if (a.has_m1) {
+        const TRef q = a.m1;
+        const bool qring = q.mode == 0;
+        const int qmask = qring ? q.lmask : -1;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int sidx = qring ? rslot[gq] : ri[gq];
+          mkv[gq] = q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+        }
+      }
+      if (a.has_m2) {
+        const TRef q = a.m2;
+        const bool qring = q.mode == 0;
+        const int qmask = qring ? q.lmask : -1;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int sidx = qring ? rslot[gq] : ri[gq];
+          mkv[gq] *= q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+        }
+      }
+  };
+  auto col_ops = [&](const int rn, const int (&ri)[4], const int (&rt)[4], const int (&rslot)[4], const int (&rpos)[4], int& co4, int& cc, bool& cok,
+                     float4 (&rv)[4], float4& bq) __attribute__((always_inline)) {
+    const int ec4 = lane & 7;
+        co4 = n0 + (wn * RN + rn) * 32 + ec4 * 4;      // first of the lane's 4 channels
+        cok = co4 < Cout;
+        cc = cok ? co4 : 0;
+        // (2) residual + style vector (16-byte loads where the layout allows)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) rv[gq] = f4zero();
+        if (has_res) {
+          const TRef rr = a.res;
+          const bool rring = rr.mode == 0;
+          const int rmask = rring ? rr.lmask : -1;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int sidx = rring ? rslot[gq] : ri[gq];
+            const int row = ((rring ? rpos[gq] * rr.rate : 0) + rr.off + rt[gq]) & rmask;
+            const float* p = rr.base + (long long)sidx * rr.slot_stride + row * rr.C + cc;
+            if (vec_ok && (rr.C & 3) == 0) rv[gq] = *reinterpret_cast<const float4*>(p);
+            else { rv[gq].x = p[0]; rv[gq].y = cc + 1 < Cout ? p[1] : 0.f; rv[gq].z = cc + 2 < Cout ? p[2] : 0.f; rv[gq].w = cc + 3 < Cout ? p[3] : 0.f; }
+          }
+        }
+        if (has_bvec) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const float* bv = a.bvec + (long long)rslot[gq] * a.bvec_stride + cc;
+            rv[gq].x += bv[0]; rv[gq].y += cc + 1 < Cout ? bv[1] : 0.f; rv[gq].z += cc + 2 < Cout ? bv[2] : 0.f; rv[gq].w += cc + 3 < Cout ? bv[3] : 0.f;
+          }
+        }
+        bq = f4zero();
+        if (a.bias) { bq.x = a.bias[cc]; bq.y = a.bias[cc + 1]; bq.z = a.bias[cc + 2]; bq.w = a.bias[cc + 3]; }   // bias is padded to Cout_pad
+  };
+      row_ops(0, pf_ri, pf_rt, pf_rslot, pf_rpos, pf_ok, pf_mk);
+      int cc_; bool cok_;
+      col_ops(0, pf_ri, pf_rt, pf_rslot, pf_rpos, pf_co4, cc_, cok_, pf_rv, pf_bq);
+    }
+  }
   const float neg_mul_c = a.in_act == ACT_LRELU ? a.in_slope : 1.0f;
   int bufc = gbuf;
   gbuf = (gbuf + nks) % NBUF;
@@ -371,7 +484,14 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   // ---- inter-block split-K hand-off.  MI355X: per-XCD L2s are not coherent; the partial tiles travel as agent-scope
   // write-through stores / sc1 loads (relaxed atomics), ordered by s_waitcnt + the ticket - no release / acquire fence,
   // i.e. no write-back and invalidate of the whole L2 per tile (same scheme as the fused Emformer's cluster exchange).
+#ifdef CK_STAMPS
+  unsigned long long* const rdbg = (a.dbg && blockIdx.x < 512) ? a.dbg + 1100 + blockIdx.x * 8 : nullptr;
+#define CK_RSTAMP(i) do { if (rdbg && tid == 0) rdbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CK_RSTAMP(i) do { } while (0)
+#endif
   if (SK && nslices > 1) {
+    CK_RSTAMP(0);
     constexpr int PER_WAVE = RM * RN * 16 * 64;
     constexpr int PER_TILE = WM * WN * PER_WAVE;
     float* mine = slab + (long long)kslice * PER_TILE + (wm * WN + wn) * PER_WAVE;
@@ -384,6 +504,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
           __hip_atomic_store(mine + ((rm * RN + rn) * 16 + e) * 64 + lane, acc[rm][rn][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its (write-through) stores
     if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    CK_RSTAMP(1);
     block_barrier();                                       // X1
     if (tid == 0) {
       const int ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -392,6 +513,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       *sflag = last;
     }
     block_barrier();                                       // X2
+    CK_RSTAMP(2);
     if (*sflag == 0) return;
     if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // reducer: sum the partial tiles in slice order (own slice from memory too: identical bits, fixed order)
@@ -401,16 +523,30 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
-    for (int q = 0; q < nslices; ++q) {
-      const float* src = slab + (long long)q * PER_TILE + (wm * WN + wn) * PER_WAVE;
+    // (QB slices per round trip: left as one slice per loop iteration the loads of slice q + 1 are issued behind the adds of slice q - one
+    // round trip to memory per slice, 1-2 us each, on the launch's critical path.  Slices past the last re-read the last one and are dropped.)
+    constexpr int QB = (TM == 32) ? 8 / (RM * RN) : 2;      // (the streaming shapes hold 128 / 160 registers: two slices at a time)
+    for (int q0 = 0; q0 < nslices; q0 += QB) {
+      float pv[QB][RM * RN * 16];
 #pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
+      for (int j = 0; j < QB; ++j) {
+        const int q = q0 + j < nslices ? q0 + j : nslices - 1;
+        const float* src = slab + (long long)q * PER_TILE + (wm * WN + wn) * PER_WAVE;
 #pragma unroll
-        for (int rn = 0; rn < RN; ++rn)
+        for (int f = 0; f < RM * RN * 16; ++f) pv[j][f] = __hip_atomic_load(src + f * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            acc[rm][rn][e] += __hip_atomic_load(src + ((rm * RN + rn) * 16 + e) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < QB; ++j) {
+        const bool in = q0 + j < nslices;
+#pragma unroll
+        for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+          for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float t = acc[rm][rn][e] + pv[j][(rm * RN + rn) * 16 + e]; acc[rm][rn][e] = in ? t : acc[rm][rn][e]; }
+      }
     }
+    CK_RSTAMP(3);
   }
 
   // ---- epilogue.  Each 32x32 accumulator tile (column on the lane, 16 rows in registers) is transposed through a
@@ -419,122 +555,120 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   // issue-bound, not bandwidth-bound) and the row -> stream/time/slot arithmetic is done for 4 rows per lane
   // instead of 16.  Every run-time option and the activation are uniform branches around straight-line passes, so
   // the loads of a pass are issued back-to-back and waited for once.
-  const int shuf = a.shuffle_r;
-  const int Cq = Cout / shuf;
-  const float oscale = a.out_scale, oslope = a.out_slope;
-  const int oact = a.out_act;
-  const int* lens = a.lens;
-  const bool yring = a.y.mode == 0;
-  const int yC = a.y.C, ymask = yring ? a.y.lmask : -1, yrate = a.y.rate, yoff = a.y.off;
-  const long long yss = a.y.slot_stride;
-  float* const ybase0 = a.y.base;
-  float* const y2base0 = a.y2_base;      // activated copy (vectorised layouts only; launch_conv checks)
-  const float y2slope = a.y2_slope;
-  const bool has_res = a.has_res != 0, has_bvec = a.bvec != nullptr;
-  const bool vec_ok = ((Cout & 3) == 0) && ((yC & 3) == 0) && ((Cq & 3) == 0);
-  float* patch = lds + STAGE_FLOATS_TOTAL + wave * (32 * EPI_LD);
-  const int er = lane >> 3;          // row within an 8-row group
-  const int ec4 = lane & 7;          // channel quad within the 32-wide tile
-
+#include "conv_mfma_epi.inc"
   auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_tag)::value;
+    float* const patch = lds + STAGE_FLOATS_TOTAL + wave * (32 * EPI_LD);
+    const int er = lane >> 3, ec4 = lane & 7;
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm) {
-      // (1) the lane's 4 rows: tile row er + 8g -> (batch index, time, slot, position)
       int ri[4], rt[4], rslot[4], rpos[4];
       unsigned okbits = 0;
-      if (fast) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int ml = (wm * RM + rm) * 32 + er + 8 * gq;
-          const int tt = t0 + ml;
-          const bool w = tt >= T;
-          ri[gq] = w ? i1 : i0; rt[gq] = w ? tt - T : tt; rslot[gq] = w ? slotB : slotA; rpos[gq] = w ? posB : posA;
-          okbits |= ((m0 + ml) < Mtot ? 1u : 0u) << gq;
-        }
-      } else {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int m = m0 + (wm * RM + rm) * 32 + er + 8 * gq;
-          const int i = m / T;
-          rt[gq] = m - i * T;
-          okbits |= (m < Mtot ? 1u : 0u) << gq;
-          ri[gq] = i < nslot ? i : nslot - 1;
-        }
-        if (slots) {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) rslot[gq] = slots[ri[gq]];
-        } else {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) rslot[gq] = ri[gq];
-        }
-        if (posp) {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) rpos[gq] = posp[rslot[gq]];
-        } else {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) rpos[gq] = 0;
-        }
-      }
-      if (lens) {
-        int rl[4];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) rl[gq] = lens[ri[gq]];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) if (rt[gq] >= rl[gq]) okbits &= ~(1u << gq);
-      }
       float mkv[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.has_m1) {
-        const TRef q = a.m1;
-        const bool qring = q.mode == 0;
-        const int qmask = qring ? q.lmask : -1;
+      if constexpr (EPF) {      // (requested in front of the K loop: row_ops / col_ops above)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int sidx = qring ? rslot[gq] : ri[gq];
-          mkv[gq] = q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+        for (int gq = 0; gq < 4; ++gq) { ri[gq] = pf_ri[gq]; rt[gq] = pf_rt[gq]; rslot[gq] = pf_rslot[gq]; rpos[gq] = pf_rpos[gq]; mkv[gq] = pf_mk[gq]; }
+        okbits = pf_ok;
+      } else {
+        // (1) the lane's 4 rows: tile row er + 8g -> (batch index, time, slot, position)
+        if (fast) {
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int ml = (wm * RM + rm) * 32 + er + 8 * gq;
+            const int tt = t0 + ml;
+            const bool w = tt >= T;
+            ri[gq] = w ? i1 : i0; rt[gq] = w ? tt - T : tt; rslot[gq] = w ? slotB : slotA; rpos[gq] = w ? posB : posA;
+            okbits |= ((m0 + ml) < Mtot ? 1u : 0u) << gq;
+          }
+        } else {
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int m = m0 + (wm * RM + rm) * 32 + er + 8 * gq;
+            const int i = m / T;
+            rt[gq] = m - i * T;
+            okbits |= (m < Mtot ? 1u : 0u) << gq;
+            ri[gq] = i < nslot ? i : nslot - 1;
+          }
+          if (slots) {
+  #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) rslot[gq] = slots[ri[gq]];
+          } else {
+  #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) rslot[gq] = ri[gq];
+          }
+          if (posp) {
+  #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) rpos[gq] = posp[rslot[gq]];
+          } else {
+  #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) rpos[gq] = 0;
+          }
         }
-      }
-      if (a.has_m2) {
-        const TRef q = a.m2;
-        const bool qring = q.mode == 0;
-        const int qmask = qring ? q.lmask : -1;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int sidx = qring ? rslot[gq] : ri[gq];
-          mkv[gq] *= q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+        if (lens) {
+          int rl[4];
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rl[gq] = lens[ri[gq]];
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) if (rt[gq] >= rl[gq]) okbits &= ~(1u << gq);
+        }
+        if (a.has_m1) {
+          const TRef q = a.m1;
+          const bool qring = q.mode == 0;
+          const int qmask = qring ? q.lmask : -1;
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int sidx = qring ? rslot[gq] : ri[gq];
+            mkv[gq] = q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+          }
+        }
+        if (a.has_m2) {
+          const TRef q = a.m2;
+          const bool qring = q.mode == 0;
+          const int qmask = qring ? q.lmask : -1;
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int sidx = qring ? rslot[gq] : ri[gq];
+            mkv[gq] *= q.base[(long long)sidx * q.slot_stride + (((qring ? rpos[gq] * q.rate : 0) + q.off + rt[gq]) & qmask)];
+          }
         }
       }
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
-        const int co4 = n0 + (wn * RN + rn) * 32 + ec4 * 4;      // first of the lane's 4 channels
+        const int co4 = EPF ? pf_co4 : n0 + (wn * RN + rn) * 32 + ec4 * 4;      // first of the lane's 4 channels
         const bool cok = co4 < Cout;
         const int cc = cok ? co4 : 0;
-        // (2) residual + style vector (16-byte loads where the layout allows)
-        float4 rv[4];
+        float4 rv[4], bq;
+        if constexpr (EPF) {
+          bq = pf_bq;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) rv[gq] = f4zero();
-        if (has_res) {
-          const TRef rr = a.res;
-          const bool rring = rr.mode == 0;
-          const int rmask = rring ? rr.lmask : -1;
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const int sidx = rring ? rslot[gq] : ri[gq];
-            const int row = ((rring ? rpos[gq] * rr.rate : 0) + rr.off + rt[gq]) & rmask;
-            const float* p = rr.base + (long long)sidx * rr.slot_stride + row * rr.C + cc;
-            if (vec_ok && (rr.C & 3) == 0) rv[gq] = *reinterpret_cast<const float4*>(p);
-            else { rv[gq].x = p[0]; rv[gq].y = cc + 1 < Cout ? p[1] : 0.f; rv[gq].z = cc + 2 < Cout ? p[2] : 0.f; rv[gq].w = cc + 3 < Cout ? p[3] : 0.f; }
+          for (int gq = 0; gq < 4; ++gq) rv[gq] = pf_rv[gq];
+        } else {
+          // (2) residual + style vector (16-byte loads where the layout allows)
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) rv[gq] = f4zero();
+          if (has_res) {
+            const TRef rr = a.res;
+            const bool rring = rr.mode == 0;
+            const int rmask = rring ? rr.lmask : -1;
+  #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const int sidx = rring ? rslot[gq] : ri[gq];
+              const int row = ((rring ? rpos[gq] * rr.rate : 0) + rr.off + rt[gq]) & rmask;
+              const float* p = rr.base + (long long)sidx * rr.slot_stride + row * rr.C + cc;
+              if (vec_ok && (rr.C & 3) == 0) rv[gq] = *reinterpret_cast<const float4*>(p);
+              else { rv[gq].x = p[0]; rv[gq].y = cc + 1 < Cout ? p[1] : 0.f; rv[gq].z = cc + 2 < Cout ? p[2] : 0.f; rv[gq].w = cc + 3 < Cout ? p[3] : 0.f; }
+            }
           }
-        }
-        if (has_bvec) {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const float* bv = a.bvec + (long long)rslot[gq] * a.bvec_stride + cc;
-            rv[gq].x += bv[0]; rv[gq].y += cc + 1 < Cout ? bv[1] : 0.f; rv[gq].z += cc + 2 < Cout ? bv[2] : 0.f; rv[gq].w += cc + 3 < Cout ? bv[3] : 0.f;
+          if (has_bvec) {
+  #pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              const float* bv = a.bvec + (long long)rslot[gq] * a.bvec_stride + cc;
+              rv[gq].x += bv[0]; rv[gq].y += cc + 1 < Cout ? bv[1] : 0.f; rv[gq].z += cc + 2 < Cout ? bv[2] : 0.f; rv[gq].w += cc + 3 < Cout ? bv[3] : 0.f;
+            }
           }
+          bq = f4zero();
+          if (a.bias) { bq.x = a.bias[cc]; bq.y = a.bias[cc + 1]; bq.z = a.bias[cc + 2]; bq.w = a.bias[cc + 3]; }   // bias is padded to Cout_pad
         }
-        float4 bq = f4zero();
-        if (a.bias) { bq.x = a.bias[cc]; bq.y = a.bias[cc + 1]; bq.z = a.bias[cc + 2]; bq.w = a.bias[cc + 3]; }   // bias is padded to Cout_pad
         // (3) transpose the accumulator tile through the wave's LDS patch
 #pragma unroll
         for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + 4 * lh) * EPI_LD + l31] = acc[rm][rn][e];
@@ -594,6 +728,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
     default: epilogue(std::integral_constant<int, ACT_NONE>{}); break;
   }
 #ifdef CK_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  CK_RSTAMP(4);
   if (a.dbg && tile == 1 && tid == 0) {
     a.dbg[0] = c_wait; a.dbg[1] = c_comp; a.dbg[2] = (unsigned long long)nks; a.dbg[3] = c_kend - c_begin; a.dbg[4] = __builtin_amdgcn_s_memtime() - c_kend; a.dbg[5] = __builtin_amdgcn_s_memtime() - c_begin; a.dbg[6] = __builtin_amdgcn_s_memrealtime() - c_rt0;
   }

@@ -25,6 +25,12 @@ __device__ __forceinline__ unsigned trow(const TRef& r, int slot, const int* pos
   }
   return (unsigned)(r.off + t);
 }
+// (the slot's frame counter already in a register: one dependent load per row instead of one per tensor)
+__device__ __forceinline__ float* trowptr_pv(const TRef& r, int i, int slot, unsigned pv, int t) {
+  const int s = r.mode == 0 ? slot : i;
+  const unsigned row = r.mode == 0 ? ((pv * (unsigned)r.rate + (unsigned)(r.off + t)) & (unsigned)r.lmask) : (unsigned)(r.off + t);
+  return r.base + (long long)s * r.slot_stride + (long long)row * r.C;
+}
 __device__ __forceinline__ float* trowptr(const TRef& r, int i, int slot, const int* pos, int t) {
   int s = r.mode == 0 ? slot : i;
   return r.base + (long long)s * r.slot_stride + (long long)trow(r, s, pos, t) * r.C;
@@ -271,20 +277,23 @@ __global__ __launch_bounds__(256) void mean_act_kernel(const MeanActArgs a) {
     const long long m = e / c4n;
     const int i = (int)(m / a.T), t = (int)(m - (long long)i * a.T);
     const int slot = a.slots ? a.slots[i] : i;
-    float4 v = *reinterpret_cast<const float4*>(trowptr(a.x[0], i, slot, a.pos, t) + c4 * 4);
+    const unsigned pv = a.pos ? (unsigned)a.pos[slot] : 0u;
+    // (the branches' rows in ONE round trip: loads behind `if (nsrc > 1)` are issued one full wait apart; an absent branch re-reads the first)
+    const float* p0 = trowptr_pv(a.x[0], i, slot, pv, t) + c4 * 4;
+    const float* p1 = a.nsrc > 1 ? trowptr_pv(a.x[1], i, slot, pv, t) + c4 * 4 : p0;
+    const float* p2 = a.nsrc > 2 ? trowptr_pv(a.x[2], i, slot, pv, t) + c4 * 4 : p0;
+    float4 v = *reinterpret_cast<const float4*>(p0);
+    const float4 v1 = *reinterpret_cast<const float4*>(p1);
+    const float4 v2 = *reinterpret_cast<const float4*>(p2);
     if (a.nsrc > 1) {
-      const float4 v1 = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
       v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
-      if (a.nsrc > 2) {
-        const float4 v2 = *reinterpret_cast<const float4*>(trowptr(a.x[2], i, slot, a.pos, t) + c4 * 4);
-        v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-      }
+      if (a.nsrc > 2) { v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w; }
       const float dn = (float)a.nsrc;      // xs / num_resblocks: true division like the reference
       v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
     }
     v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
     v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-    *reinterpret_cast<float4*>(trowptr(a.y, i, slot, a.pos, t) + c4 * 4) = v;
+    *reinterpret_cast<float4*>(trowptr_pv(a.y, i, slot, pv, t) + c4 * 4) = v;
   }
 }
 void launch_mean_act(const MeanActArgs& a, hipStream_t st) {
@@ -316,24 +325,29 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
   // here) exactly when the caller passes the activated-mean ring
   const bool form = a.xmean.base != nullptr;
   const int total = rows * c4n;
-  constexpr int U = 8;
+  const unsigned pv = a.pos ? (unsigned)a.pos[slot] : 0u;
+  const int nsrc = a.nsrc;
+  const float slope = a.slope;
+  // (9 units per thread: the 262 x 8 units of the shipped shape - 32 channels, 7 taps - in one pass; every load unconditional with a
+  // clamped address: behind `if (t < T) .. if (nsrc > 1)` hipcc waits for each load before it issues the next - two dozen round
+  // trips in a kernel with a microsecond of arithmetic)
+  constexpr int U = 9;
   for (int e0 = 0; e0 < total; e0 += 256 * U) {
     float4 v0[U], v1[U], v2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e = e0 + (int)threadIdx.x + 256 * u;
-      v0[u] = v1[u] = v2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < total) {
-        const int r = e / c4n, c4 = e - r * c4n;
-        const int t = t0 + r - (a.k - 1);            // may be negative: ring history (zeros before stream start)
-        if (t < a.T && form && t < 0) {
-          v0[u] = *reinterpret_cast<const float4*>(trowptr(a.xmean, i, slot, a.pos, t) + c4 * 4);       // earlier steps: the activated mean as stored
-        } else if (t < a.T) {
-          v0[u] = *reinterpret_cast<const float4*>(trowptr(a.x[0], i, slot, a.pos, t) + c4 * 4);
-          if (form && a.nsrc > 1) v1[u] = *reinterpret_cast<const float4*>(trowptr(a.x[1], i, slot, a.pos, t) + c4 * 4);
-          if (form && a.nsrc > 2) v2[u] = *reinterpret_cast<const float4*>(trowptr(a.x[2], i, slot, a.pos, t) + c4 * 4);
-        }
-      }
+      const int ec = e < total ? e : 0;
+      const int r = ec / c4n, c4 = ec - r * c4n;
+      const int t = t0 + r - (a.k - 1);            // may be negative: ring history (zeros before stream start)
+      const int tc = t < a.T ? t : a.T - 1;          // (rows past the step: read the last row, dropped below)
+      const bool hist = form && tc < 0;              // earlier steps: the activated mean as stored
+      const float* p0 = (hist ? trowptr_pv(a.xmean, i, slot, pv, tc) : trowptr_pv(a.x[0], i, slot, pv, tc)) + c4 * 4;
+      const float* p1 = (form && !hist && nsrc > 1) ? trowptr_pv(a.x[1], i, slot, pv, tc) + c4 * 4 : p0;
+      const float* p2 = (form && !hist && nsrc > 2) ? trowptr_pv(a.x[2], i, slot, pv, tc) + c4 * 4 : p0;
+      v0[u] = *reinterpret_cast<const float4*>(p0);
+      v1[u] = *reinterpret_cast<const float4*>(p1);
+      v2[u] = *reinterpret_cast<const float4*>(p2);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -341,15 +355,14 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const ConvPostArgs a) {
       if (e >= total) continue;
       const int r = e / c4n, c4 = e - r * c4n;
       const int t = t0 + r - (a.k - 1);
-      float4 v = v0[u];
+      float4 v = t < a.T ? v0[u] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (form && t >= 0 && t < a.T) {        // leaky_relu(mean of the branches): mean_act_kernel's arithmetic, operation for operation
-        if (a.nsrc > 1) { v.x += v1[u].x; v.y += v1[u].y; v.z += v1[u].z; v.w += v1[u].w; }
-        if (a.nsrc > 2) { v.x += v2[u].x; v.y += v2[u].y; v.z += v2[u].z; v.w += v2[u].w; }
-        const float dn = (float)a.nsrc;
-        v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
-        v.x = v.x > 0.f ? v.x : v.x * a.slope; v.y = v.y > 0.f ? v.y : v.y * a.slope;
-        v.z = v.z > 0.f ? v.z : v.z * a.slope; v.w = v.w > 0.f ? v.w : v.w * a.slope;
-        if (r >= a.k - 1) *reinterpret_cast<float4*>(trowptr(a.xmean, i, slot, a.pos, t) + c4 * 4) = v;   // this tile's own rows -> the mean ring
+        if (nsrc > 1) { v.x += v1[u].x; v.y += v1[u].y; v.z += v1[u].z; v.w += v1[u].w; }
+        if (nsrc > 2) { v.x += v2[u].x; v.y += v2[u].y; v.z += v2[u].z; v.w += v2[u].w; }
+        if (nsrc > 1) { const float dn = (float)nsrc; v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn; }
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        if (r >= a.k - 1) *reinterpret_cast<float4*>(trowptr_pv(a.xmean, i, slot, pv, t) + c4 * 4) = v;   // this tile's own rows -> the mean ring
       }
       *reinterpret_cast<float4*>(cps + r * ld + c4 * 4) = v;
     }

@@ -56,13 +56,30 @@ int main(int argc, char** argv) {
     {"conv_pre (M=256,80->512,k7) K4", 64, 4, 80, 512, 7, 1, 1, cnk::CFG_32x32_K4},
   };
   int nslots = 64;
+  // CB_N=<streams>: the small-batch shapes of one vocoder step with the inter-block split-K of streams.hip (S = CUs / tiles, <= K-steps / 2, <= 16)
+  const int cbn = getenv("CB_N") ? atoi(getenv("CB_N")) : 0;
+  if (cbn > 0) {
+    shapes = {
+      {"conv_pre (80->512,k7)", cbn, 4, 80, 512, 7, 1, 1, cnk::CFG_32x32_K4},
+      {"ups0 (512->2048,k16)", cbn, 4, 512, 2048, 16, 1, 1, cnk::CFG_32x32_K4},
+      {"stage1 c1 mixed k (C=256)", cbn, 32, 256, 256, -1, 3, 3, cnk::CFG_32x32_K4},
+      {"stage1 c1 k3 only (C=256)", cbn, 32, 256, 256, 3, 1, 1, cnk::CFG_32x32_K4},
+      {"ups1 (256->640,k10)", cbn, 32, 256, 640, 10, 1, 1, cnk::CFG_32x32_K4},
+      {"stage2 c1 mixed k (C=128)", cbn, 160, 128, 128, -1, 3, 3, cnk::CFG_32x32_K4},
+      {"ups2 (128->256,k8)", cbn, 160, 128, 256, 8, 1, 1, cnk::CFG_32x32_K4},
+      {"stage3 c1 mixed k (C=64)", cbn, 640, 64, 64, -1, 3, 3, cnk::CFG_32x32_K4},
+    };
+  }
+  float* slab = nullptr; int* counters = nullptr;
+  const size_t slab_floats = 256 * 16 * 32 * 32;
+  CHECK(hipMalloc(&slab, slab_floats * 4)); CHECK(hipMalloc(&counters, 4096 * 4)); CHECK(hipMemset(counters, 0, 4096 * 4));
   for (auto& s : shapes) {
     const int L = 4096;  // ring rows (pow2) >= T + halo
     int Lr = 1; while (Lr < s.T + 64) Lr <<= 1;
     size_t xfl = (size_t)nslots * Lr * s.Cin, yfl = (size_t)nslots * Lr * s.Cout;
     float *x, *y, *w, *b; int *slots, *pos;
 #ifdef CK_STAMPS
-    unsigned long long* dbg; CHECK(hipMalloc(&dbg, (32 + 1024) * 8)); CHECK(hipMemset(dbg, 0, (32 + 1024) * 8));
+    unsigned long long* dbg; CHECK(hipMalloc(&dbg, (1100 + 512 * 8) * 8)); CHECK(hipMemset(dbg, 0, (1100 + 512 * 8) * 8));
 #endif
     CHECK(hipMalloc(&x, xfl * 4 * 3)); CHECK(hipMalloc(&y, yfl * 4 * 3));
     int Cin_pad = (s.Cin + 31) / 32 * 32, Cin_alloc = (s.Cin + 127) / 128 * 128, Cout_pad = (s.Cout + 63) / 64 * 64;
@@ -91,6 +108,14 @@ int main(int argc, char** argv) {
       a.dbg = dbg;
 #endif
     }
+    if (cbn > 0) {
+      long long tiles = 0; int nks = 0;
+      for (int p = 0; p < s.nprob; ++p) { tiles += (long long)((s.n * s.T + 31) / 32) * ((s.Cout + 31) / 32); nks = std::max(nks, g.p[p].ktaps * ((Cin_pad + 127) / 128)); }
+      int S = (int)(256 / std::max(1LL, tiles)); if (S > nks / 2) S = nks / 2; if (S > 16) S = 16;
+      if (getenv("CB_S")) S = atoi(getenv("CB_S"));
+      g.slab = slab; g.counters = counters; g.ksplit = S >= 2 ? S : 1; g.split_from = 0;
+      printf("  tiles %lld K-steps %d split %d\n", tiles, nks, g.ksplit);
+    }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int it = 0; it < 3; ++it) cnk::launch_conv(g, s.nprob, s.cfg, 0);
     CHECK(hipDeviceSynchronize());
@@ -104,6 +129,14 @@ int main(int argc, char** argv) {
 #ifdef CK_STAMPS
     { unsigned long long h[16]; CHECK(hipMemcpy(h, dbg, 128, hipMemcpyDeviceToHost)); double n = (double)h[2];
       printf("      [block 1] matrix wave: barrier-wait/step=%.0f mfma/step=%.0f kloop=%llu epilogue=%llu | loader: vmcnt-wait/step=%.0f barrier/step=%.0f issue/step=%.0f (cycles); in-kernel clock %.2f GHz\n", h[0] / n, h[1] / n, h[3], h[4], h[8] / n, h[9] / n, h[10] / n, (double)h[5] / (double)h[6] * 0.1); }
+    { std::vector<unsigned long long> h(1100 + 512 * 8); CHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+      // split-K blocks: K loop end, partial stores acknowledged, ticket known, (reducers) partials summed, epilogue stores acknowledged - us after the block's start
+      double sum[5] = {0}, rsum[5] = {0}; int nb = 0, nr = 0;
+      for (int b = 0; b < 512; ++b) { const unsigned long long* r = &h[1100 + b * 8]; const unsigned long long st0 = h[32 + 2 * b];
+        if (!st0 || !r[0] || !r[2]) continue;
+        if (r[3] && r[4]) { for (int i = 0; i < 5; ++i) rsum[i] += (r[i] - st0) * 0.01; ++nr; } else { for (int i = 0; i < 3; ++i) sum[i] += (r[i] - st0) * 0.01; ++nb; } }
+      if (nb) printf("      %3d non-reducers: K loop end %.2f  stores acked %.2f  ticket known %.2f\n", nb, sum[0] / nb, sum[1] / nb, sum[2] / nb);
+      if (nr) printf("      %3d reducers:     K loop end %.2f  stores acked %.2f  ticket known %.2f  partials summed %.2f  epilogue stored %.2f\n", nr, rsum[0] / nr, rsum[1] / nr, rsum[2] / nr, rsum[3] / nr, rsum[4] / nr); }
     { std::vector<unsigned long long> h(32 + 1024); CHECK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
       std::vector<double> st, en; unsigned long long t0 = ~0ull;
       for (int b = 0; b < 512; ++b) if (h[32 + 2 * b]) t0 = std::min(t0, h[32 + 2 * b]);
