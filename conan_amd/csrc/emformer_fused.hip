@@ -19,10 +19,13 @@
 // Cluster mode (EmfFusedArgs::cs = 2, 4, 8): the step is a chain of latency-bound phases on ONE 16-row tile, 69 % of it
 // the feed-forward GEMMs, so with few streams most of the chip idles for 245 us.  cs consecutive workgroups (dealt
 // round-robin over the XCDs: one per XCD) then own the same streams; each runs every phase redundantly except the
-// feed-forward, of which it takes hidden chunks m, m + cs, ...; the partial [16 x D] sums meet in global memory once per
-// layer (agent-scope write-through stores / sc1 loads, a per-member flag word carrying the launch epoch - no fence, so
-// the weights in this XCD's L2 survive; with release / acquire fences the step measured 181 us instead of 141) and are
-// summed in member order, so every member continues with identical bits.  Member 0 alone writes rings, outputs and
+// feed-forward, of which it takes hidden chunks m, m + cs, ...; every CHUNK's partial [16 x D] sum is formed from zero (the four
+// waves' K quarters added in wave order), the chunks' partials meet in global memory once per layer (agent-scope write-through
+// stores / sc1 loads, a per-member flag word carrying the launch epoch - no fence, so the weights in this XCD's L2 survive; with
+// release / acquire fences the step measured 181 us instead of 141) and are summed in CHUNK order by every member: identical bits in
+// every member AND for every cluster size (round 5: until then a member accumulated its chunks in registers and the members' sums
+// were added in member order - the cluster size was part of the result's bits, so blocking steps had to use the pipelined steps'
+// 64-workgroup split).  Member 0 alone writes rings, outputs and
 // past lengths.  One stream: 245 -> 121 us; 64 streams as 32 groups x 4: 147 us.  Forward progress does not need all
 // workgroups resident at once: workgroups are dispatched in index order on every XCD, so the members of the earliest
 // unfinished cluster are always dispatched before any member of a later one.
@@ -492,15 +495,15 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
     ef_barrier();
     EF_STAMP(5);
     f32x4 acc2[KQD];
-#pragma unroll
-    for (int t = 0; t < KQD; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 b2[KQD][KQ2];
 #pragma unroll
     for (int kq = 0; kq < KQ2; ++kq)
 #pragma unroll
       for (int t = 0; t < KQD; ++t) b2[t][kq] = ef_frag(w.w2, ((member * (EF_HCHUNK / 64) + wave) * KQ2 + kq) * KQD + t, lane16);
     // (cluster member m runs hidden chunks m, m + cs, ...)
+    constexpr int XE = (EF_ROWS * D + 255) / 256;
     const int cstep = cs * EF_HCHUNK;
+    float* const xbase = a.xch + ((long long)cluster * 2 + (l & 1)) * EMF_MAX_CHUNKS * (EF_ROWS * D);
     for (int c0 = member * EF_HCHUNK; c0 < a.F; c0 += cstep) {
       const bool more = c0 + cstep < a.F;
       const int un = (c0 + cstep) / 64 + wave;                   // this wave's 64 hidden columns in its next chunk
@@ -529,7 +532,10 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       ef_barrier();
       EF_STAMPC(11);
       EF_STAMPC(12);
-      // FF2: all D output columns, this wave's quarter of the chunk's K
+      // FF2: all D output columns, this wave's quarter of the chunk's K - from zero: a chunk's partial sum does not depend on which
+      // member computes it, or on what that member computed before
+#pragma unroll
+      for (int t = 0; t < KQD; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       ef_mma_tiles_refill<KQD, KQ2>(acc2, b2, Hb, ldh, wave * (EF_HCHUNK / 4), lane, [&](int kq) {
         if (more && !EF_NOLOAD) {
 #pragma unroll
@@ -539,44 +545,52 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       EF_STAMPC(13);
       ef_barrier();
       EF_STAMPC(14);
-    }
-    EF_STAMP(6);
-    // next layer's parameters: in flight during the tail of this layer, parked in the other LDS parameter block
-    float4 np[EF_PP];
-    if (l + 1 < a.L) {
-      const float4* src = reinterpret_cast<const float4*>(a.layers[l + 1].params);
+      // the chunk's partial sum: the waves' K quarters through LDS (RED overlays the hidden chunk, which every wave has read), added in
+      // wave order; one workgroup per group keeps the running sum over its chunks - all of them, in chunk order - in ATT, cluster
+      // members hand every chunk's partial to the exchange buffer
 #pragma unroll
-      for (int i = 0; i < EF_PP; ++i) { const int e = tid + 256 * i; np[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (e < par / 4) np[i] = src[e]; }
-    }
+      for (int t = 0; t < KQD; ++t)
 #pragma unroll
-    for (int t = 0; t < KQD; ++t)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) RED[(wave * EF_ROWS + (lane >> 4) * 4 + r4) * ld + t * 16 + (lane & 15)] = acc2[t][r4];
-    ef_barrier();
-    EF_STAMP(7);
-    // + bias + residual -> ATT (reused as the pre-LN buffer), then layer_norm_output -> X
-    if (cs == 1) {
-      for (int e = tid; e < EF_ROWS * D; e += 256) {
-        const int r = e / D, c = e - r * D;
-        ATT[r * ld + c] = ((RED[(0 * EF_ROWS + r) * ld + c] + RED[(1 * EF_ROWS + r) * ld + c]) + (RED[(2 * EF_ROWS + r) * ld + c] + RED[(3 * EF_ROWS + r) * ld + c])) + pb[PB_B2 + c] + R1[r * ld + c];
-      }
-    } else {
-      // Cluster exchange.  The per-XCD L2s are not coherent with each other: partial sums and flags are written
-      // through and read with agent-scope (sc1) accesses, which leaves the weights cached in this XCD's L2 alone (an
-      // acquire fence would invalidate them every layer).  The buffer of layer l is reused by layer l + 2: a member
-      // writes it only after the exchange of layer l + 1, which every member enters after it has read layer l.
-      constexpr int XE = (EF_ROWS * D + 255) / 256;
-      float* const xbase = a.xch + ((long long)cluster * 2 + (l & 1)) * EMF_MAX_CLUSTER * (EF_ROWS * D);
-      unsigned* const fl = a.xflag + ((long long)cluster * EMF_MAX_LAYERS + l) * EMF_MAX_CLUSTER;
+        for (int r4 = 0; r4 < 4; ++r4) RED[(wave * EF_ROWS + (lane >> 4) * 4 + r4) * ld + t * 16 + (lane & 15)] = acc2[t][r4];
+      ef_barrier();
+      const int ci = c0 / EF_HCHUNK;
 #pragma unroll
       for (int i = 0; i < XE; ++i) {
         const int e = tid + 256 * i;
         if (e < EF_ROWS * D) {
           const int r = e / D, c = e - r * D;
           const float v = (RED[(0 * EF_ROWS + r) * ld + c] + RED[(1 * EF_ROWS + r) * ld + c]) + (RED[(2 * EF_ROWS + r) * ld + c] + RED[(3 * EF_ROWS + r) * ld + c]);
-          __hip_atomic_store(xbase + member * (EF_ROWS * D) + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (cs == 1) ATT[r * ld + c] = ci == 0 ? v : ATT[r * ld + c] + v;
+          else __hip_atomic_store(xbase + (long long)ci * (EF_ROWS * D) + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      if (more) ef_barrier();        // (the next chunk's FF1 writes the hidden chunk over RED)
+    }
+    EF_STAMP(6);
+    // next layer's parameters: in flight during the tail of this layer, parked in the other LDS parameter block
+    float4 np[EF_PP];
+    auto load_np = [&]() __attribute__((always_inline)) {
+      if (l + 1 < a.L) {
+        const float4* src = reinterpret_cast<const float4*>(a.layers[l + 1].params);
+#pragma unroll
+        for (int i = 0; i < EF_PP; ++i) { const int e = tid + 256 * i; np[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (e < par / 4) np[i] = src[e]; }
+      }
+    };
+    if constexpr (!MEM) load_np();      // (the memory-bank build has no registers left for them across the exchange: behind it)
+    EF_STAMP(7);
+    // + bias + residual -> ATT (reused as the pre-LN buffer), then layer_norm_output -> X
+    if (cs == 1) {
+      ef_barrier();
+      for (int e = tid; e < EF_ROWS * D; e += 256) {
+        const int r = e / D, c = e - r * D;
+        ATT[r * ld + c] = ATT[r * ld + c] + pb[PB_B2 + c] + R1[r * ld + c];
+      }
+    } else {
+      // Cluster exchange.  The per-XCD L2s are not coherent with each other: partial sums and flags are written
+      // through and read with agent-scope (sc1) accesses, which leaves the weights cached in this XCD's L2 alone (an
+      // acquire fence would invalidate them every layer).  The buffer of layer l is reused by layer l + 2: a member
+      // writes it only after the exchange of layer l + 1, which every member enters after it has read layer l.
+      unsigned* const fl = a.xflag + ((long long)cluster * EMF_MAX_LAYERS + l) * EMF_MAX_CLUSTER;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's partial-sum stores are complete ...
       if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       ef_barrier();
@@ -592,26 +606,39 @@ __global__ __launch_bounds__(256) void emformer_fused_kernel(const EmfFusedArgs 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       ef_barrier();
-      float pv[EMF_MAX_CLUSTER][XE];
+      // every chunk's partial, eight at a time (unconditional loads: chunks past the last re-read the last and are dropped), summed in
+      // chunk order - the order of a single workgroup's running sum
+      const int nch = a.F / EF_HCHUNK;
+      constexpr int QB = MEM ? 4 : 8;      // (the memory-bank build sits at the register file's edge: four at a time)
+      float sum[XE];
+      for (int q0 = 0; q0 < nch; q0 += QB) {
+        float pv[QB][XE];
 #pragma unroll
-      for (int m = 0; m < EMF_MAX_CLUSTER; ++m)
+        for (int m = 0; m < QB; ++m)
 #pragma unroll
-        for (int i = 0; i < XE; ++i) {
-          const int e = tid + 256 * i;
-          pv[m][i] = (m < cs && e < EF_ROWS * D) ? __hip_atomic_load(xbase + m * (EF_ROWS * D) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-        }
+          for (int i = 0; i < XE; ++i) {
+            const int e = tid + 256 * i;
+            const int q = q0 + m < nch ? q0 + m : nch - 1;
+            pv[m][i] = __hip_atomic_load(xbase + (long long)q * (EF_ROWS * D) + (e < EF_ROWS * D ? e : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+        for (int m = 0; m < QB; ++m)
+#pragma unroll
+          for (int i = 0; i < XE; ++i) {
+            const float t = (q0 + m == 0) ? pv[m][i] : sum[i] + pv[m][i];
+            sum[i] = (q0 + m < nch) ? t : sum[i];
+          }
+      }
 #pragma unroll
       for (int i = 0; i < XE; ++i) {
         const int e = tid + 256 * i;
         if (e < EF_ROWS * D) {
           const int r = e / D, c = e - r * D;
-          float sum = pv[0][i];                                   // member order: the same bits in every member
-#pragma unroll
-          for (int m = 1; m < EMF_MAX_CLUSTER; ++m) if (m < cs) sum += pv[m][i];
-          ATT[r * ld + c] = sum + pb[PB_B2 + c] + R1[r * ld + c];
+          ATT[r * ld + c] = sum[i] + pb[PB_B2 + c] + R1[r * ld + c];
         }
       }
     }
+    if constexpr (MEM) load_np();
     ef_barrier();
     ef_layernorm<KQD>(ATT, X, ld, pb + PB_LNOUT, pb + PB_LNOUT + D, tid);
     if (M > 0) {      // the summary / memory-input rows carry no layer input (their residual is zero): the row's own lanes clear them
@@ -710,7 +737,7 @@ static void launch_ef(const EmfFusedArgs& a, hipStream_t st) {
   }
   EmfFusedArgs b = a;
   const int chunks = a.F / EF_HCHUNK;
-  if (b.cs < 1 || b.cs > EMF_MAX_CLUSTER || (b.cs & (b.cs - 1)) || chunks % b.cs || !b.xch || !b.xflag || !b.xepoch) b.cs = 1;
+  if (b.cs < 1 || b.cs > EMF_MAX_CLUSTER || (b.cs & (b.cs - 1)) || chunks % b.cs || chunks > EMF_MAX_CHUNKS || !b.xch || !b.xflag || !b.xepoch) b.cs = 1;
   hipLaunchKernelGGL((emformer_fused_kernel<KQD, DH, MEM>), dim3(((a.n + G - 1) / G) * b.cs), dim3(256), emformer_fused_smem(a), st, b);
 }
 

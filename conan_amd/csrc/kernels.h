@@ -354,7 +354,7 @@ struct EmfFusedArgs {
   // cluster mode (cs = 2, 4, 8): cs workgroups share one group of streams, each runs 1/cs of the feed-forward hidden
   // units and the partial sums meet in `xch` once per layer.  Workspace sizes: emformer_cluster_ws().
   int cs;
-  float* xch;             // [cluster][2][EMF_MAX_CLUSTER][16][D] partial sums (layer parity double buffer)
+  float* xch;             // [cluster][2][EMF_MAX_CHUNKS][16][D] the feed-forward's per-chunk partial sums (layer parity double buffer)
   unsigned* xflag;        // [cluster][EMF_MAX_LAYERS][EMF_MAX_CLUSTER] "partial of this launch is written" (= epoch + 1)
   unsigned* xepoch;       // [cluster] launches this cluster has taken part in
   int fenced;             // 1: release / acquire fences around the exchange as well (CONAN_FENCED=1 cross-check)
@@ -367,8 +367,9 @@ struct EmfFusedArgs {
   long long bank_slot_stride;
 };
 constexpr int EMF_MAX_CLUSTER = 8;
+constexpr int EMF_MAX_CHUNKS = 16;      // hidden chunks of 256 columns per layer (ffn_dim <= 4096)
 // floats of xch / words of xflag+xepoch for up to `max_groups` stream groups
-inline size_t emformer_cluster_xch_floats(int max_groups, int D) { return (size_t)max_groups * 2 * EMF_MAX_CLUSTER * 16 * D; }
+inline size_t emformer_cluster_xch_floats(int max_groups, int D) { return (size_t)max_groups * 2 * EMF_MAX_CHUNKS * 16 * D; }
 inline size_t emformer_cluster_flag_words(int max_groups) { return (size_t)max_groups * (EMF_MAX_LAYERS * EMF_MAX_CLUSTER + 1); }
 int emformer_fused_streams_per_block(const EmfFusedArgs& a);
 bool emformer_fused_supported(const EmfFusedArgs& a);

@@ -659,13 +659,14 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       // once (one 129 KB workgroup per CU).  The developer override is clamped to that like the automatic choice, and a
       // CU-masked Emformer stream (CONAN_EMF_CUSTRIDE) gets no clusters at all.
       static const bool masked = getenv("CONAN_EMF_CUSTRIDE") != nullptr && atoi(getenv("CONAN_EMF_CUSTRIDE")) >= 2;
-      // (At most 64 workgroups: a workgroup needs a whole CU for the launch's 150-250 us, and in pipelined steps the vocoder's
-      // persistent launches run beside it on what is left.  Measured per pipelined step / blocking p50 at 32 / 48 / 64 streams and
-      // 128 streams of 40 ms chunks, 128 -> 64 workgroups: 0.990 -> 0.979, 1.175 -> 1.154, 1.336 -> 1.317, 1.516 -> 1.509 ms per
-      // step for 1.62 -> 1.65, 1.81 -> 1.85, 1.96 -> 1.99, 2.08 -> 2.15 ms of blocking latency, where the Emformer is on the critical
-      // path: 147 -> 200 us alone at 64 streams.  256 workgroups cost the vocoder 6 % of the step.  The same split in both step
-      // styles: the members' partial sums are added in member order, so the cluster size is part of the result's bits.)
-      const int cap = emf_cluster > 0 ? ctx->num_cu : 64;
+      // (Pipelined steps - the launch is on the stream-set's own Emformer stream: at most 64 workgroups.  A workgroup needs a whole CU
+      // for the launch's 150-250 us, and the vocoder's persistent launches run beside it on what is left.  Measured per pipelined step
+      // at 32 / 48 / 64 streams and 128 streams of 40 ms chunks, 128 -> 64 workgroups: 0.990 -> 0.979, 1.175 -> 1.154, 1.336 -> 1.317,
+      // 1.516 -> 1.509 ms; 256 workgroups cost the vocoder 6 % of the step.  Blocking steps and direct calls - any other stream - have the
+      // chip to themselves for the launch and take one workgroup per CU: 64 streams 190 -> 141 us.  Round 5: the feed-forward's sum is
+      // formed chunk by chunk in chunk order whatever the cluster size (emformer_fused.hip), so the two step styles - which until then had
+      // to use the same split - still produce the same bits.)
+      const int cap = (emf_cluster > 0 || st != st_emf) ? ctx->num_cu : 64;
       a.cs = emf_cluster > 0 ? std::min(emf_cluster, (int)cnk::EMF_MAX_CLUSTER) : cnk::EMF_MAX_CLUSTER;
       while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two
       while (a.cs > 1 && groups * a.cs > cap) a.cs >>= 1;

@@ -118,7 +118,9 @@ def test_hot_kernels_do_not_spill(tmp_path):
             # the memory-bank build (MEM = true; configs with max_memory_size > 0, not the headline one) carries the bank's
             # row offsets and prefetched bank rows on top of a kernel that already fills the register file: a few registers
             # of scratch outside the K loops (b128s2mem4 runs at b128s2's step time); the MEM = false build must stay clean
-            assert ks[k]["spill"] <= 24 and ks[k]["scratch"] <= 96, (k, ks[k])
+            # (round 5: + the per-chunk exchange of the cluster-size-independent feed-forward sum: 32 registers / 132 bytes, stored in front of
+            # the layer loop, reloaded once per layer in the key-table epilogue)
+            assert ks[k]["spill"] <= 36 and ks[k]["scratch"] <= 144, (k, ks[k])
             continue
         if "resblock_limb_kernel" in k and k.endswith("ELb1EEEvNS_6RBArgsE"):
             assert ks[k]["spill"] == 0 and ks[k]["scratch"] <= 16, (k, ks[k])      # see test_co_residency_budgets
