@@ -22,4 +22,7 @@ CONAN_BENCH_COMM=1 timeout 900 python bench.py --no-cpu-baseline --no-other --no
 for W in b1 b1win b128s2 b128s2win b128s2mem4; do
   timeout 900 python bench.py --workload $W --no-cpu-baseline 2> $O/bench_$W.err | grep '^{' > $O/${R}_${W}_bench.json
 done
+# the driver's own parameters (K = 20, W = 5), and one blocking one-stream step as a dispatch timeline
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other 2> $O/bench_k20.err | grep '^{' > $O/${R}_b64_bench_k20.json
+( cd /tmp && export TMPDIR=/tmp; cd /root/repo; rm -rf gpurun_out/${R}_tl1; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${R}_tl1 -o run -- python3 tools/blocking_trace.py 1 > gpurun_out/${R}_tl1.log 2>&1; python3 tools/trace_timeline.py gpurun_out/${R}_tl1/run_kernel_trace.csv 6 > $O/${R}_b1_step_timeline.txt; rm -rf gpurun_out/${R}_tl1 )
 cat $O/${R}_pytest_gpu.txt; cut -c1-300 $O/${R}_b64_bench.json; tail -30 $O/collect_b64.log
