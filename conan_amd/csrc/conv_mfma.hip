@@ -267,10 +267,12 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   // Small-M shapes (one 32 x 32 tile per wave group: latency-bound launches of 10 us): the operands are requested in FRONT of the K
   // loop by the wave that will run the epilogue - the matrix waves issue no vector loads in the loop, so nothing waits for them -
   // instead of behind the split-K hand-off, where each `if (has_res)` / `if (bias)` block was a round trip of its own.
-  constexpr bool EPF = (TM == 32);
+  // (only the 32 x 32 shape: the 32 x 64 shape is ups.0's at serving sizes, where its workgroups share CUs with the decoder's persistent
+  // launch - 2 x 139 + 128 registers per SIMD lane fit, 2 x 231 did not, and the pipelined step lost 4 %)
+  constexpr bool EPF = (TM == 32 && TN == 32);
   int pf_ri[4], pf_rt[4], pf_rslot[4], pf_rpos[4], pf_co4 = 0; unsigned pf_ok = 0; float pf_mk[4]; float4 pf_rv[4], pf_bq;
   if constexpr (EPF) {
-    static_assert(TM != 32 || (RM == 1 && RN == 1), "one tile per wave");
+    static_assert(!EPF || (RM == 1 && RN == 1), "one tile per wave");
     if (wk == 0) {
 #include "conv_mfma_epi.inc"
   // the epilogue's per-row and per-column operands (row -> stream / time / slot / frame counter, masks; residual, style vector, bias)
@@ -525,7 +527,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
         for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
     // (QB slices per round trip: left as one slice per loop iteration the loads of slice q + 1 are issued behind the adds of slice q - one
     // round trip to memory per slice, 1-2 us each, on the launch's critical path.  Slices past the last re-read the last one and are dropped.)
-    constexpr int QB = (TM == 32) ? 8 / (RM * RN) : 2;      // (the streaming shapes hold 128 / 160 registers: two slices at a time)
+    constexpr int QB = (TM == 32 && TN == 32) ? 8 : 2;      // (the streaming shapes hold 128 / 160 registers: two slices at a time)
     for (int q0 = 0; q0 < nslices; q0 += QB) {
       float pv[QB][RM * RN * 16];
 #pragma unroll

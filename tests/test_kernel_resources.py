@@ -102,6 +102,13 @@ def test_co_residency_budgets(tmp_path):
         # per wave) leave the 128-register decoder build its place
         if "ILi4ELi1ELi1ELi4E" in k or "ILi5ELi1ELi1ELi4E" in k:
             assert 2 * gran(f["vgpr"] + f["agpr"]) + 128 <= 512, (k, f)
+    # conv_mfma's shapes that run at serving sizes beside the 128-register decoder build (ups.0: <32,64,1,2,2,64>, ups.1: <64,64,2,2,1,32>,
+    # two waves per SIMD each): round 5 briefly gave the 32-row shapes a 64-register split-K batch and an operand prefetch - 231
+    # registers, the decoder's workgroups no longer fitted beside ups.0's and the pipelined step lost 4 % (1.355 -> 1.40 ms); they are
+    # now confined to the 32 x 32 shape, which only small stream-sets launch
+    for sub in ("conv_mfma_kernelILi32ELi64ELi1ELi2ELi2ELi64E", "conv_mfma_kernelILi64ELi64ELi2ELi2ELi1ELi32E"):
+        f = _find(ks, sub)
+        assert 2 * gran(f["vgpr"] + f["agpr"]) + 128 <= 512, (sub, f)
     for key, f in list(fused.items()) + [("pair", pair)] + list(limb.items()):
         assert 2 * gran(f["vgpr"] + f["agpr"]) + 80 <= 512, (key, f)
         assert f["lds"] + mega_lds <= 160 * 1024, (key, f)
