@@ -666,7 +666,8 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       // chip to themselves for the launch and take one workgroup per CU: 64 streams 190 -> 141 us.  Round 5: the feed-forward's sum is
       // formed chunk by chunk in chunk order whatever the cluster size (emformer_fused.hip), so the two step styles - which until then had
       // to use the same split - still produce the same bits.)
-      const int cap = (emf_cluster > 0 || st != st_emf) ? ctx->num_cu : 64;
+      const bool pipelined = st_emf != nullptr && st == st_emf;       // (the internal stream exists only once a pipelined step has run; a caller's null stream is not it)
+      const int cap = (emf_cluster > 0 || !pipelined) ? ctx->num_cu : 64;
       a.cs = emf_cluster > 0 ? std::min(emf_cluster, (int)cnk::EMF_MAX_CLUSTER) : cnk::EMF_MAX_CLUSTER;
       while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two
       while (a.cs > 1 && groups * a.cs > cap) a.cs >>= 1;
