@@ -129,11 +129,15 @@ int conan_streams_destroy(conan_streams* s);
  *                     error below 2^-130.
  *   CONAN_ARITH_AUTO  the library's default: LIMB wherever the context holds limb weights and a limb kernel exists for the launch
  *                     (ResBlock1 stages; upsamplers whose tiles fill the chip), F32 elsewhere (ResBlock2, decoder, Emformer).
- * The choice is a property of the stream-set, fixed at creation, reported by conan_streams_arith().  Which launches of an AUTO
- * stream-set have a limb kernel depends on max_slots (the C = 256 stage's grouped limb convs exist from 16 slots on, the fused limb
- * passes of the C = 128 / 64 stages from 4, of the C = 32 stage always), never on how many slots a step activates: a stream's audio is bit-reproducible within a stream-set whatever the
- * other slots do, and differs between stream-sets of different sizes by fp32 re-association (<= 2e-5 of the stage maxima; tests/
- * test_gpu_round5.py holds both forms against the reference goldens at the plan-switch sizes 3, 4, 15, 16, 17, 40). */
+ * The choice is a property of the stream-set, fixed at creation, reported by conan_streams_arith().  What is and is not invariant:
+ * a step is bit-reproducible for a given stream-set, list of active slots and frame count (also pipelined against blocking steps, and
+ * after a reset).  WHICH launches of an AUTO stream-set run a limb kernel depends on max_slots (the fused limb passes exist from 4
+ * slots on for the C = 128 / 64 stages, always for C = 32; the C = 256 stage's grouped limb convs from 16) and, for the plain convs
+ * (ups.2 / ups.3, the C = 256 stage), on whether the step's ACTIVE slots give the launch enough tiles to fill the chip - few active
+ * slots in a large stream-set take the f32 kernels there, exactly like the split-K factor of the f32 conv kernel follows the active
+ * count.  A stream's audio therefore differs between steps with different active sets by fp32 re-association / the form of a
+ * product, within the tolerance every form is held to (tests/test_gpu_configs.py: a stream inside a batch of 64 against the same
+ * stream alone, 2e-5; tests/test_gpu_round5.py: both forms against the reference goldens at the plan-switch sizes 3 .. 40). */
 typedef enum conan_arith { CONAN_ARITH_AUTO = 0, CONAN_ARITH_F32 = 1, CONAN_ARITH_LIMB = 2 } conan_arith;
 /* Deployment choices of a stream-set (conan_streams_opts.flags; ABI 7 - until round 4 environment variables):
  *   CONAN_STREAMS_FUSED_DECODER_BLOCKS  the decoder's conv blocks [LN -> k5 conv -> GELU] -> [1x1 conv + residual] as ONE operator each
