@@ -525,9 +525,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
       for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[rm][rn][e] = 0.f;
-    // (QB slices per round trip: left as one slice per loop iteration the loads of slice q + 1 are issued behind the adds of slice q - one
+    // (QB slices per round trip - 4 for the 32 x 32 shape: 166 registers; 8 slices at a time measured the same and took 231 -: left as one slice per loop iteration the loads of slice q + 1 are issued behind the adds of slice q - one
     // round trip to memory per slice, 1-2 us each, on the launch's critical path.  Slices past the last re-read the last one and are dropped.)
-    constexpr int QB = (TM == 32 && TN == 32) ? 8 : 2;      // (the streaming shapes hold 128 / 160 registers: two slices at a time)
+    constexpr int QB = (TM == 32 && TN == 32) ? 4 : 2;      // (the streaming shapes hold 128 / 160 registers: two slices at a time)
     for (int q0 = 0; q0 < nslices; q0 += QB) {
       float pv[QB][RM * RN * 16];
 #pragma unroll
