@@ -1,5 +1,5 @@
-"""Fill the @PLACEHOLDER@ cells of DESIGN.md's round table from the committed profiles (profiles/<round>_*): run after tools/collect_round.sh
-has been copied into profiles/.   python tools/fill_design.py [round]      (idempotent only while the placeholders are still there)"""
+"""Regenerate DESIGN.md's round table (between the round-table markers) from tools/design_round_table.tpl and the committed profiles
+(profiles/<round>_*): run after tools/collect_round.sh's output has been copied into profiles/.   python tools/fill_design.py [round]"""
 import json, re, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r5"
 P = "profiles/%s_" % R
@@ -43,11 +43,13 @@ fill = {
     "B128P50": "%.2f" % b128["p50_latency_ms"], "B128WIN": "%.2f" % b128w["ms_per_step"], "MEM4": "%.3f" % m4["ms_per_step"],
     "COMM": "%.3f" % comm["ms_per_step"], "CPU": "%.1f" % cpu["value"], "CPUS": "%.1f" % cpu["stateful_value"], "TESTS": tests.strip("= "),
 }
-s = open("DESIGN.md").read()
-missing = []
+t = open("tools/design_round_table.tpl").read()
 for k, v in fill.items():
-    if "@" + k + "@" in s:
-        s = s.replace("@" + k + "@", str(v))
-left = re.findall(r"@[A-Z0-9]+@", s)
-open("DESIGN.md", "w").write(s)
-print("filled; placeholders left:", sorted(set(left)))
+    t = t.replace("@" + k + "@", str(v))
+left = re.findall(r"@[A-Z0-9]+@", t)
+s = open("DESIGN.md").read()
+a = s.index("<!-- round-table-begin")
+a = s.index("\n", a) + 1
+b = s.index("<!-- round-table-end -->")
+open("DESIGN.md", "w").write(s[:a] + t + s[b:])
+print("table regenerated; placeholders left:", sorted(set(left)))
