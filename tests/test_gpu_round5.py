@@ -241,3 +241,50 @@ def test_deployment_flags_through_the_c_abi():
         ctx.streams(2, flags=1 << 9)
     assert ei.value.code == _lib.ERR_INVALID
     ctx.close()
+
+
+def test_rccl_process_group_runs_the_gather_choreography_world1():
+    """SURVEY.md §8e's only exchange, on the real backend: an RCCL ("nccl") process group of ONE rank on this GPU runs the very
+    collectives of the N > 1 bench path - the grouped gather of finished audio on a side stream behind an event fence, the all_gather
+    of checksums, the barrier - with the tensors the 64-stream workload uses ([4 steps, 64 streams, 1280 samples] fp32).  It cannot
+    show scaling; it shows that RCCL initialises on this image and that the calls, shapes and stream usage are what RCCL accepts
+    (the multi-rank choreography itself is driven on gloo by tests/test_distributed_cpu.py)."""
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    try:
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    except Exception as e:  # noqa: BLE001
+        pytest.skip(f"RCCL process group could not be initialised here: {type(e).__name__}: {e}")
+    try:
+        dev = torch.device("cuda", 0)
+        grp = torch.randn(4, 64, 1280, device=dev)
+        out = [torch.empty_like(grp)]
+        side = torch.cuda.Stream()
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            dist.gather(grp, out, dst=0)
+            done.record(side)
+        torch.cuda.current_stream().wait_event(done)
+        assert torch.equal(out[0], grp)
+        csum = grp.view(torch.int32).to(torch.int64).sum().reshape(1)
+        sums = [torch.zeros_like(csum)]
+        dist.all_gather(sums, csum)
+        assert int(sums[0].item()) == int(csum.item())
+        dist.barrier()
+        torch.cuda.synchronize()
+        # ... and the ring class itself with the collective path switched on (always=True): world 1 hands rank 0 its own buffers
+        from conan_amd.engine import AudioGatherRing
+        seen = []
+        ring = AudioGatherRing(lambda: torch.empty(8, 1280, device=dev), 1, 0, always=True, every=4, on_gathered=lambda j, bufs: seen.append((j, bufs[0].clone())))
+        for j in range(9):
+            buf, fence = ring.acquire(j, fence=True)
+            buf.fill_(float(j))
+            ring.submit(j, join=None, wait_current=True)
+        ring.flush(8); ring.drain()
+        assert [j for j, _ in seen] == list(range(9)) and all(float(b.mean()) == float(j) for j, b in seen)
+    finally:
+        dist.destroy_process_group()
