@@ -630,7 +630,9 @@ void conan_streams::build_emformer() {
     }
     { const unsigned long long per_g = (unsigned long long)std::max(c.emf_left_context, 1) * (D / 4); a.magic_per_g = (unsigned)(((1ull << 32) + per_g - 1) / per_g); }
     {  // cluster mode workspace (zeroed once: flags and epochs count up from there)
-      const size_t xf = cnk::emformer_cluster_xch_floats(max_slots, D), fw = cnk::emformer_cluster_flag_words(max_slots);
+      // (the exchange buffer is indexed by cluster, and clusters of more than one workgroup exist only while groups x cs <= CUs: at most
+      // CUs / 2 of them, however many slots the stream-set has - 160 KB per cluster)
+      const size_t xf = cnk::emformer_cluster_xch_floats(std::min(max_slots, std::max(1, ctx->num_cu / 2)), D), fw = cnk::emformer_cluster_flag_words(max_slots);
       a.xch = alloc(xf);
       unsigned* words = reinterpret_cast<unsigned*>(alloc(fw));
       HIP_CHECK(hipMemset(words, 0, fw * sizeof(unsigned)));

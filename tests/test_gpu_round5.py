@@ -1,6 +1,8 @@
 """Round-5 GPU tests: the decoder megakernel's xcd mode (single-tile steps), the one-launch vocoder step of small stream-sets
 (opt-in), the deployment flags of conan_streams_opts, and the reference fixtures at the stream counts where the vocoder's plan
 changes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -243,48 +245,54 @@ def test_deployment_flags_through_the_c_abi():
     ctx.close()
 
 
+_RCCL_WORLD1 = r"""
+import socket, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, ".")
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+try:
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+except Exception as e:
+    print(f"RCCL-INIT-FAILED {type(e).__name__}: {e}"); sys.exit(0)
+dev = torch.device("cuda", 0)
+grp = torch.randn(4, 64, 1280, device=dev)
+out = [torch.empty_like(grp)]
+side = torch.cuda.Stream(); done = torch.cuda.Event()
+with torch.cuda.stream(side):
+    side.wait_stream(torch.cuda.current_stream())
+    dist.gather(grp, out, dst=0)
+    done.record(side)
+torch.cuda.current_stream().wait_event(done)
+assert torch.equal(out[0], grp)
+csum = grp.view(torch.int32).to(torch.int64).sum().reshape(1)
+sums = [torch.zeros_like(csum)]
+dist.all_gather(sums, csum)
+assert int(sums[0].item()) == int(csum.item())
+dist.barrier(); torch.cuda.synchronize()
+from conan_amd.engine import AudioGatherRing
+seen = []
+ring = AudioGatherRing(lambda: torch.empty(8, 1280, device=dev), 1, 0, always=True, every=4, on_gathered=lambda j, bufs: seen.append((j, bufs[0].clone())))
+for j in range(9):
+    buf, fence = ring.acquire(j, fence=True)
+    buf.fill_(float(j))
+    ring.submit(j, join=None, wait_current=True)
+ring.flush(8); ring.drain()
+assert [j for j, _ in seen] == list(range(9)) and all(float(b.mean()) == float(j) for j, b in seen)
+dist.destroy_process_group()
+print("RCCL-WORLD1-OK")
+"""
+
+
 def test_rccl_process_group_runs_the_gather_choreography_world1():
     """SURVEY.md §8e's only exchange, on the real backend: an RCCL ("nccl") process group of ONE rank on this GPU runs the very
     collectives of the N > 1 bench path - the grouped gather of finished audio on a side stream behind an event fence, the all_gather
-    of checksums, the barrier - with the tensors the 64-stream workload uses ([4 steps, 64 streams, 1280 samples] fp32).  It cannot
-    show scaling; it shows that RCCL initialises on this image and that the calls, shapes and stream usage are what RCCL accepts
-    (the multi-rank choreography itself is driven on gloo by tests/test_distributed_cpu.py)."""
-    import socket
-    import torch.distributed as dist
-    if dist.is_initialized():
-        pytest.skip("a process group is already initialised in this process")
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    try:
-        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    except Exception as e:  # noqa: BLE001
-        pytest.skip(f"RCCL process group could not be initialised here: {type(e).__name__}: {e}")
-    try:
-        dev = torch.device("cuda", 0)
-        grp = torch.randn(4, 64, 1280, device=dev)
-        out = [torch.empty_like(grp)]
-        side = torch.cuda.Stream()
-        done = torch.cuda.Event()
-        with torch.cuda.stream(side):
-            side.wait_stream(torch.cuda.current_stream())
-            dist.gather(grp, out, dst=0)
-            done.record(side)
-        torch.cuda.current_stream().wait_event(done)
-        assert torch.equal(out[0], grp)
-        csum = grp.view(torch.int32).to(torch.int64).sum().reshape(1)
-        sums = [torch.zeros_like(csum)]
-        dist.all_gather(sums, csum)
-        assert int(sums[0].item()) == int(csum.item())
-        dist.barrier()
-        torch.cuda.synchronize()
-        # ... and the ring class itself with the collective path switched on (always=True): world 1 hands rank 0 its own buffers
-        from conan_amd.engine import AudioGatherRing
-        seen = []
-        ring = AudioGatherRing(lambda: torch.empty(8, 1280, device=dev), 1, 0, always=True, every=4, on_gathered=lambda j, bufs: seen.append((j, bufs[0].clone())))
-        for j in range(9):
-            buf, fence = ring.acquire(j, fence=True)
-            buf.fill_(float(j))
-            ring.submit(j, join=None, wait_current=True)
-        ring.flush(8); ring.drain()
-        assert [j for j, _ in seen] == list(range(9)) and all(float(b.mean()) == float(j) for j, b in seen)
-    finally:
-        dist.destroy_process_group()
+    of checksums, the barrier - with the tensors the 64-stream workload uses ([4 steps, 64 streams, 1280 samples] fp32), and
+    AudioGatherRing with its collective path switched on.  It cannot show scaling; it shows that RCCL initialises on this image and
+    that the calls, shapes and stream usage are what RCCL accepts (the multi-rank choreography itself is driven on gloo by
+    tests/test_distributed_cpu.py).  In a child process: the process group, and whatever RCCL prints, stay out of this one."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1], cwd=root, capture_output=True, text=True, timeout=600)
+    if "RCCL-INIT-FAILED" in r.stdout:
+        pytest.skip("RCCL process group could not be initialised here: " + r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and "RCCL-WORLD1-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
