@@ -57,6 +57,35 @@ def test_batch64_full_size_streams_are_independent(arith):
     eng.st.close(); solo.st.close(); ctx.close()
 
 
+def test_large_stream_set_with_a_few_scattered_active_slots():
+    """1024 slots (9 GB of per-stream state; the exchange and split-K workspaces must not grow with it), six of them active at
+    scattered indices: the same streams in a 6-slot stream-set agree up to fp32 re-association / the arithmetic form of individual
+    launches (include/conan_hip.h, conan_arith: what is and is not invariant), a re-run reproduces the bits, pipelined == blocking."""
+    from conan_amd.engine import StreamingVoiceConversionEngine
+    ctx, chp, vhp = _full_ctx()
+    slots = [1000, 3, 517, 64, 999, 1]
+    B, T, Tr = len(slots), 12, 40
+    src = torch.from_numpy(np.concatenate([synth.mel(T, 77 + s) for s in range(B)])).cuda()
+    ref = torch.from_numpy(np.concatenate([synth.mel(Tr, 177 + s) for s in range(B)])).cuda()
+    free0 = torch.cuda.mem_get_info()[0]
+    big = StreamingVoiceConversionEngine(ctx, 1024, max_ref_frames=64)
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < 16 * 2**30, f"{used / 2**30:.1f} GiB for 1024 slots"
+    big.slots = slots
+    wav, mel, codes = big.infer(src, ref)
+    assert wav.shape == (B, T * 320) and torch.isfinite(wav).all()
+    small = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=64)
+    w1, m1, c1 = small.infer(src, ref)
+    assert torch.equal(c1, codes)
+    np.testing.assert_allclose(m1.cpu().numpy(), mel.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(w1.cpu().numpy(), wav.cpu().numpy(), atol=2e-5, rtol=0)
+    wav2, mel2, _ = big.infer(src, ref)
+    assert torch.equal(wav, wav2) and torch.equal(mel, mel2)
+    wav3, mel3, codes3 = big.infer(src, ref, pipelined=False)
+    assert torch.equal(wav, wav3) and torch.equal(mel, mel3) and torch.equal(codes, codes3)
+    big.st.close(); small.st.close(); ctx.close()
+
+
 def test_windowed_mode_matches_reference_windows():
     """configs[1]/[4] windowed mode = state reset + (ctx + chunk) frames in one step, emit the last chunk.  Oracle:
     the reference module fed the same window (golden mel_out_win{8,16,32}, tools/make_goldens.py)."""
