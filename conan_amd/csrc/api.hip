@@ -171,6 +171,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
       // (a CU-masked front-end stream - developer switch - cannot hold the megakernel's grid resident: its barriers would never complete)
       { const char* e = getenv("CONAN_FRONT_CUSTRIDE"); if (e && atoi(e) >= 2) s->use_mega = false; }
       { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
+      { const char* e = getenv("CONAN_MEGA_NARROW"); if (e && e[0] == '0') s->mega_narrow_ksplit = false; }      // developer A/B switch
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
       s->mega_x = reinterpret_cast<unsigned*>(s->alloc(256 + 32 * 64));
 

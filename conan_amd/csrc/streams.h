@@ -248,6 +248,7 @@ struct conan_streams {
   bool use_mega = true;                          // CONAN_DEC_MEGA=0: the decoder step as separate launches
   int mega_grid = 128;                           // CONAN_MEGA_GRID
   int mega_gs = 8;                               // workgroups per group (CONAN_MEGA_GS: 4, 8 or 16)
+  bool mega_narrow_ksplit = true;                // narrow layers of multi-tile launches as K-split 16-column strips (CONAN_MEGA_NARROW=0: off)
   int mega_ffn_gs = 8;                           // members of a fused feed-forward while a program is recorded (run_mega)
   unsigned* mega_bar = nullptr;                  // the grid barrier's arrival counter (counts for ever); the group counters follow it, 16 words apart
   unsigned mega_bar_count = 0;                   // its value once every launch enqueued so far has finished

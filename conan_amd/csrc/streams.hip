@@ -152,6 +152,21 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     int ldsf = 0;
     const int v = cnk::rowconv_plan(op.u.rc, &op.nbx, &op.nby, &ldsf);
     op.type = v == 3 ? cnk::MOP_ROWLIN : (v == 2 ? cnk::MOP_RC114 : cnk::MOP_RC111);
+    // Several row tiles, a narrow layer (at most half as many 64-column strips as the group has members: the uv predictor's 128-wide
+    // convs, the 256-wide 1x1 / k3 layers): 16-column strips with the K groups split over a workgroup's waves instead - every member
+    // works, a wave's chain of MFMAs is a quarter as long - where the K-split patch (3 KB) still fits under the launch's LDS contract
+    // (the k = 5, 256-channel window: tests/test_kernel_resources.py).  Results differ from the 64-column form by fp32 re-association.
+    // (measured per operator at 64 streams, us: the uv predictor's 128 -> 128 k5 convs 9.0 -> 5.6, mel_out 6.4 -> 4.7, the 256 -> 256 k3 convs
+    // 10.5 / 12.0 -> 9.8 / 10.6 - but the 256 -> 256 1x1 layers 6.5 -> 8.0: four waves' partial tiles through LDS for 16 K groups each
+    // is more than the chain it shortens.  So: a quarter as many strips as members, or half as many with at least 3 taps.)
+    const int strips64 = (op.u.rc.Cout_pad + 63) / 64;
+    if (v == 0 && !a.w2 && a.n * a.T > 16 && mega_narrow_ksplit && (strips64 * 4 <= mega_gs || (strips64 * 2 <= mega_gs && a.ktaps >= 3)) && (a.ktaps * (a.Cin >> 4)) % 4 == 0) {
+      const int ldsk = (32 + op.u.rc.wr_max * (a.Cin + 8) + 3 * 64 * 4);      // rowconv_lds_bytes(a, true) / 4
+      cnk::MegaOp t = op; t.type = cnk::MOP_RC114;
+      if (cnk::decoder_mega_lds_floats(t, ldsk) * 4 <= (96 + 32 * 264) * 4) {
+        op.type = cnk::MOP_RC114; op.nbx = (op.u.rc.Cout_pad + 15) / 16; ldsf = ldsk;
+      }
+    }
     if (a.w2) {        // fused conv -> 1x1 conv: behind the window, the member's 16 x (Cout / 8 + 8) hidden tile - or, with a single 64-column
                        // hidden strip per member (the decoder's conv blocks), in the window's place once every wave has read it out
       // (v == 2: a single row tile - the plan of the plain conv would split K over the waves; the fused operator has its own geometry)
