@@ -2,7 +2,7 @@
 
 | | bf16-limb (default, headline) | exact-f32 MFMA (`--arith f32`) |
 |---|---|---|
-| B = 64 streams, full pipeline, pipelined steps | **@MS64@ ms per step = @V64@ k chunks/s** (@RT64@ real-time streams; unprimed @UNP64@; 1.33-1.38 across the boxes of this round's runs) | @F32MS@ ms |
+| B = 64 streams, full pipeline, pipelined steps | **@MS64@ ms per step = @V64@ k chunks/s** (@RT64@ real-time streams; unprimed @UNP64@; 1.33-1.38 across the boxes of this round's runs, whose vocoder-alone times range from 1.19 to 1.25 ms) | @F32MS@ ms |
 | same, blocking fused steps | **p50 @P50@ ms** (p95 @P95@; round 4: 2.02) | p50 @F32P50@ ms |
 | B = 1 / B = 4 streams, blocking p50 | **@B1@ / @B4@ ms** per 80 ms chunk (round 4: 0.906 / 0.95) | @F32B1@ |
 | dominant kernel (9 launches per step, 105.7 GFLOP algorithmic) | `cnk::resblock_limb_kernel`: @KMS@ ms = **@ACH@ TFLOP/s = @FRAC@ of the limb ceiling** (419.5); C = 128 / 64 / 32: @F128@ / @F64@ / @F32C@ | `cnk::resblock_fused_kernel` @F32FRAC@ of 157.3 |
