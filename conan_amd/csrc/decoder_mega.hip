@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
         } break;
         case MOP_XATTN: {
           const auto& a = MG_AS4(XAttnArgs, &op->u);
-          for (int r0 = sb * 2; r0 < ro::RC_TM; r0 += GS * 2) { __syncthreads(); ro::mg_xattn_rows<CM>(a, tab, r0, lds); }
+          for (int r0 = sb * 2; r0 < ro::RC_TM; r0 += GS * 2) { __syncthreads(); ro::mg_xattn_rows<CM, (OCC < 6)>(a, tab, r0, lds); }
         } break;
         case MOP_PITCH: {
           const auto& a = MG_AS4(PitchHeadArgs, &op->u);
