@@ -137,7 +137,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
     HIP_CHECK(hipSetDevice(ctx->device));
     conan_streams* s = new conan_streams();
     try {
-      s->ctx = ctx; s->max_slots = max_slots; s->max_frames = std::max(max_frames, ctx->cfg.emf_segment); s->max_ref = std::max(4, max_ref_frames);
+      s->ctx = ctx; s->live = ctx->live_streams; s->live->fetch_add(1); s->max_slots = max_slots; s->max_frames = std::max(max_frames, ctx->cfg.emf_segment); s->max_ref = std::max(4, max_ref_frames);
       s->d_slots = (int*)s->alloc(max_slots + 1); s->d_ident = (int*)s->alloc(max_slots + 1); s->d_zero = (int*)s->alloc(max_slots);
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);

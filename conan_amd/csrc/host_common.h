@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -87,6 +89,8 @@ struct conan_ctx {
   int64_t weight_bytes = 0;
   int hop = 1;
   int num_cu = 256;
+  // stream-sets of this context that exist right now (conan_streams_create .. _destroy); shared: a stream-set may outlive its context's handle
+  std::shared_ptr<std::atomic<int>> live_streams = std::make_shared<std::atomic<int>>(0);
   bool has_limb_weights = false;   // finalize packed bf16-limb copies of the vocoder's conv weights (resblock_limb.hip / conv_limb.hip)
 
   float* dev_alloc(size_t floats, bool zero = true);

@@ -56,6 +56,7 @@ struct PinRing {
 
 struct conan_streams {
   conan_ctx* ctx = nullptr;
+  std::shared_ptr<std::atomic<int>> live;      // the context's count of live stream-sets
   int max_slots = 0, max_frames = 0, max_ref = 0, S_max = 0;
   std::vector<void*> allocs;
   int64_t state_bytes = 0;
@@ -187,6 +188,7 @@ struct conan_streams {
 
   void mega_print_stamps();
   ~conan_streams() {
+    if (live) live->fetch_sub(1);
     if (mega_dbg) mega_print_stamps();
     if (st_emf) (void)hipStreamDestroy(st_emf);
     if (st_front) (void)hipStreamDestroy(st_front);

@@ -676,15 +676,21 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       // once (one 129 KB workgroup per CU).  The developer override is clamped to that like the automatic choice, and a
       // CU-masked Emformer stream (CONAN_EMF_CUSTRIDE) gets no clusters at all.
       static const bool masked = getenv("CONAN_EMF_CUSTRIDE") != nullptr && atoi(getenv("CONAN_EMF_CUSTRIDE")) >= 2;
-      // (Pipelined steps - the launch is on the stream-set's own Emformer stream: at most 64 workgroups.  A workgroup needs a whole CU
-      // for the launch's 150-250 us, and the vocoder's persistent launches run beside it on what is left.  Measured per pipelined step
-      // at 32 / 48 / 64 streams and 128 streams of 40 ms chunks, 128 -> 64 workgroups: 0.990 -> 0.979, 1.175 -> 1.154, 1.336 -> 1.317,
-      // 1.516 -> 1.509 ms; 256 workgroups cost the vocoder 6 % of the step.  Blocking steps and direct calls - any other stream - have the
-      // chip to themselves for the launch and take one workgroup per CU: 64 streams 190 -> 141 us.  Round 5: the feed-forward's sum is
-      // formed chunk by chunk in chunk order whatever the cluster size (emformer_fused.hip), so the two step styles - which until then had
-      // to use the same split - still produce the same bits.)
+      // (At most 64 workgroups - unless this launch cannot overlap anything else of the context.  A workgroup needs a whole CU for the
+      // launch's 150-250 us.  In pipelined steps - the launch is on the stream-set's own Emformer stream - the vocoder's persistent
+      // launches run beside it on what is left: 128 -> 64 workgroups measured 0.990 -> 0.979, 1.175 -> 1.154, 1.336 -> 1.317, 1.516 ->
+      // 1.509 ms per pipelined step at 32 / 48 / 64 streams and 128 streams of 40 ms chunks; 256 cost the vocoder 6 % of the step.
+      // And the limit is what keeps launches that wait inside themselves from deadlocking each other: cluster members wait for
+      // partners that need WHOLE CUs, the decoder launch's 128 workgroups and the f32 pair kernel's partners wait for workgroups that
+      // need PART of one - with the Emformer on more than CUs - 128 - .. workgroups two overlapping launches can each hold what the
+      // other still needs (round 5: one workgroup per CU in every blocking step made tests/test_gpu_stress.py, whose blocking and
+      // pipelined stream-sets overlap on the device, give up in the pair kernel's mailbox wait one run in five).  So one workgroup per
+      // CU - 64 streams: 190 -> 136 us on the blocking chunk's critical path - only for a blocking step of the ONLY stream-set of its
+      // context: its launches are serialised on one stream.  The feed-forward's sum is formed chunk by chunk in chunk order whatever the
+      // cluster size (emformer_fused.hip), so the step styles and both policies produce the same bits.)
       const bool pipelined = st_emf != nullptr && st == st_emf;       // (the internal stream exists only once a pipelined step has run; a caller's null stream is not it)
-      const int cap = (emf_cluster > 0 || !pipelined) ? ctx->num_cu : 64;
+      const bool alone = !pipelined && live && live->load() == 1;
+      const int cap = (emf_cluster > 0 || alone) ? ctx->num_cu : 64;
       a.cs = emf_cluster > 0 ? std::min(emf_cluster, (int)cnk::EMF_MAX_CLUSTER) : cnk::EMF_MAX_CLUSTER;
       while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two
       while (a.cs > 1 && groups * a.cs > cap) a.cs >>= 1;
