@@ -380,6 +380,49 @@ def dominant(prof):
             "launches_per_step": k_n / prof["nprof"], "avg_launch_us": k_ms * 1e3 / k_n, "gflop_per_launch": k_fl / k_n / 1e9, "instantiations": insts}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(gpus, argv, env=None, port=None):
+    """`python bench.py --gpus N` without a launcher around it (the shape of the driver's N = 1 command) has to measure N GPUs:
+    -> the torch.distributed.run command that starts the N ranks (one process per GPU, RCCL over xGMI, rendezvous on
+    127.0.0.1), or None when this process IS a rank already (WORLD_SIZE / RANK set by a launcher: no recursion) or N = 1.
+    BASELINE.json configs[3] (512 streams over 8 GPUs) is this path."""
+    env = os.environ if env is None else env
+    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(gpus, argv):
+    """Run the N ranks as a CHILD process (never exec: this must also be safe in a process that has touched the GPU), relay
+    their output, return their exit code; None when there is nothing to spawn.  Asking for more GPUs than the node has is an
+    error here, before anything is launched (torch.cuda.device_count() does not initialise the GPU)."""
+    cmd = launcher_command(gpus, argv)
+    if cmd is None:
+        return None
+    have = torch.cuda.device_count()
+    if have < gpus:
+        print(f"bench.py: --gpus {gpus} but this node has {have} GPU(s)", file=sys.stderr)
+        return 2
+    import subprocess
+    return subprocess.run(cmd, env=dict(os.environ)).returncode
+
+
+def check_ranks(gpus, world, devices):
+    """A rank's view must be the job that was asked for: -> error text or None."""
+    if world != gpus:
+        return f"--gpus {gpus} but WORLD_SIZE={world}: start bench.py with --gpus equal to the launcher's --nproc-per-node (or without a launcher: it starts its own ranks)"
+    if devices < world:
+        return f"{world} ranks but {devices} visible GPU(s): one process per GPU"
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -399,11 +442,14 @@ def main():
                                                          "every other leg (rocprofv3 --pmc passes: tools/summarize_pmc.py keeps the dispatches between the marks)")
     args = ap.parse_args()
 
+    rc = spawn_ranks(args.gpus, sys.argv[1:])      # --gpus N > 1 outside a launcher: this process only starts the N ranks
+    if rc is not None:
+        raise SystemExit(rc)
+    err = check_ranks(args.gpus, int(os.environ.get("WORLD_SIZE", "1")), torch.cuda.device_count())
+    if err:
+        raise SystemExit("bench.py: " + err)
     from conan_amd.engine import init_distributed
     rank, local, world = init_distributed()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
@@ -447,6 +493,8 @@ def main():
                      "ms_per_step_max": max(float(r[0].item()) for r in allr) / args.steps * 1e3,
                      "gathers": ring.submitted, "gather_every": ring.every,
                      "gather_check": {"step": gj, "ok": got == want, "checksums_rank0_gathered": got, "checksums_ranks_own": want}}
+            if ranks["rccl_world"] != args.gpus or len(set(ranks["devices"])) != args.gpus:
+                raise SystemExit("bench.py: asked for %d GPUs, ran on RCCL world %d over devices %r" % (args.gpus, ranks["rccl_world"], ranks["devices"]))
             if got != want:
                 raise SystemExit("bench.py: the audio gathered on rank 0 differs from what the ranks produced: %r vs %r" % (got, want))
     else:

@@ -2,11 +2,14 @@
 (stream-sharded data parallelism)."""
 import os
 import socket
+import sys
 
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from conan_amd.engine import gather_audio, gather_audio_equal, shard_range
 
@@ -206,3 +209,51 @@ def test_bench_gather_check_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---- bench.py starts its own ranks (task 1): `python bench.py --gpus N` without a launcher must measure N GPUs ----
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launcher_command_and_no_recursion():
+    b = _bench_module()
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = b.launcher_command(8, argv, env={}, port=29611)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    k = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[k + 1:] == argv                                  # the ranks get the very same arguments
+    # a process that is a rank already (started by torch.distributed.run, the driver's N > 1 form) never spawns again
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        assert b.launcher_command(8, argv, env={var: "1"}) is None
+    assert b.launcher_command(1, ["--gpus", "1"], env={}) is None
+    # a free port is chosen when none is given
+    assert int(b.launcher_command(2, [], env={})[cmd.index("--master-port") + 1]) > 0
+
+
+def test_bench_rank_count_mismatch_is_an_error_not_a_warning():
+    b = _bench_module()
+    assert b.check_ranks(8, 8, 8) is None and b.check_ranks(1, 1, 1) is None
+    assert "WORLD_SIZE=2" in b.check_ranks(8, 2, 8)
+    assert "one process per GPU" in b.check_ranks(2, 2, 1)
+
+
+def test_bench_asked_for_more_gpus_than_the_node_has_exits_nonzero():
+    """This container has no GPU (a 1-GPU box asked for 2 takes the same branch): nothing is launched, exit code != 0."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "GPU(s)" in r.stderr
+    assert r.stdout.strip() == ""                              # no JSON line for a job that did not run
+    # a rank whose WORLD_SIZE disagrees with --gpus refuses as well
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
