@@ -99,11 +99,15 @@ def build_context(device, chunk_ms=80, memory=0):
     return ctx, chp, vhp
 
 
+STREAM_OPTS = {"flags": 0, "dev_plan": None}      # conan_streams_opts.flags / .dev_plan of every stream-set this run creates (--fixed-plan, --dev-plan)
+
+
 def make_engine(ctx, B, first_stream, window=0, arith="auto"):
     """B streams with their reference set and every full chunk of the 3 s utterance staged in HBM."""
     from conan_amd import synth
     from conan_amd.engine import StreamingVoiceConversionEngine
-    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1, max_frames=window + ctx.cfg.emf_segment if window else None, arith=arith)
+    eng = StreamingVoiceConversionEngine(ctx, B, max_ref_frames=N_REF + 1, max_frames=window + ctx.cfg.emf_segment if window else None, arith=arith,
+                                         flags=STREAM_OPTS["flags"], dev_plan=STREAM_OPTS["dev_plan"])
     src = np.concatenate([synth.mel(N_FRAMES, 1234 + first_stream + s) for s in range(B)])
     ref = np.concatenate([synth.mel(N_REF, 4321 + first_stream + s) for s in range(B)])
     src = torch.from_numpy(src).cuda()
@@ -207,7 +211,7 @@ def pmc_summary(tag):
     from inside the benchmark): profiles/r<round>_<tag>_pmc.json, made by tools/collect_profiles.sh + tools/summarize_pmc.py
     (newest round first).  The summary records the sha256 of the library it was collected with; `stale` says whether that
     differs from the library loaded now (a summary without a hash counts as stale)."""
-    for rnd in ("r5", "r4"):
+    for rnd in ("r6", "r5", "r4"):
         path = os.path.join(REPO, "profiles", f"{rnd}_{tag}_pmc.json")
         try:
             d = json.load(open(path))
@@ -434,6 +438,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: the workload's)")
     ap.add_argument("--prime", type=int, default=int(os.environ.get("CONAN_BENCH_PRIME", "100")),
                     help="setup: pipelined steps run once after the stream-set is built, before the W warm-up steps (0: none)")
+    ap.add_argument("--fixed-plan", action="store_true", help="CONAN_STREAMS_FIXED_PLAN: the launch plan from max_slots only (a stream's bits do not depend on the other active slots)")
+    ap.add_argument("--dev-plan", default=None, help="developer switches of the launch plan, 'NAME=value;...' (conan_streams_opts.dev_plan; A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-steps", type=int, default=40)
     ap.add_argument("--no-b1", action="store_true", help="skip the batch=1 latency leg (keeps profiler summaries to one workload)")
@@ -453,6 +459,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
+    from conan_amd import _lib
+    STREAM_OPTS["flags"] = _lib.STREAMS_FIXED_PLAN if args.fixed_plan else 0
+    STREAM_OPTS["dev_plan"] = args.dev_plan
     wl = WORKLOADS[args.workload]
     B = args.streams or wl["streams"]
     window = wl["window"]
@@ -638,7 +647,7 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[arith], "data": "synthetic",
             "config": {"workload": wl["desc"] if not args.streams else f"batch={B} streams per GPU, {wl['chunk_ms']} ms chunk" + (", windowed" if window else ", stateful"),
-                       "name": args.workload, "baseline_config": wl["config"], "arith": arith, "arith_requested": args.arith,
+                       "name": args.workload, "baseline_config": wl["config"], "arith": arith, "arith_requested": args.arith, "fixed_plan": bool(args.fixed_plan), "dev_plan": args.dev_plan,
                        "streams_per_gpu": B, "global_streams": world * B, "chunk_ms": wl["chunk_ms"], "context_window_frames": window, "sample_rate": 16000,
                        "architecture": "egs/conan_emformer.yaml + egs/hifi_16k320_shuffle.yaml shapes, random-init weights",
                        "parallelism": f"dp{world} (streams sharded by slot range; RCCL gather of audio to rank 0)" if world > 1 else "dp1",

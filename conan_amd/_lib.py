@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libconan_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "conan_hip.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_UPS, MAX_RESBLOCKS, MAX_DILATIONS, MAX_DEC_BLOCKS = 8, 4, 4, 16
 MODEL_EMFORMER, MODEL_CONAN, MODEL_HIFIGAN = 1, 2, 4
 
@@ -43,11 +43,12 @@ class ConanCfg(C.Structure):
 
 class StreamsOpts(C.Structure):
     """conan_streams_opts (include/conan_hip.h)."""
-    _fields_ = [("abi_version", C.c_int32), ("arith", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("abi_version", C.c_int32), ("arith", C.c_int32), ("flags", C.c_int32), ("reserved0", C.c_int32),
+                ("dev_plan", C.c_char_p), ("reserved", C.c_int32 * 2)]
 
 
-# conan_streams_opts.flags
-STREAMS_FUSED_DECODER_BLOCKS, STREAMS_SEPARATE_SMALL_STEPS, STREAMS_VOCODER_CHAIN = 1, 2, 4
+# conan_streams_opts.flags (bit 4 - ABI 7's VOCODER_CHAIN - is retired and rejected)
+STREAMS_FUSED_DECODER_BLOCKS, STREAMS_SEPARATE_SMALL_STEPS, STREAMS_FIXED_PLAN, STREAMS_SHARED_DEVICE = 1, 2, 8, 16
 
 
 class ConanError(RuntimeError):

@@ -129,7 +129,8 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
       if (opts->abi_version != CONAN_HIP_ABI_VERSION) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.abi_version mismatch");
       for (int r : opts->reserved) if (r != 0) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.reserved must be 0");
       arith = opts->arith; flags = opts->flags;
-      if (flags & ~(CONAN_STREAMS_FUSED_DECODER_BLOCKS | CONAN_STREAMS_SEPARATE_SMALL_STEPS | CONAN_STREAMS_VOCODER_CHAIN)) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.flags: unknown bits");
+      if (opts->reserved0 != 0) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.reserved0 must be 0");
+      if (flags & ~(CONAN_STREAMS_FUSED_DECODER_BLOCKS | CONAN_STREAMS_SEPARATE_SMALL_STEPS | CONAN_STREAMS_FIXED_PLAN | CONAN_STREAMS_SHARED_DEVICE)) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.flags: unknown bits");
       if (arith != CONAN_ARITH_AUTO && arith != CONAN_ARITH_F32 && arith != CONAN_ARITH_LIMB) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.arith: 0 (auto), 1 (f32) or 2 (limb)");
     }
     if (!ctx->finalized) throw Error(CONAN_ERR_STATE, "conan_ctx_finalize must run before conan_streams_create");
@@ -137,41 +138,36 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
     HIP_CHECK(hipSetDevice(ctx->device));
     conan_streams* s = new conan_streams();
     try {
-      s->ctx = ctx; s->live = ctx->live_streams; s->live->fetch_add(1); s->max_slots = max_slots; s->max_frames = std::max(max_frames, ctx->cfg.emf_segment); s->max_ref = std::max(4, max_ref_frames);
-      s->d_slots = (int*)s->alloc(max_slots + 1); s->d_ident = (int*)s->alloc(max_slots + 1); s->d_zero = (int*)s->alloc(max_slots);
+      s->parse_dev_plan(opts ? opts->dev_plan : nullptr);
+      s->fixed_plan = (flags & CONAN_STREAMS_FIXED_PLAN) != 0; s->shared_device = (flags & CONAN_STREAMS_SHARED_DEVICE) != 0;
+      s->ctx = ctx; s->live = &device_live_streams(ctx->device); s->live->fetch_add(1); s->max_slots = max_slots; s->max_frames = std::max(max_frames, ctx->cfg.emf_segment); s->max_ref = std::max(4, max_ref_frames);
+      s->d_slots = (int*)s->alloc(max_slots + cnk::kSlotTablePad); s->d_ident = (int*)s->alloc(max_slots + 1); s->d_zero = (int*)s->alloc(max_slots);
       s->d_lens = (int*)s->alloc(max_slots); s->d_lens2 = (int*)s->alloc(max_slots);
       s->d_codes = (int*)s->alloc((size_t)max_slots * s->max_frames * 2);
       s->sk_slab_floats = 8ll << 20; s->sk_max_tiles = 4096;
       for (int w = 0; w < 3; ++w) { s->sk_slab[w] = s->alloc((size_t)s->sk_slab_floats); s->sk_counters[w] = (int*)s->alloc(s->sk_max_tiles); }
       for (int w = 0; w < 2; ++w) s->rb_sched[w] = (int*)s->alloc(4);
       for (int w = 0; w < 3; ++w) s->cp_ticket[w] = (int*)s->alloc(4);
-      { const char* e = getenv("CONAN_RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
-      { const char* e = getenv("CONAN_ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
-      s->rb_merge = getenv("CONAN_RB_NOMERGE") == nullptr;
+      { const char* e = s->dev("RESERVE_CUS"); s->reserve_cus = e ? atoi(e) : 0; }
+      { const char* e = s->dev("ROWCONV"); s->use_rowconv = !(e && e[0] == '0'); }
+      s->rb_merge = s->dev("RB_NOMERGE") == nullptr;
       // fp32 products of the vocoder's matrix kernels as six bf16 limb products (resblock_limb.hip, conv_limb.hip) or on the
       // f32-input MFMA: conan_streams_opts.arith.  AUTO = the limb form wherever the context packed limb weights (ResBlock1
       // vocoders); the developer switch CONAN_RB_NOLIMB=1 turns AUTO into F32 for A/B runs - it never overrides an explicit request.
       if (arith == CONAN_ARITH_LIMB && !((ctx->cfg.models & CONAN_MODEL_HIFIGAN) && ctx->has_limb_weights))
         throw Error(CONAN_ERR_UNSUPPORTED, "arith = limb: this context holds no bf16-limb weights (no HiFi-GAN model, or a vocoder configuration without limb kernels)");
       s->arith_auto = arith == CONAN_ARITH_AUTO;
-      s->rb_limb = arith == CONAN_ARITH_LIMB || (arith == CONAN_ARITH_AUTO && ctx->has_limb_weights && getenv("CONAN_RB_NOLIMB") == nullptr);
-      // small stream-sets (one mel row tile per step) run the vocoder step as one persistent launch on the f32 MFMA (voc_chain.hip)
-      // unless the caller asked for the limb arithmetic: AUTO resolves to F32 there (conan_streams_arith says so)
-      // deployment flags (conan_streams_opts.flags); the environment variables of earlier rounds stay as developer overrides
+      s->rb_limb = arith == CONAN_ARITH_LIMB || (arith == CONAN_ARITH_AUTO && ctx->has_limb_weights && s->dev("RB_NOLIMB") == nullptr);
+      // deployment flags (conan_streams_opts.flags)
       s->opt_flags = flags;
-      if (getenv("CONAN_MEGA_BLK")) s->opt_flags |= CONAN_STREAMS_FUSED_DECODER_BLOCKS;
-      { const char* e = getenv("CONAN_MEGA_SINGLE"); if (e && e[0] == '0') s->opt_flags |= CONAN_STREAMS_SEPARATE_SMALL_STEPS; }
-      { const char* e = getenv("CONAN_VOC_CHAIN"); if (e && e[0] == '1') s->opt_flags |= CONAN_STREAMS_VOCODER_CHAIN; }
       s->mega_single = !(s->opt_flags & CONAN_STREAMS_SEPARATE_SMALL_STEPS);
-      s->voc_chain = s->chain_eligible(arith == CONAN_ARITH_LIMB);
-      if (s->voc_chain) s->rb_limb = false;
-      { const char* e = getenv("CONAN_FENCED"); s->fenced = e && e[0] == '1'; }
-      { const char* e = getenv("CONAN_DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
-      { const char* e = getenv("CONAN_MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }
+      { const char* e = s->dev("FENCED"); s->fenced = e && e[0] == '1'; }
+      { const char* e = s->dev("DEC_MEGA"); s->use_mega = !(e && e[0] == '0'); }
+      { const char* e = s->dev("MEGA_GRID"); if (e && atoi(e) > 0) s->mega_grid = std::min(atoi(e), ctx->num_cu); }
       // (a CU-masked front-end stream - developer switch - cannot hold the megakernel's grid resident: its barriers would never complete)
-      { const char* e = getenv("CONAN_FRONT_CUSTRIDE"); if (e && atoi(e) >= 2) s->use_mega = false; }
-      { const char* e = getenv("CONAN_MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
-      { const char* e = getenv("CONAN_MEGA_NARROW"); if (e && e[0] == '0') s->mega_narrow_ksplit = false; }      // developer A/B switch
+      { const char* e = s->dev("FRONT_CUSTRIDE"); if (e && atoi(e) >= 2) s->use_mega = false; }
+      { const char* e = s->dev("MEGA_GS"); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16)) s->mega_gs = atoi(e); }
+      { const char* e = s->dev("MEGA_NARROW"); if (e && e[0] == '0') s->mega_narrow_ksplit = false; }      // developer A/B switch
       s->mega_bar = reinterpret_cast<unsigned*>(s->alloc(16 * (size_t)(ctx->num_cu + 2)));
       s->mega_x = reinterpret_cast<unsigned*>(s->alloc(256 + 32 * 64));
 
@@ -184,7 +180,7 @@ int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int
         HIP_CHECK(hipMemcpy(s->d_guard + 2, &hdev, sizeof(hdev), hipMemcpyHostToDevice));
       }
       s->slot_seen.assign(max_slots, 0); s->has_ref.assign(max_slots, 0); s->voc_fresh.assign(max_slots, 1);
-      s->pin.init((size_t)max_slots + 1);
+      s->pin.init((size_t)max_slots + cnk::kSlotTablePad);
       s->pos_emf = (int*)s->alloc(max_slots); s->pos_dec = (int*)s->alloc(max_slots); s->pos_voc = (int*)s->alloc(max_slots);
       std::vector<int> id(max_slots);
       for (int i = 0; i < max_slots; ++i) id[i] = i;
@@ -445,9 +441,9 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     int* codes_seg = s->codes_hand[p];
     // developer timing switch (results are then meaningless): CONAN_SKIP_STAGE bit 0 skips the Emformer launch, bit 1 the decoder's
 #ifdef CONAN_DEV_SWITCHES        // `make DEV=1`: timing experiments only, never in the shipped library (a skipped stage returns garbage with CONAN_OK)
-    static const int skip = getenv("CONAN_SKIP_STAGE") ? atoi(getenv("CONAN_SKIP_STAGE")) : 0;
+    static const int skip = ch::dev_getenv("CONAN_SKIP_STAGE") ? atoi(ch::dev_getenv("CONAN_SKIP_STAGE")) : 0;
     // (the Emformer's workgroups need whole CUs for ~0.15 ms; they are kept away from the pair kernel's launches: see ev_wide)
-    static const bool hold = getenv("CONAN_EMF_HOLD") != nullptr;      // (off by default: see streams.h, ev_wide)
+    static const bool hold = ch::dev_getenv("CONAN_EMF_HOLD") != nullptr;      // (off by default: see streams.h, ev_wide)
 #else
     constexpr int skip = 0; constexpr bool hold = false;
 #endif

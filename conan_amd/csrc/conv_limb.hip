@@ -121,8 +121,8 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
         roff[u] = -1; loff[u] = 0;
         if (idx < total) {
           const int w = idx >> 3, c4 = idx & 7, s = w / wrs, o = w - s * wrs;
-          // (a last tile with fewer slots than it has room for - an odd number of streams in 2-slot tiles - reads slot-table entry n:
-          // the host keeps a copy of the last slot there, conan_streams::set_slots)
+          // (a last tile with fewer slots than it has room for reads slot-table entries n .. n + TM / T - 2: the host keeps
+          // kSlotTablePad copies of the last slot there, conan_streams::set_slots)
           const int i = i0 + s, slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
           const int row = ((ring ? pv * xrate : 0) + xoff + ta + o) & xmask;
           roff[u] = (int)((long long)(ring ? slot : i) * xss) + row * xC + c4 * 4;
@@ -453,6 +453,8 @@ bool shape_fits(const CLShape& s, const ConvArgs& a, bool ragged_ok) {
   // rule that its rows divide into tiles: ragged 160-row tiles measured 104 us against 70 us of its f32 launch.  Tiles inside a slot
   // must divide it.)
   if (a.T < TM ? ((TM % a.T) != 0 || (!ragged_ok && (M % TM) != 0)) : ((a.T % TM) != 0 || (M % TM) != 0)) return false;
+  // (a ragged last tile reads the slot table up to TM / T - 1 entries past n: the table carries kSlotTablePad copies of the last slot)
+  if (a.T < TM && (M % TM) != 0 && TM / a.T - 1 > kSlotTablePad) return false;
   const int cols = ((a.Cout + 15) / 16) * 16;
   return cols % TN == 0;
 }
@@ -472,8 +474,10 @@ bool conv_limb_supported(const ConvArgs& a) {
 
 // tile shape index for a group of problems (same n, T and column count), or -1: the shape with the smallest estimated
 // makespan among those that fit and give every CU a tile
-int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu) {
-  static const int forced = (getenv("CONAN_CL_SHAPE") && *getenv("CONAN_CL_SHAPE")) ? atoi(getenv("CONAN_CL_SHAPE")) : -1;      // developer switch
+// plan_n > 0 (fixed-plan stream-sets): tile counts, the fill-the-chip thresholds and the cost model use plan_n slots instead of the
+// launch's own, and a last tile may be ragged for a single problem too - the choice must not depend on the active slots
+int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n) {
+  static const int forced = (dev_getenv("CONAN_CL_SHAPE") && *dev_getenv("CONAN_CL_SHAPE")) ? atoi(dev_getenv("CONAN_CL_SHAPE")) : -1;      // developer switch
   int best = -1; double best_cost = 1e30;
   for (int si = 0; si < kNumShapes; ++si) {
     const CLShape& s = kShapes[si];
@@ -482,11 +486,11 @@ int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu) {
     double units = 0, umax = 0;
     long long tiles = 0;
     for (int q = 0; q < nprob && ok; ++q) {
-      ok = shape_fits(s, p[q], nprob > 1);
+      ok = shape_fits(s, p[q], nprob > 1 || plan_n > 0);
       if (!ok) break;
       const int Tt = std::min(p[q].T, TM), wr = (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil);
       if (wr > 32 * CL_NIT || (size_t)2 * 3 * wr * CL_LDB * 2 > 126 * 1024) { ok = false; break; }
-      const long long t = (((long long)p[q].n * p[q].T + TM - 1) / TM) * ((((p[q].Cout + 15) / 16) * 16) / TN);
+      const long long t = (((long long)(plan_n > 0 ? plan_n : p[q].n) * p[q].T + TM - 1) / TM) * ((((p[q].Cout + 15) / 16) * 16) / TN);
       const double u = (double)p[q].ktaps * p[q].Cin * TM * TN;
       tiles += t; units += u * t; umax = std::max(umax, u);
     }

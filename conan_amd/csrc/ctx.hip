@@ -13,7 +13,6 @@ using ch::HostTensor;
 using ch::PackedConv;
 
 conan_ctx::~conan_ctx() {
-  if (chain_done) (void)hipEventDestroy(chain_done);
   for (void* p : allocs) (void)hipFree(p);
 }
 

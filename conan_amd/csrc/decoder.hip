@@ -76,7 +76,7 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
     mega_rec = &ops; mega_rec_ok = true; mega_rec_lds = 0; mega_rec_flops = 0.0;
     // members a fused feed-forward's hidden columns are split over: the group's workgroups, or - a single row tile, whose group forms
     // at run time (xcd mode) - one virtual member per 64 hidden columns
-    mega_ffn_gs = n * T <= 16 ? std::max(1, (int)ctx->conv("conan.align.0.ff1").Cout / 64) : mega_gs;
+    mega_ffn_gs = plan_n(n) * T <= 16 ? std::max(1, (int)ctx->conv("conan.align.0.ff1").Cout / 64) : mega_gs;
     try {
       if (ex.codes_dst) {      // the caller's copy of the step's codes: independent of everything else
         cnk::MegaOp op; memset(&op, 0, sizeof(op));
@@ -116,8 +116,8 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
       // A single tile (<= 16 rows: one to four streams): xcd mode - one workgroup per CU is launched (enough dynamic LDS that two do
       // not share a CU), the ~32 that land on workgroup 0's XCD walk the program as ONE group whose hand-offs stay in that XCD's L2
       // (plain stores, L1-bypassing loads, flag barriers: ~1 us per operator instead of ~5 through memory), the others leave at once.
-      e->xcd = njobs == 1;
-      if (njobs == 1) { e->groups = 1; e->group_size = ctx->num_cu; }
+      e->xcd = plan_n(n) * T <= 16;      // (fixed-plan stream-sets: by max_slots - a single active tile of a larger set runs the multi-tile form)
+      if (e->xcd) { e->groups = 1; e->group_size = ctx->num_cu; }
       else {
         e->group_size = mega_gs; e->groups = std::max(1, std::min(njobs, mega_grid / mega_gs));
         // (group-fastest layout: with a group count that is a multiple of 8 a group's members share an XCD - decoder_mega.hip, CM = 3;
@@ -158,7 +158,8 @@ void conan_streams::decoder_step(int n, int T, const int32_t* codes, float* mel_
   // A single tile (<= 4 streams): round 3 kept the separate launches for it - a grid-wide barrier through memory per operator cost
   // what the launch boundaries do (0.47 against 0.39 ms at one stream).  Round 5: such steps run the persistent launch in xcd mode
   // (run_mega), whose barriers and hand-offs stay inside one XCD's L2; mega_single (conan_streams_opts / CONAN_MEGA_SINGLE=0) turns it off.
-  const bool tiles_ok = (16 % T == 0 && n * T > 16) || (n * T <= 16 && T >= 2 && mega_single);
+  const int prows = plan_n(n) * T;      // the rows the plan is made for: the step's own, or - CONAN_STREAMS_FIXED_PLAN - the full stream-set's
+  const bool tiles_ok = (16 % T == 0 && prows > 16) || (prows <= 16 && T >= 2 && mega_single);
   // (the per-op Emformer plan - memory bank, shapes the fused step does not cover - is ~90 launches whose conv_mfma workgroups
   // need CUs of their own: beside 128 resident decoder workgroups they queue, b128s2mem4 2.13 against 2.00 ms per step)
   const bool emf_ok = !(ctx->cfg.models & CONAN_MODEL_EMFORMER) || emf_fused;
@@ -210,7 +211,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
   // Megakernel, several row tiles: the feed-forward of a layer is ONE operator (ff1 -> ReLU -> ff2 with the hidden columns
   // split over the 8 members of a group, decoder_mega.hip MOP_FFN); what ff2 would have written to c_a1 then exists as 8
   // partial tensors + bias + residual, summed by whoever reads it (the norm2 behind it).
-  static const bool ffn_fuse_on = getenv("CONAN_MEGA_NOFFN") == nullptr;
+  static const bool ffn_fuse_on = ch::dev_getenv("CONAN_MEGA_NOFFN") == nullptr;
   bool ffn_parts = false;
   const long long part_stride = (long long)max_slots * max_frames * H;
   auto x_parts = [&](auto& a, const PackedConv& ff2) {
@@ -238,7 +239,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
       const PackedConv &f1 = ctx->conv(nm + ".ff1"), &f2 = ctx->conv(nm + ".ff2");
       // (a single row tile - xcd mode, decoder_mega.hip - splits the hidden columns over Cout / 64 virtual members: mega_ffn_gs)
       if (mega_rec && ffn_fuse_on && rowconv_ok(f1, 1, T) && f2.wf && f1.k == 1 && f2.k == 1 && f1.Cout % (64 * mega_ffn_gs) == 0 && f1.Cout / mega_ffn_gs <= 256 &&
-          (n * T > 16 || f1.Cout / mega_ffn_gs == 64) && mega_ffn_gs <= 32 && f2.Cin == f1.Cout && f2.Cout == H && H % 64 == 0) {
+          (plan_n(n) * T > 16 || f1.Cout / mega_ffn_gs == 64) && mega_ffn_gs <= 32 && f2.Cin == f1.Cout && f2.Cout == H && H % 64 == 0) {
         cnk::RowConvArgs a = mk_rc(f1, c_a1.ref(), c_ff.ref(), n, T);
         a.ln = 1; a.hist = c_a2.ref(); a.gamma = ctx->vec(nm + ".norm1.g"); a.beta = ctx->vec(nm + ".norm1.b");
         a.out_act = cnk::ACT_RELU;
@@ -259,7 +260,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
     // ff2 (K = 2048) -> c_a1 (free again): rowlin - a 33 KB block that shares CUs with the vocoder's, where the split-K conv_mfma
     // build (126 KB of LDS) needs CUs of its own; a handful of rows (one row tile) keep the split-K build, which spreads K over blocks
     if (ffn_parts) {
-    } else if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && (n * T > 16 || mega_rec)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
+    } else if (rowconv_ok(ctx->conv(nm + ".ff2"), 1, T) && (plan_n(n) * T > 16 || mega_rec)) { cnk::RowConvArgs a = mk_rc(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T); a.res = c_a2.ref(); a.has_res = 1; rowconv(a, st); }
     else { ConvArgs a = mk(ctx->conv(nm + ".ff2"), c_ff.ref(), c_a1.ref(), n, T, pos); a.res = c_a2.ref(); a.has_res = 1; conv(a, st); }
     if (l == 0 && rowconv_ok(ctx->conv("conan.align.1.q"), 1, T)) n2_pending = true;      // norm2 -> c_x[0] happens in layer 1's q launch
     else {
@@ -324,7 +325,7 @@ void conan_streams::decoder_ops(int n, int T, const int32_t* codes, float* mel_o
       const bool last_sub = b == c.dec_num_blocks - 1 && j == c.dec_layers_in_block - 1;
       {
         const PackedConv &p1 = ctx->conv(nm + ".c1"), &p2 = ctx->conv(nm + ".c2");
-        if (mega_rec && blk_fuse_on && n * T > 16 && rowconv_ok(p1, c.dec_dilations[b], T) && p2.wf && p2.k == 1 && p1.Cout % (64 * mega_gs) == 0 &&
+        if (mega_rec && blk_fuse_on && plan_n(n) * T > 16 && rowconv_ok(p1, c.dec_dilations[b], T) && p2.wf && p2.k == 1 && p1.Cout % (64 * mega_gs) == 0 &&
             p1.Cout / mega_gs <= 256 && (p1.Cout / mega_gs == 64 || (p1.Cout / mega_gs) % 128 == 0) && p2.Cin == p1.Cout && p2.Cout == H && H % 64 == 0) {
           cnk::RowConvArgs a = mk_rc(p1, c_x[cur].ref(), c_h.ref(), n, T, c.dec_dilations[b]);
           a.ln = 1; a.hist = lr.ref(); a.gamma = ctx->vec(nm + ".ln.g"); a.beta = ctx->vec(nm + ".ln.b");
@@ -419,8 +420,11 @@ void conan_streams::set_reference(const int32_t* slots, int n_all, const float* 
   const int H = c.hidden_size, NM = c.num_mels;
   for (int i = 0; i < n_all; ++i)
     if (ref_len[i] <= 0 || ref_len[i] > max_len || ref_len[i] > max_ref) throw Error(CONAN_ERR_INVALID, "reference length out of range");
-  for (int b0 = 0; b0 < n_all; b0 += sp_batch) {
-    const int n = std::min(sp_batch, n_all - b0);
+  // (fixed-plan stream-sets: one slot per pass - the batch's longest reference sets every conv's row count, and with it the plan)
+  struct StyleScope { bool& f; StyleScope(bool& x) : f(x) { f = true; } ~StyleScope() { f = false; } } style_scope(in_style_pass);
+  const int batch = fixed_plan ? 1 : sp_batch;
+  for (int b0 = 0; b0 < n_all; b0 += batch) {
+    const int n = std::min(batch, n_all - b0);
     set_slots(slots + b0, n, st);
     std::vector<int> lens(ref_len + b0, ref_len + b0 + n), lens2(n);
     int T = 0;

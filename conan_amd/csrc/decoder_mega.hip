@@ -29,6 +29,7 @@
 // CU by LDS) and with the vocoder's, and nothing resident ever waits for this kernel, so it is always eventually placed
 // in full ("decoder megakernel").
 #include <algorithm>
+#include <atomic>
 
 #include "kernels.h"
 #include "rowops.h"
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
       }
       __syncthreads();
       l2 = tab.l2;
-      if (dbg && sb == 0 && threadIdx.x == 0) dbg[700 + g] = 0x100u | (unsigned)l2 | (__hip_atomic_load(xs + 128 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16);
+      if (dbg && sb == 0 && threadIdx.x == 0) dbg[kMegaDbgGroupWords + g] = 0x100u | (unsigned)l2 | (__hip_atomic_load(xs + 128 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 16);
     }
   }
   for (int job = g; job < njobs; job += NG) {
@@ -261,9 +262,11 @@ __global__ __launch_bounds__(256, OCC) void decoder_mega_kernel(const MegaOp* __
           if constexpr (CM == 2) {
             // xcd mode: the group's size is only known at run time - the hidden columns are split over Cout / 64 VIRTUAL members
             // (one 64-column strip each: 32 for the aligner's 2048-wide feed-forward), dealt to the workgroups that are there
+            // (the LayerNorm prologue's row stores are owned by the members that stage: only those that run the loop - a feed-forward
+            // narrower than 64 x the group size leaves the others without a virtual member)
             const int VG = a.Cout >> 6;
             for (int v = sb; v < VG; v += GS) {
-              ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, GS);
+              ro::mg_stage<(OCC < 6), CM>(a, tab, lds, sb, GS < VG ? GS : VG);
               ro::mg_ffn<(OCC < 6), CM>(a, tab, v, VG, lds);
             }
           } else {
@@ -351,8 +354,15 @@ int decoder_mega_blocks_per_cu(int lds_bytes, bool wide_regs) {
 
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st) {
   if (m.xcd) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_mega_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+    // (the attribute is per device: one bit per device id, like conv_limb's and rowconv's)
+    static std::atomic<unsigned long long> attr_devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_mega_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_devs.fetch_or(bit, std::memory_order_release);
+    }
     hipLaunchKernelGGL((decoder_mega_kernel<4, 2>), dim3(m.groups * m.group_size), dim3(256), m.lds_bytes, st, m.prog, m.nops, m.njobs, m.group_size, m.slots, m.pos, m.n, m.T,
                        m.gbar, m.bar, m.bar_base, m.dbg, m.guard, m.xs, m.xseq, m.xdec_base);
   } else if (m.wide_regs)

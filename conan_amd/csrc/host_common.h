@@ -24,7 +24,8 @@ struct Error : std::runtime_error {
 };
 
 void hip_check(hipError_t e, const char* what);
-#define HIP_CHECK(x) ::ch::hip_check((x), #x)
+
+using cnk::dev_getenv;
 
 struct HostTensor {
   std::vector<int64_t> shape;
@@ -77,6 +78,16 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 int conan_mel_frames(const conan_mel_cfg& m, int samples);   // frontend.hip: frames conan_wav2mel writes per waveform
 
+// Stream-sets that exist right now on a device (conan_streams_create .. _destroy), over ALL contexts of this process: launches that
+// wait inside themselves (Emformer clusters on whole CUs, the decoder's resident groups, the f32 pair kernel) can only be given
+// the whole chip when nothing else of the process can overlap them on that device - two contexts on one GPU each counted
+// themselves "alone" while the count was per context.  Other PROCESSES on the device are not visible here:
+// CONAN_STREAMS_SHARED_DEVICE says so.
+inline std::atomic<int>& device_live_streams(int device) {
+  static std::atomic<int> counts[64];
+  return counts[device & 63];
+}
+
 struct conan_ctx {
   int device = 0;
   conan_cfg cfg;
@@ -89,8 +100,6 @@ struct conan_ctx {
   int64_t weight_bytes = 0;
   int hop = 1;
   int num_cu = 256;
-  // stream-sets of this context that exist right now (conan_streams_create .. _destroy); shared: a stream-set may outlive its context's handle
-  std::shared_ptr<std::atomic<int>> live_streams = std::make_shared<std::atomic<int>>(0);
   bool has_limb_weights = false;   // finalize packed bf16-limb copies of the vocoder's conv weights (resblock_limb.hip / conv_limb.hip)
 
   float* dev_alloc(size_t floats, bool zero = true);
@@ -111,14 +120,6 @@ struct conan_ctx {
   void finalize_hifigan();
   void finalize_conan();
   void finalize_emformer();
-  // fragment-major copies of the vocoder's conv weights for voc_chain.hip, made on the device from the conv_mfma layout the first
-  // time a small stream-set asks for them (most contexts never do: 120 MB)
-  std::map<std::string, float*> chain_w;
-  std::mutex chain_mu;
-  const float* chain_weight(const std::string& conv_name);
-  // the persistent chain launches of a context never overlap on the device (each needs its whole grid resident): every launch
-  // waits for the event recorded behind the one before
-  hipEvent_t chain_done = nullptr;
   // mel front-end (frontend.hip): tables are built on first use per configuration; one workspace, regrown when a call needs more
   float* fe_ws = nullptr; size_t fe_ws_floats = 0;
   void wav2mel(const conan_mel_cfg& m, const float* wav, int n, int samples, float* mel_out, hipStream_t st);

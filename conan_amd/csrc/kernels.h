@@ -2,8 +2,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace cnk {
+
+// Developer switches read from the ENVIRONMENT exist only in `make DEV=1` builds (CONAN_DEV_SWITCHES): the shipped library reads
+// no environment variable - a deployed process's launch plan is a function of the arguments it passes (conan_streams_opts.flags,
+// .dev_plan), not of its environment.
+inline const char* dev_getenv(const char* name) {
+#ifdef CONAN_DEV_SWITCHES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+#define HIP_CHECK(x) ::ch::hip_check((x), #x)
+
 
 // A channel-last fp32 activation tensor [slot][row][C].
 //  mode 0 (ring):   row(t) = (pos[slot] * rate + off + t) & lmask, slot = slots[i]
@@ -18,6 +33,16 @@ struct TRef {
   int mode;
   int pad_;
 };
+
+// The device slot table (conan_streams::d_slots) holds the n active slots followed by kSlotTablePad copies of the last one: kernels
+// whose tiles take several whole slots (conv_limb's ragged last tile) read entries past n without a clamp.
+constexpr int kSlotTablePad = 32;
+
+// decoder_mega's developer stamp buffer (CONAN_MEGA_STAMPS), in 8-byte words: [0, 128) per-operator end stamps, [128, 512) four
+// stage stamps per operator, [512, 512 + 4 * kMegaMaxOps) the gather's stamps, then one XCC-mask word per group.
+constexpr int kMegaMaxOps = 80;
+constexpr int kMegaDbgGroupWords = 512 + 4 * kMegaMaxOps;
+constexpr int kMegaDbgWords = kMegaDbgGroupWords + 64;
 
 enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4 };
 
@@ -39,7 +64,7 @@ enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_TANH = 4
 // budget down, a wait without an end takes the box with it).
 constexpr unsigned long long kSpinBudgetTicks = 5000000ull;
 constexpr unsigned long long kSpinGapTicks = 100000ull;
-enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4, WAIT_VOC_PHASE = 5, WAIT_MEGA_ELECT = 6, WAIT_MEGA_DECIDED = 7, WAIT_MEGA_FLAGS = 8 };
+enum WaitCode { WAIT_MEGA_BARRIER = 1, WAIT_EMF_CLUSTER = 2, WAIT_PAIR_FLAG = 3, WAIT_PAIR_MAILBOX = 4, WAIT_RETIRED_5 = 5 /* (voc_chain, rounds 4-5: tools/experiments/voc_chain) */, WAIT_MEGA_ELECT = 6, WAIT_MEGA_DECIDED = 7, WAIT_MEGA_FLAGS = 8 };
 struct SpinGuard { unsigned long long last = 0, acc = 0; unsigned it = 0; };
 #if defined(__HIPCC__)
 // true: give up (budget spent, or another wait of this stream-set already failed)
@@ -143,7 +168,7 @@ struct ConvLimbGroup {
   int wr_max;           // window rows of the largest problem's tile
 };
 bool conv_limb_supported(const ConvArgs& a);
-int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu);      // tile shape for these problems, -1: none fits
+int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n = 0);      // tile shape for these problems, -1: none fits (plan_n: conv_limb.hip)
 bool launch_conv_limb(const ConvLimbGroup& g, int shape, int num_cu, hipStream_t st);
 const char* conv_limb_name(int shape);
 
@@ -254,9 +279,10 @@ struct RowConvArgs {
   int hid_overlay;      // MOP_FFN with one 64-column hidden strip per member: the hidden tile overlays the window (read out by then)
 };
 bool rowconv_supported(int Cin, int ktaps, int dil, int T);
-void launch_rowconv(const RowConvArgs& a, hipStream_t st);
-const char* rowconv_kernel_name(const RowConvArgs& a);   // as rocprofv3 prints it
-int rowconv_plan(RowConvArgs& a, int* nbx, int* nby, int* lds_floats);   // tile geometry for the decoder megakernel
+// plan_rows (all three): the row count the kernel variant is chosen for; 0 = the launch's own n * T (rowconv.hip)
+void launch_rowconv(const RowConvArgs& a, hipStream_t st, int plan_rows = 0);
+const char* rowconv_kernel_name(const RowConvArgs& a, int plan_rows = 0);   // as rocprofv3 prints it
+int rowconv_plan(RowConvArgs& a, int* nbx, int* nby, int* lds_floats, int plan_rows = 0);   // tile geometry for the decoder megakernel
 
 // LayerNorm over the channel axis of each row:
 //   y[i][t][:] = (LN(x[i][t][:] (+ pre[i][t][:])) * gamma + beta) * m1 * m2 (+ post[i][t][:])
@@ -448,60 +474,6 @@ struct MegaLaunch {
   int xcd; unsigned* xs; unsigned xseq, xdec_base;
 };
 void launch_decoder_mega(const MegaLaunch& m, hipStream_t st);
-
-// The vocoder step of a SMALL stream-set (slots x frames <= 16 mel rows) as ONE persistent launch (voc_chain.hip): conv_pre ->
-// 4 x (upsampler + MRF stage) -> conv_post (HifiGanGenerator.forward, hifigan_causal.py:314-333) walked as a list of PHASES; a
-// phase is one conv layer of all branches, cut into jobs (problem, row tile, column group) that the grid's workgroups deal among
-// themselves; dependent phases are separated by an arrival counter.  Activations cross workgroups as agent-scope write-through
-// stores / sc1 loads (no fence), weights are fragment-major and prefetched into registers BEFORE the wait for the previous phase.
-constexpr int VC_MAX_PHASES = 40;
-struct VCProb {
-  TRef xnew[3];         // input rows of THIS step (tau >= 0): one tensor, or nsrc raw branch outputs whose leaky_relu(mean) is the input
-  TRef xhist;           // input rows of earlier steps (tau < 0): a ring; with store_new the rows formed from xnew are appended to it
-  TRef y;               // output ring
-  TRef res;             // residual operand (has_res)
-  const float* w;       // fragment-major [ncts][k + 1 taps (last zero)][KQ][64 lanes][4] (+ slack: the register ring reads ahead)
-  const float* bias;    // [>= ncts * 16], packed column order
-  int nsrc, store_new, has_res, in_lrelu;
-  int io_in;            // 1: xnew[0].base comes from the launch arguments (the step's mel chunk)
-  int tap;              // index into VCIO::tap of a linear copy [n][rows out][Cy] of the stored rows, -1: none
-  int Cin, Cout, k, dil, KQ, ncts;
-  int out_act; float in_slope, out_slope, mean_slope;
-  int shuffle_r, Cq;    // pixel shuffle: packed column c -> output row t * r + c / Cq, channel c % Cq
-  int tap_new;          // index into VCIO::tap of a linear copy [n][T][Cin] of the rows formed from xnew (store_new), -1: none
-  int pad_;
-};
-struct VCPhase {
-  int type;             // 0: convolution on the f32 MFMA, 1: conv_post (VALU dot product + tanh)
-  int nprob, n, T;      // problems (branches), slots, conv rows per slot and step
-  int NRT, NCT, KS;     // per job: row tiles of 16 rows, column tiles of 16 per workgroup, K slices per column tile (NCT * KS = 8 waves)
-  int tiles_per_slot;   // T >= 16: a job's rows are 16 * NRT consecutive rows of one slot
-  int spt;              // T < 16: a job's rows are ALL rows of spt consecutive slots (spt * T <= 16); 0 otherwise
-  int tiles;            // row tiles per problem
-  int ncg;              // column groups per (problem, row tile) = ncts / NCT
-  int njobs;
-  int magic_c4;         // floor(2^32 / (Cin / 4)) + 1
-  int kpost;            // conv_post: taps
-  float bpost;          // conv_post: bias
-  int pad_;
-  const float* wpost;   // conv_post: [k][C]
-  VCProb p[3];
-};
-constexpr int VC_MAX_TAPS = 20;
-struct VCIO { const float* mel; float* wav; float* pre; float* tap[VC_MAX_TAPS]; };
-struct VCLaunch {
-  const VCPhase* prog; int nphases, grid, lds_bytes;
-  const int* slots; int* pos; int n, adv;   // pos[slots[q]] += adv by the last workgroup to finish
-  unsigned* bar;                            // (VC_MAX_PHASES + 1) arrival counters, 16 words apart, zero before the first launch
-  unsigned* guard;
-  VCIO io;
-  unsigned long long* dbg;                  // developer stamps (CONAN_VC_STAMPS=1): [VC_MAX_PHASES][4] + 2, zero before the launch
-};
-void launch_voc_chain(const VCLaunch& l, hipStream_t st);
-int voc_chain_max_grid(int lds_bytes, int num_cu);     // workgroups that can be resident at once
-// fragment-major repack of a conv_mfma weight ([Cout_pad/64][k][Cin_alloc/4][64][4]) for voc_chain: returns floats written
-size_t voc_chain_weight_floats(int Cout, int Cin, int k);
-void launch_voc_chain_repack(float* dst, const float* w, int Cout, int Cout_pad, int Cin, int Cin_alloc, int k, hipStream_t st);
 
 struct ArgmaxArgs { const float* x; int* idx; int rows, C; };
 void launch_argmax(const ArgmaxArgs& a, hipStream_t st);

@@ -82,30 +82,32 @@ static void rc_launch(const RowConvArgs& a, int mt, int nt, int lds, hipStream_t
 }
 
 // which kernel a launch uses: 0 <1,1,1>, 1 <4,1,1>, 2 <1,1,4>, 3 rowlin
-int rowconv_variant(const RowConvArgs& a);
-static int rc_variant(const RowConvArgs& a) { return rowconv_variant(a); }
-int rowconv_variant(const RowConvArgs& a) {
-  static const bool no_ksplit = getenv("CONAN_RC_NOKSPLIT") != nullptr;   // developer switch
+// plan_rows: the row count the PLAN is made for (0: the launch's own n * T; a fixed-plan stream-set passes max_slots * T, so that the
+// single-tile K-split form - a different summation order - is chosen by the stream-set's size, not by the active slots)
+int rowconv_variant(const RowConvArgs& a, int plan_rows);
+static int rc_variant(const RowConvArgs& a, int plan_rows) { return rowconv_variant(a, plan_rows); }
+int rowconv_variant(const RowConvArgs& a, int plan_rows) {
+  static const bool no_ksplit = dev_getenv("CONAN_RC_NOKSPLIT") != nullptr;   // developer switch
   if (a.Cin > 512) return 3;
-  const int mt = (a.n * a.T + RC_TM - 1) / RC_TM;
+  const int mt = ((plan_rows > 0 ? plan_rows : a.n * a.T) + RC_TM - 1) / RC_TM;
   // a single row tile (<= 16 rows in the launch): K split over the waves of a block, one 16-column strip per block
   // (the waves take runs of 4 K groups: rc_krange - uneven when the group count is not a multiple of 16, e.g. 128 channels x 5 taps)
   if (mt == 1 && ((a.ktaps * (a.Cin >> 4)) % 4) == 0 && !no_ksplit) return 2;
   // wide layers: 4 column tiles per wave (256 columns per block) keep the block count near the CU count
-  static const int wide_min = getenv("CONAN_RC_WIDE_MIN") ? atoi(getenv("CONAN_RC_WIDE_MIN")) : 1024;    // developer switch
+  static const int wide_min = dev_getenv("CONAN_RC_WIDE_MIN") ? atoi(dev_getenv("CONAN_RC_WIDE_MIN")) : 1024;    // developer switch
   return (a.Cout_pad >= wide_min && a.Cout_pad % 256 == 0) ? 1 : 0;
 }
-const char* rowconv_kernel_name(const RowConvArgs& a) {
+const char* rowconv_kernel_name(const RowConvArgs& a, int plan_rows) {
   static const char* names[4] = {"cnk::rowconv_kernel<1, 1, 1>", "cnk::rowconv_kernel<4, 1, 1>", "cnk::rowconv_kernel<1, 1, 4>", "cnk::rowlin_kernel"};
-  return names[rc_variant(a)];
+  return names[rc_variant(a, plan_rows)];
 }
 
 // Tile geometry of a launch for the decoder megakernel: fills wr_max, returns the variant it would run as ONE-column-tile
 // tiles (0: <1,1,1>, 2: <1,1,4>, 3: rowlin; the 4-column-tile build needs more registers than the megakernel's bound) with
 // the tile grid (nbx column strips x nby row tiles) and the LDS floats a tile needs.
-int rowconv_plan(RowConvArgs& a, int* nbx, int* nby, int* lds_floats) {
+int rowconv_plan(RowConvArgs& a, int* nbx, int* nby, int* lds_floats, int plan_rows) {
   const int M = a.n * a.T, halo = (a.ktaps - 1) * a.dil;
-  int v = rc_variant(a);
+  int v = rc_variant(a, plan_rows);
   if (v == 1) v = 0;
   a.wr_max = rc_window_rows(RC_TM, a.T, halo);
   const int mt = (M + RC_TM - 1) / RC_TM;
@@ -115,13 +117,13 @@ int rowconv_plan(RowConvArgs& a, int* nbx, int* nby, int* lds_floats) {
   return v;
 }
 
-void launch_rowconv(const RowConvArgs& ain, hipStream_t st) {
+void launch_rowconv(const RowConvArgs& ain, hipStream_t st, int plan_rows) {
   RowConvArgs a = ain;
   const int T = a.T, M = a.n * T;
   if (M <= 0) return;
   const int halo = (a.ktaps - 1) * a.dil;
   const int ncols = a.Cout_pad;
-  const int v = rc_variant(a);
+  const int v = rc_variant(a, plan_rows);
   a.wr_max = rc_window_rows(RC_TM, T, halo);
   const int lds = rowconv_lds_bytes(a, v == 2);
   const int mt = (M + RC_TM - 1) / RC_TM;

@@ -56,7 +56,27 @@ struct PinRing {
 
 struct conan_streams {
   conan_ctx* ctx = nullptr;
-  std::shared_ptr<std::atomic<int>> live;      // the context's count of live stream-sets
+  std::atomic<int>* live = nullptr;            // this device's count of live stream-sets (device_live_streams)
+  // developer / test switches of the launch plan: conan_streams_opts.dev_plan ("NAME=value;..."; DEV builds: also CONAN_<NAME> in the environment)
+  std::map<std::string, std::string> dev_plan;
+  void parse_dev_plan(const char* text);
+  const char* dev(const char* name) const {
+    if (!dev_plan.empty()) {
+      auto it = dev_plan.find(name);
+      if (it != dev_plan.end()) return it->second.c_str();
+    }
+#ifdef CONAN_DEV_SWITCHES
+    return getenv((std::string("CONAN_") + name).c_str());
+#else
+    return nullptr;
+#endif
+  }
+  // CONAN_STREAMS_FIXED_PLAN: every plan choice from max_slots, never from the step's active slot count
+  bool fixed_plan = false;
+  // (the per-utterance style pass of a fixed-plan stream-set runs one slot at a time: its plan follows the slot's own reference length)
+  bool in_style_pass = false;
+  int plan_n(int n) const { return (fixed_plan && !in_style_pass) ? max_slots : n; }
+  bool shared_device = false;                  // CONAN_STREAMS_SHARED_DEVICE: other processes drive this GPU too - never take whole-chip launch shapes
   int max_slots = 0, max_frames = 0, max_ref = 0, S_max = 0;
   std::vector<void*> allocs;
   int64_t state_bytes = 0;
@@ -101,7 +121,7 @@ struct conan_streams {
     const unsigned code = *(volatile const unsigned*)h_guard;
     if (code == 0) return;
     static const char* what[] = {"?", "decoder_mega_kernel group / grid barrier", "emformer_fused_kernel cluster exchange", "resblock_pair_kernel partner flag", "resblock_pair_kernel tile mailbox",
-                                 "voc_chain_kernel phase counter", "decoder_mega_kernel xcd election", "decoder_mega_kernel xcd roll call", "decoder_mega_kernel xcd flag barrier"};
+                                 "(retired)", "decoder_mega_kernel xcd election", "decoder_mega_kernel xcd roll call", "decoder_mega_kernel xcd flag barrier"};
     throw ch::Error(CONAN_ERR_HIP, std::string("a cross-workgroup wait gave up after its 50 ms budget (") + what[code < 9 ? code : 0] +
                                        "): results since then are invalid and this stream-set is unusable - destroy it and create a new one");
   }
@@ -201,7 +221,6 @@ struct conan_streams {
     for (auto& e : clock_ev) (void)hipEventDestroy(e);
     for (auto& m : mega_cache) { if (m.copied) (void)hipEventDestroy(m.copied); if (m.pinned) (void)hipHostFree(m.pinned); if (m.dev) (void)hipFree(m.dev); }
     for (auto& e : tl_ev) (void)hipEventDestroy(e);
-    for (auto& v : vc_progs) if (v.dev) (void)hipFree(v.dev);
   }
 
   void build_vocoder();
@@ -227,7 +246,7 @@ struct conan_streams {
   cnk::RowConvArgs mk_rc(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, int dil = 1) const;
   void rowconv(const cnk::RowConvArgs& a, hipStream_t st);
   template <typename F> void profiled(const std::string& name, double flops, hipStream_t st, F&& launch);
-  void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(a.n * a.T, a.Cout, 1), st); }
+  void conv(const ConvArgs& a, hipStream_t st) { ConvGroup g; g.p[0] = a; launch_group(g, 1, pick_cfg(plan_n(a.n) * a.T, a.Cout, 1), st); }
   ConvArgs mk(const PackedConv& pc, const TRef& x, const TRef& y, int n, int T, const int* pos, int dil = 1, int pad_left = -1) const;
 
   // --- decoder megakernel (decoder_mega.hip): the decoder step's operator list, recorded once per (slot count, frames,
@@ -244,7 +263,7 @@ struct conan_streams {
     hipEvent_t copied = nullptr;
     long long stamp = 0;               // least-recently-used replacement
   };
-  static constexpr int kMegaMaxOps = 80, kMegaEntries = 12;
+  static constexpr int kMegaMaxOps = cnk::kMegaMaxOps, kMegaEntries = 12;
   std::vector<MegaProgram> mega_cache;
   long long mega_clock = 0;
   bool use_mega = true;                          // CONAN_DEC_MEGA=0: the decoder step as separate launches
@@ -274,16 +293,6 @@ struct conan_streams {
   void op_advance(int* pos, int n, int delta, hipStream_t st);
 
   void hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps = nullptr);
-  // --- small stream-sets (max_slots x max_frames <= 16 mel rows): the vocoder step as ONE persistent launch (voc_chain.hip,
-  // voc_chain_host.hip).  Chosen at creation (chain_eligible); such a stream-set has no other vocoder plan.
-  bool voc_chain = false;
-  unsigned* vc_bar = nullptr;                    // per-phase arrival counters
-  struct VCProgram { int n = 0, frames = 0, nphases = 0, lds_bytes = 0, grid = 0; double flops = 0.0; cnk::VCPhase* dev = nullptr; };
-  std::vector<VCProgram> vc_progs;               // one per (slots, frames) seen so far
-  bool chain_eligible(bool limb_requested) const;
-  bool chain_build(int n, int frames, std::vector<cnk::VCPhase>& out, int* lds_bytes, int* grid) const;
-  const VCProgram& chain_program(int n, int frames);
-  void chain_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps);
   void emformer_step(int n, const float* chunk, float* out, float* logits, int32_t* codes, hipStream_t st);
   void decoder_step(int n, int frames, const int32_t* codes, float* mel_out, const conan_decoder_taps& taps, hipStream_t st, const DecExtra* extra = nullptr);
   void set_reference(const int32_t* slots, int n, const float* ref, const int32_t* ref_len, int max_len, hipStream_t st);

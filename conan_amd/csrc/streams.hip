@@ -63,7 +63,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     bool ok = true;
     for (int p = 0; p < nprob; ++p) ok = ok && cnk::conv_limb_supported(gin.p[p]) && gin.p[p].n == gin.p[0].n && gin.p[p].T == gin.p[0].T && gin.p[p].Cout == gin.p[0].Cout;
     const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
-    const int shape = ok ? cnk::conv_limb_shape(gin.p, nprob, cus) : -1;
+    const int shape = ok ? cnk::conv_limb_shape(gin.p, nprob, cus, fixed_plan ? plan_n(gin.p[0].n) : 0) : -1;
     if (shape >= 0) {
       cnk::ConvLimbGroup lg; memset(&lg, 0, sizeof(lg));
       for (int p = 0; p < nprob; ++p) lg.p[p] = gin.p[p];
@@ -94,13 +94,14 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     // last `rem` tiles are cut into S K-slices each, rem * S <= CUs, so that every CU gets the same 1 + 1/S (2 + 1/S ...)
     // tiles of MFMA work instead of some CUs getting one tile more than the others - the tail of a stream-K schedule,
     // with the fence-free partial-tile hand-off of the small-M shapes.
-    static const bool off = getenv("CONAN_NO_TAILSPLIT") != nullptr;
+    static const bool off = ch::dev_getenv("CONAN_NO_TAILSPLIT") != nullptr;
     const ConvArgs& a = g.p[0];
     const int TM = cnk::conv_cfg_tm(cfg), TN = cnk::conv_cfg_tn(cfg), KS = cnk::conv_cfg_ks(cfg);
     const long long tiles = (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
     const int nks = a.ktaps * ((a.Cin_pad + KS - 1) / KS);
     const long long rem = tiles % cus_all;
-    if (!off && tiles > cus_all && rem > 0 && tiles <= sk_max_tiles) {
+    // (a fixed-plan stream-set has no split tail: WHICH tiles would be split follows a slot's position in the active list)
+    if (!off && !fixed_plan && tiles > cus_all && rem > 0 && tiles <= sk_max_tiles) {
       int S = (int)std::min<long long>(8, cus_all / rem);
       S = std::min(S, nks / 8);                                  // at least 8 K-steps per slice (ups[3], 8 K-steps in all: the hand-off costs more than the tail it removes, 27 against 23 us)
       while (S > 1 && rem * S * TM * TN > sk_slab_floats) --S;
@@ -115,7 +116,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     int nks = 0;
     for (int p = 0; p < nprob; ++p) {
       const ConvArgs& a = g.p[p];
-      tiles += (long long)((a.n * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
+      tiles += (long long)((plan_n(a.n) * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);      // (one factor for every tile: fixed-plan stream-sets size it by max_slots)
       nks = std::max(nks, a.ktaps * ((a.Cin_pad + KS - 1) / KS));
     }
     int S = tiles > 0 ? (int)(ctx->num_cu / tiles) : 1;
@@ -125,7 +126,7 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     // the hand-off (write-through partial-tile stores, ticket, sc1 loads) is not free - with fences it cost about 6 K-steps
     // of 32 channels -: split only when it removes clearly more than that from the critical path (thresholds of 2 .. 12
     // measure the same at one and four streams)
-    static const int min_saved = getenv("CONAN_SK_MIN") ? atoi(getenv("CONAN_SK_MIN")) : 12;
+    static const int min_saved = ch::dev_getenv("CONAN_SK_MIN") ? atoi(ch::dev_getenv("CONAN_SK_MIN")) : 12;
     if (S >= 2 && tiles <= sk_max_tiles && (nks - nks / S) * (KS / 32) >= min_saved) g.ksplit = S;
   }
   double fl = 0.0;
@@ -150,7 +151,8 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     cnk::MegaOp op; memset(&op, 0, sizeof(op));
     op.u.rc = a;
     int ldsf = 0;
-    const int v = cnk::rowconv_plan(op.u.rc, &op.nbx, &op.nby, &ldsf);
+    const int prows = fixed_plan ? plan_n(a.n) * a.T : 0;
+    const int v = cnk::rowconv_plan(op.u.rc, &op.nbx, &op.nby, &ldsf, prows);
     op.type = v == 3 ? cnk::MOP_ROWLIN : (v == 2 ? cnk::MOP_RC114 : cnk::MOP_RC111);
     // Several row tiles, a narrow layer (at most half as many 64-column strips as the group has members: the uv predictor's 128-wide
     // convs, the 256-wide 1x1 / k3 layers): 16-column strips with the K groups split over a workgroup's waves instead - every member
@@ -160,7 +162,7 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     // 10.5 / 12.0 -> 9.8 / 10.6 - but the 256 -> 256 1x1 layers 6.5 -> 8.0: four waves' partial tiles through LDS for 16 K groups each
     // is more than the chain it shortens.  So: a quarter as many strips as members, or half as many with at least 3 taps.)
     const int strips64 = (op.u.rc.Cout_pad + 63) / 64;
-    if (v == 0 && !a.w2 && a.n * a.T > 16 && mega_narrow_ksplit && (strips64 * 4 <= mega_gs || (strips64 * 2 <= mega_gs && a.ktaps >= 3)) && (a.ktaps * (a.Cin >> 4)) % 4 == 0) {
+    if (v == 0 && !a.w2 && plan_n(a.n) * a.T > 16 && mega_narrow_ksplit && (strips64 * 4 <= mega_gs || (strips64 * 2 <= mega_gs && a.ktaps >= 3)) && (a.ktaps * (a.Cin >> 4)) % 4 == 0) {
       const int ldsk = (32 + op.u.rc.wr_max * (a.Cin + 8) + 3 * 64 * 4);      // rowconv_lds_bytes(a, true) / 4
       cnk::MegaOp t = op; t.type = cnk::MOP_RC114;
       if (cnk::decoder_mega_lds_floats(t, ldsk) * 4 <= (96 + 32 * 264) * 4) {
@@ -182,7 +184,8 @@ void conan_streams::rowconv(const cnk::RowConvArgs& a, hipStream_t st) {
     mega_push(op, cnk::decoder_mega_lds_floats(op, ldsf));
     return;
   }
-  profiled(cnk::rowconv_kernel_name(a), fl, st, [&] { cnk::launch_rowconv(a, st); });
+  const int prows = fixed_plan ? plan_n(a.n) * a.T : 0;
+  profiled(cnk::rowconv_kernel_name(a, prows), fl, st, [&] { cnk::launch_rowconv(a, st, prows); });
 }
 
 // one ResBlock1 unit per branch (c1 -> LeakyReLU -> c2 -> + residual) as one tile pass
@@ -200,14 +203,14 @@ bool conan_streams::launch_rb(const cnk::RBArgs& ain, int C, hipStream_t st, con
   int span = 0;
   bool limb = rb_limb;
   for (int p = 0; p < a.nprob; ++p) { span = std::max(span, (a.p[p].k - 1) * a.p[p].dil); limb = limb && a.p[p].w1l && a.p[p].w2l; }
-  limb = limb && a.n <= cnk::kResblockLimbMaxSlots && cnk::resblock_limb_supported(C, kmax, span);
+  limb = limb && plan_n(a.n) <= cnk::kResblockLimbMaxSlots && cnk::resblock_limb_supported(C, kmax, span);
   // (AUTO takes the limb pass wherever it exists, like an explicit request: measured at 1 / 4 / 8 / 16 / 32 streams the limb pass is
   // never the slower one - 0.72 against 0.87 ms per pipelined step at 8 streams, equal at one - tools/arith_sweep.sh)
-  const int rows = limb ? cnk::resblock_limb_rows(C, span) : cnk::resblock_fused_rows(C, a.T, a.n, ksum, kmax, cus);
+  const int rows = limb ? cnk::resblock_limb_rows(C, span) : cnk::resblock_fused_rows(C, a.T, plan_n(a.n), ksum, kmax, cus);
   // Last dilation of a stage: with at least one (slot, row tile) group per CU a workgroup runs the group's branches one after
   // the other and stores only leaky_relu(mean) - equal work per group, no branch outputs written, no mean_act launch.
   // With fewer groups than CUs (C = 128 at 64 streams: 128) the branches stay separate tiles.
-  const long long groups = (long long)a.n * ((a.T + rows - 1) / rows);
+  const long long groups = (long long)plan_n(a.n) * ((a.T + rows - 1) / rows);
   // (a group is the unit of work of a merged launch: the last round of groups must not leave most CUs idle - 320 groups on 256
   // CUs, the limb build of the C = 128 stage at 64 streams, ran 137 us merged against 98 + 6 us as separate branches + mean_act)
   const long long rounds = (groups + cus - 1) / cus;
@@ -240,7 +243,7 @@ void conan_streams::mega_print_stamps() {
   if (!mega_dbg || mega_dbg_prog < 0 || mega_dbg_prog >= (int)mega_cache.size()) return;
   (void)hipDeviceSynchronize();
   const MegaProgram& e = mega_cache[mega_dbg_prog];
-  std::vector<unsigned long long> h(512 + 4 * kMegaMaxOps);
+  std::vector<unsigned long long> h(cnk::kMegaDbgWords);
   if (hipMemcpy(h.data(), mega_dbg, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
   static const char* names[] = {"rowconv<1,1,1>", "rowconv<1,1,4>", "rowlin", "layernorm", "xattn", "pitch_head", "embed", "copy32", "advance", "ffn"};
   constexpr int nnames = (int)(sizeof(names) / sizeof(names[0]));
@@ -248,7 +251,7 @@ void conan_streams::mega_print_stamps() {
           e.groups, e.group_size, e.njobs, e.nops, e.barriers, (h[e.nops + 1] - h[0]) / 100.0);
   if (!e.xcd) {
     fprintf(stderr, "  groups on one XCD (l2 mode) / XCC masks:");
-    for (int g2 = 0; g2 < e.groups && g2 < 32; ++g2) if (h[700 + g2]) fprintf(stderr, " %d:%llu/%02llx", g2, h[700 + g2] & 1ull, (h[700 + g2] >> 16) & 0xffull);
+    for (int g2 = 0; g2 < e.groups && g2 < 32; ++g2) if (h[cnk::kMegaDbgGroupWords + g2]) fprintf(stderr, " %d:%llu/%02llx", g2, h[cnk::kMegaDbgGroupWords + g2] & 1ull, (h[cnk::kMegaDbgGroupWords + g2] >> 16) & 0xffull);
     fprintf(stderr, "\n");
   }
   for (int o = 0; o < e.nops; ++o) {
@@ -264,8 +267,9 @@ void conan_streams::mega_print_stamps() {
 }
 
 void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
-  static const bool stamps = getenv("CONAN_MEGA_STAMPS") != nullptr;
-  if (stamps && !mega_dbg) mega_dbg = reinterpret_cast<unsigned long long*>(alloc(2 * (512 + 4 * kMegaMaxOps)));
+  static const bool stamps = ch::dev_getenv("CONAN_MEGA_STAMPS") != nullptr;
+  if (stamps && !mega_dbg) mega_dbg = reinterpret_cast<unsigned long long*>(alloc(2 * (size_t)cnk::kMegaDbgWords));
+  if (stamps) HIP_CHECK(hipMemsetAsync(mega_dbg, 0, sizeof(unsigned long long) * cnk::kMegaDbgWords, st));      // (no stale stamps of another program)
   if (stamps) mega_dbg_prog = (int)(&e - mega_cache.data());
   cnk::MegaLaunch m; memset(&m, 0, sizeof(m));
   m.prog = e.dev; m.nops = e.nops; m.njobs = e.njobs; m.groups = e.groups; m.group_size = e.group_size; m.kw4 = e.kw4; m.lds_bytes = e.lds_bytes;
@@ -283,11 +287,37 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   if (test_fault == 1) { m.bar_base += 1u; test_fault = 0; }       // test hook: the grid barrier waits for one arrival too many
   mega_gseq = mega_gseq + 1u;             // (its own sequence: the xcd mode's election word tracks mega_xseq launch by launch)
   m.xs = mega_x; m.xseq = mega_gseq;      // (the flag barriers of groups that sit on one XCD count in epochs of this sequence number)
-  { static const bool nol2 = getenv("CONAN_MEGA_NOL2") != nullptr;
-    static const bool mfast = getenv("CONAN_MEGA_LAYOUT") != nullptr && getenv("CONAN_MEGA_LAYOUT")[0] == 'm';
+  { const bool nol2 = dev("MEGA_NOL2") != nullptr;
+    const bool mfast = dev("MEGA_LAYOUT") != nullptr && dev("MEGA_LAYOUT")[0] == 'm';
     m.xdec_base = (nol2 ? 1u : 0u) | (mfast ? 2u : 0u); }
   profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 3>" : "cnk::decoder_mega_kernel<6, 3>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
+}
+
+// conan_streams_opts.dev_plan: "NAME=value;NAME=value" (a bare NAME means NAME=1)
+void conan_streams::parse_dev_plan(const char* text) {
+  static const char* known[] = {"RESERVE_CUS", "ROWCONV", "RB_NOMERGE", "RB_NOLIMB", "FENCED", "DEC_MEGA", "MEGA_GRID", "FRONT_CUSTRIDE", "EMF_CUSTRIDE", "MEGA_GS",
+                                "MEGA_NARROW", "MEGA_NOL2", "MEGA_LAYOUT", "FRONT_PRIO", "RB_UNFUSED", "RB_FUSED", "RB_PAIR", "RB_NOPAIR", "RP_MIN_SLOTS",
+                                "UPS_CFG", "EMF_CLUSTER", "EMF_UNFUSED", "UPS_F32", "C256_SHAPE"};
+  dev_plan.clear();
+  if (!text) return;
+  const std::string t(text);
+  size_t p = 0;
+  while (p < t.size()) {
+    size_t q = t.find(';', p);
+    if (q == std::string::npos) q = t.size();
+    std::string item = t.substr(p, q - p);
+    p = q + 1;
+    while (!item.empty() && item.front() == ' ') item.erase(item.begin());
+    while (!item.empty() && item.back() == ' ') item.pop_back();
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    const std::string name = item.substr(0, eq), value = eq == std::string::npos ? "1" : item.substr(eq + 1);
+    bool ok = false;
+    for (const char* k : known) ok = ok || name == k;
+    if (!ok) throw Error(CONAN_ERR_INVALID, "conan_streams_opts.dev_plan: unknown switch '" + name + "'");
+    dev_plan[name] = value;
+  }
 }
 
 void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
@@ -304,9 +334,10 @@ void conan_streams::set_slots(const int32_t* slots, int n, hipStream_t st) {
     slot_seen[slots[i]] = slot_gen;
   }
   h_slots.assign(slots, slots + n);
-  // (entry n = a copy of the last slot: conv_limb's 2-slot tiles read one slot past an odd count)
-  std::vector<int> up(h_slots); up.push_back(h_slots.back());
-  pin.upload(d_slots, up.data(), (size_t)n + 1, st);
+  // (entries n .. n + kSlotTablePad - 1 = copies of the last slot: a ragged last tile of conv_limb stages ALL the slots it has room for -
+  // TM / T of them, e.g. 4-5 with 40 ms chunks in the C = 256 stage - and reads the table up to TM / T - 1 entries past n)
+  std::vector<int> up(h_slots); up.resize((size_t)n + cnk::kSlotTablePad, h_slots.back());
+  pin.upload(d_slots, up.data(), up.size(), st);
 }
 
 // ------------------------------------------------------------------------------------------------ pipelined stepping
@@ -317,11 +348,11 @@ void conan_streams::async_init() {
     // CONAN_FRONT_PRIO: 1 = front-end stream at the highest priority, -1 = at the lowest, 0 = default (experiment knob)
     int lo = 0, hi = 0;
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const char* e = getenv("CONAN_FRONT_PRIO");
+    const char* e = dev("FRONT_PRIO");
     const int mode = e ? atoi(e) : 0;
     // CONAN_FRONT_CUSTRIDE / CONAN_EMF_CUSTRIDE = s: that stage's stream may only use CUs i with i % s == 0 (experiment knob)
     auto masked = [&](hipStream_t* st, const char* env) {
-      const char* v = getenv(env);
+      const char* v = dev(env);
       const int stride = v ? atoi(v) : 0;
       if (stride < 2) { HIP_CHECK(hipStreamCreateWithFlags(st, hipStreamNonBlocking)); return; }
       std::vector<uint32_t> mask((ctx->num_cu + 31) / 32, 0u);
@@ -329,9 +360,9 @@ void conan_streams::async_init() {
       HIP_CHECK(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
     };
     if (mode == 0) {
-      masked(&st_front, "CONAN_FRONT_CUSTRIDE");
+      masked(&st_front, "FRONT_CUSTRIDE");
       HIP_CHECK(hipStreamCreateWithFlags(&st_voc, hipStreamNonBlocking));
-      masked(&st_emf, "CONAN_EMF_CUSTRIDE");
+      masked(&st_emf, "EMF_CUSTRIDE");
     } else {
       HIP_CHECK(hipStreamCreateWithPriority(&st_emf, hipStreamNonBlocking, mode > 0 ? hi : lo));
       HIP_CHECK(hipStreamCreateWithPriority(&st_front, hipStreamNonBlocking, mode > 0 ? hi : lo));
@@ -378,8 +409,7 @@ void conan_streams::build_vocoder() {
     // stages; at C = 32 a tile is short enough that the single pass wins even for one stream: 0.99 -> 0.95 ms per chunk)
     // (limb stream-sets: from 4 slots - measured per chunk at 4 / 6 streams 0.591 / 0.676 ms fused against 0.603 / 0.714 ms with the
     // two-launch plan in the wide stages, blocking p50 0.98 / 1.14 against 1.03 / 1.19 ms; at 1-3 streams the two-launch plan is as fast or faster)
-    // (chain stream-sets - voc_chain.hip: one persistent launch per step - keep the two-launch plan's rings, without the activated twins)
-    s.fused = !voc_chain && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && (max_slots >= (rb_limb ? 4 : 8) || ch_ <= 32 || getenv("CONAN_RB_FUSED") != nullptr);
+    s.fused = c.voc_resblock != 2 && dev("RB_UNFUSED") == nullptr && (max_slots >= (rb_limb ? 4 : 8) || ch_ <= 32 || dev("RB_FUSED") != nullptr);
     for (int b = 0; b < c.voc_num_resblocks && s.fused; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d)
         s.fused = s.fused && cnk::resblock_fused_supported(ch_, c.voc_rb_kernels[b], (c.voc_rb_kernels[b] - 1) * c.voc_rb_dilations[b][d]);
@@ -394,9 +424,9 @@ void conan_streams::build_vocoder() {
     // (round 4, late; until then from 48 slots on, where the two took the same time alone before conv_limb's last 10 %).  Below 16
     // slots the stage keeps conv_mfma's two-launch plan with its split-K tails: the grouped limb launches would be 2-5 % faster per
     // pipelined step there and 5-9 % slower per blocking step.  CONAN_RB_PAIR=1 keeps the pair kernel.
-    const bool limb_groups = rb_limb && max_slots >= 16 && getenv("CONAN_RB_PAIR") == nullptr;
-    if (!s.fused && !voc_chain && !limb_groups && c.voc_resblock != 2 && getenv("CONAN_RB_UNFUSED") == nullptr && getenv("CONAN_RB_NOPAIR") == nullptr &&
-        c.voc_num_resblocks <= kMaxBranches && max_slots >= (getenv("CONAN_RP_MIN_SLOTS") ? atoi(getenv("CONAN_RP_MIN_SLOTS")) : 16) && max_frames * rate <= 32) {
+    const bool limb_groups = rb_limb && max_slots >= 16 && dev("RB_PAIR") == nullptr;
+    if (!s.fused && !limb_groups && c.voc_resblock != 2 && dev("RB_UNFUSED") == nullptr && dev("RB_NOPAIR") == nullptr &&
+        c.voc_num_resblocks <= kMaxBranches && max_slots >= (dev("RP_MIN_SLOTS") ? atoi(dev("RP_MIN_SLOTS")) : 16) && max_frames * rate <= 32) {
       s.pair = true;
       for (int b = 0; b < c.voc_num_resblocks; ++b)
         for (int d = 0; d < c.voc_rb_num_dil; ++d)
@@ -410,7 +440,7 @@ void conan_streams::build_vocoder() {
     s.xs = mk_ring(ch_, rate, next_pad, &voc_state);
     // LeakyReLU'd twins of `up` and of the resblock outputs that feed another c1: the producer's epilogue writes both
     // (ConvArgs::y2_base), c1 reads the activated copy, the residual add reads the raw one
-    if (!s.fused && !voc_chain) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
+    if (!s.fused) s.upa = mk_ring(ch_, rate, (maxk - 1) * c.voc_rb_dilations[0][0], &voc_state);
     s.xt.resize(c.voc_num_resblocks); s.xo.resize(c.voc_num_resblocks); s.xa.resize(c.voc_num_resblocks);
     for (int b = 0; b < c.voc_num_resblocks; ++b)
       for (int d = 0; d < c.voc_rb_num_dil; ++d) {
@@ -418,7 +448,7 @@ void conan_streams::build_vocoder() {
         if (!s.fused) s.xt[b].push_back(mk_ring(ch_, rate, k - 1, &voc_state));
         const int h = (d + 1 < c.voc_rb_num_dil) ? (k - 1) * (c.voc_rb_dilations[b][d + 1] + (s.fused ? 1 : 0)) : next_pad;
         s.xo[b].push_back(mk_ring(ch_, rate, h, &voc_state));
-        if (!s.fused && !voc_chain && d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
+        if (!s.fused && d + 1 < c.voc_rb_num_dil) s.xa[b].push_back(mk_ring(ch_, rate, h, &voc_state));
       }
     if (s.pair) {
       s.xh.resize(c.voc_num_resblocks);
@@ -431,7 +461,6 @@ void conan_streams::build_vocoder() {
       }
     }
   }
-  if (voc_chain) vc_bar = reinterpret_cast<unsigned*>(alloc(16 * (size_t)(cnk::VC_MAX_PHASES + 2)));
 }
 
 void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float* wav_out, float* pre_tanh, hipStream_t st, const conan_hifigan_taps* taps) {
@@ -447,7 +476,6 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
                                        " needs conan_streams_reset(CONAN_MODEL_HIFIGAN) before every vocoder step (whole-utterance or windowed forward only)");
     voc_fresh[h_slots[i]] = 0;
   }
-  if (voc_chain) { chain_step(n, frames, mel_dev, wav_out, pre_tanh, st, taps); return; }      // small stream-sets: the whole step in one persistent launch
   {  // mel chunk -> ring (conv_pre needs 6 frames of left context)
     cnk::CopyArgs ca; memset(&ca, 0, sizeof(ca));
     ca.x = ch::lin_ref(const_cast<float*>(mel_dev), frames, c.num_mels); ca.y = v_mel.ref();
@@ -482,7 +510,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
       if (!s.fused) { a.y2_base = s.upa.base; a.y2_slope = LR; }
       {
         // developer switch: CONAN_UPS_CFG=c0,c1,c2,c3 forces the tile configuration (ConvCfg index) of the i-th upsampler
-        static const std::vector<int> forced = [] { std::vector<int> v; const char* e = getenv("CONAN_UPS_CFG"); if (e) { std::string t(e); size_t p = 0; while (p <= t.size()) { size_t q = t.find(',', p); if (q == std::string::npos) q = t.size(); v.push_back(atoi(t.substr(p, q - p).c_str())); p = q + 1; } } return v; }();
+        const std::vector<int> forced = [&] { std::vector<int> v; const char* e = dev("UPS_CFG"); if (e) { std::string t(e); size_t p = 0; while (p <= t.size()) { size_t q = t.find(',', p); if (q == std::string::npos) q = t.size(); v.push_back(atoi(t.substr(p, q - p).c_str())); p = q + 1; } } return v; }();
         if (i < (int)forced.size() && forced[i] >= 0 && forced[i] < cnk::NUM_CFG) { ConvGroup g; g.p[0] = a; launch_group(g, 1, forced[i], st); }
         else conv(a, st);
       }
@@ -533,7 +561,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         if (d + 1 < ND) { a1.y2_base = s.xa[b][d].base; a1.y2_slope = LR; }
         g1.p[b] = a1;
       }
-      launch_group(g1, NB, pick_cfg(n * T, s.C, NB), st);
+      launch_group(g1, NB, pick_cfg(plan_n(n) * T, s.C, NB), st);
     }
     for (int d = 0; d < ND && c.voc_resblock != 2 && !s.fused; ++d) {  // ResBlock1 as two grouped conv launches (widths the fused pass does not cover)
       ConvGroup g1, g2;
@@ -550,7 +578,7 @@ void conan_streams::hifigan_step(int n, int frames, const float* mel_dev, float*
         if (d + 1 < ND) { a2.y2_base = s.xa[b][d].base; a2.y2_slope = LR; }
         g2.p[b] = a2;
       }
-      const int cfg = pick_cfg(n * T, s.C, NB);
+      const int cfg = pick_cfg(plan_n(n) * T, s.C, NB);
       launch_group(g1, NB, cfg, st);
       launch_group(g2, NB, cfg, st);
     }
@@ -652,10 +680,10 @@ void conan_streams::build_emformer() {
       unsigned* words = reinterpret_cast<unsigned*>(alloc(fw));
       HIP_CHECK(hipMemset(words, 0, fw * sizeof(unsigned)));
       a.xflag = words; a.xepoch = words + (size_t)max_slots * cnk::EMF_MAX_LAYERS * cnk::EMF_MAX_CLUSTER;
-      const char* e = getenv("CONAN_EMF_CLUSTER");
+      const char* e = dev("EMF_CLUSTER");
       emf_cluster = e ? atoi(e) : 0;       // 0: chosen per launch from the stream count
     }
-    const char* off = getenv("CONAN_EMF_UNFUSED");
+    const char* off = dev("EMF_UNFUSED");
     emf_fused = cnk::emformer_fused_supported(a) && !(off && off[0] == '1');
   }
 }
@@ -675,7 +703,7 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       // The members of a cluster spin on each other's flags: every workgroup of the launch must be able to be resident at
       // once (one 129 KB workgroup per CU).  The developer override is clamped to that like the automatic choice, and a
       // CU-masked Emformer stream (CONAN_EMF_CUSTRIDE) gets no clusters at all.
-      static const bool masked = getenv("CONAN_EMF_CUSTRIDE") != nullptr && atoi(getenv("CONAN_EMF_CUSTRIDE")) >= 2;
+      const bool masked = dev("EMF_CUSTRIDE") != nullptr && atoi(dev("EMF_CUSTRIDE")) >= 2;
       // (At most 64 workgroups - unless this launch cannot overlap anything else of the context.  A workgroup needs a whole CU for the
       // launch's 150-250 us.  In pipelined steps - the launch is on the stream-set's own Emformer stream - the vocoder's persistent
       // launches run beside it on what is left: 128 -> 64 workgroups measured 0.990 -> 0.979, 1.175 -> 1.154, 1.336 -> 1.317, 1.516 ->
@@ -685,11 +713,11 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       // need PART of one - with the Emformer on more than CUs - 128 - .. workgroups two overlapping launches can each hold what the
       // other still needs (round 5: one workgroup per CU in every blocking step made tests/test_gpu_stress.py, whose blocking and
       // pipelined stream-sets overlap on the device, give up in the pair kernel's mailbox wait one run in five).  So one workgroup per
-      // CU - 64 streams: 190 -> 136 us on the blocking chunk's critical path - only for a blocking step of the ONLY stream-set of its
-      // context: its launches are serialised on one stream.  The feed-forward's sum is formed chunk by chunk in chunk order whatever the
+      // CU - 64 streams: 190 -> 136 us on the blocking chunk's critical path - only for a blocking step of the ONLY stream-set on its
+      // device (counted over all contexts of the process; CONAN_STREAMS_SHARED_DEVICE when other processes use the GPU): its launches are serialised on one stream.  The feed-forward's sum is formed chunk by chunk in chunk order whatever the
       // cluster size (emformer_fused.hip), so the step styles and both policies produce the same bits.)
       const bool pipelined = st_emf != nullptr && st == st_emf;       // (the internal stream exists only once a pipelined step has run; a caller's null stream is not it)
-      const bool alone = !pipelined && live && live->load() == 1;
+      const bool alone = !pipelined && !shared_device && live && live->load() == 1;
       const int cap = (emf_cluster > 0 || alone) ? ctx->num_cu : 64;
       a.cs = emf_cluster > 0 ? std::min(emf_cluster, (int)cnk::EMF_MAX_CLUSTER) : cnk::EMF_MAX_CLUSTER;
       while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two

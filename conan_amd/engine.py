@@ -202,11 +202,13 @@ class StreamingVoiceConversionEngine:
     """The chunk loop of StreamingVoiceConversion.infer_once (inference/Conan.py:72-166) for many
     streams at once: mel in -> (wav, mel, codes) out, state carried in a conan_streams handle."""
 
-    def __init__(self, ctx, n_streams, max_ref_frames=256, max_frames=None, arith="auto"):
+    def __init__(self, ctx, n_streams, max_ref_frames=256, max_frames=None, arith="auto", flags=0, dev_plan=None):
         self.ctx = ctx
         self.n = n_streams
         self.arith = arith          # conan_streams_opts.arith of the stream-set: 'auto' | 'f32' | 'limb'
-        self.st = ctx.streams(n_streams, max_frames=max(ctx.cfg.emf_segment, max_frames or 0), max_ref_frames=max_ref_frames, arith=arith)
+        self.flags, self.dev_plan = flags, dev_plan      # conan_streams_opts.flags (_lib.STREAMS_*) / .dev_plan
+        self.st = ctx.streams(n_streams, max_frames=max(ctx.cfg.emf_segment, max_frames or 0), max_ref_frames=max_ref_frames, arith=arith,
+                              flags=flags, dev_plan=dev_plan)
         self.slots = list(range(n_streams))
         self.seg, self.rc = ctx.cfg.emf_segment, ctx.cfg.emf_right_context
 
@@ -284,7 +286,7 @@ class StreamingVoiceConversionEngine:
         if self.st.max_frames < T:
             mr = self.st.max_ref_frames
             self.st.close()
-            self.st = self.ctx.streams(self.n, max_frames=T, max_ref_frames=mr, arith=self.arith)
+            self.st = self.ctx.streams(self.n, max_frames=T, max_ref_frames=mr, arith=self.arith, flags=self.flags, dev_plan=self.dev_plan)
         self.start(ref_mel, ref_len)
         hop = self.ctx.hop
         wavs, mels, codes = [], [], []

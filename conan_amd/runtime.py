@@ -91,10 +91,11 @@ class Context:
         assert got.value == frames
         return mel
 
-    def streams(self, max_slots, max_frames=4, max_ref_frames=256, arith="auto", flags=0):
+    def streams(self, max_slots, max_frames=4, max_ref_frames=256, arith="auto", flags=0, dev_plan=None):
         """A stream-set.  arith: 'auto' (library default), 'f32' (f32-input MFMA everywhere) or 'limb' (fp32 products of the
-        vocoder's matrix kernels as bf16 limb products) - conan_streams_opts.arith."""
-        return Streams(self, max_slots, max_frames, max_ref_frames, arith, flags)
+        vocoder's matrix kernels as bf16 limb products) - conan_streams_opts.arith; flags: _lib.STREAMS_*; dev_plan: developer /
+        test switches of the launch plan, "NAME=value;..." (conan_streams_opts.dev_plan; None in deployments)."""
+        return Streams(self, max_slots, max_frames, max_ref_frames, arith, flags, dev_plan)
 
     def close(self):
         if getattr(self, "h", None):
@@ -111,12 +112,12 @@ class Context:
 class Streams:
     """conan_streams: per-slot streaming state + the step functions."""
 
-    def __init__(self, ctx, max_slots, max_frames=4, max_ref_frames=256, arith="auto", flags=0):
+    def __init__(self, ctx, max_slots, max_frames=4, max_ref_frames=256, arith="auto", flags=0, dev_plan=None):
         self.ctx, self.lib = ctx, ctx.lib
         self.max_slots, self.max_frames, self.max_ref_frames = max_slots, max_frames, max_ref_frames
         if arith not in _lib.ARITH_NAMES:
             raise ValueError(f"arith must be one of {sorted(_lib.ARITH_NAMES)}, got {arith!r}")
-        opts = _lib.StreamsOpts(_lib.ABI_VERSION, _lib.ARITH_NAMES[arith], int(flags))      # flags: _lib.STREAMS_* (conan_streams_opts.flags)
+        opts = _lib.StreamsOpts(_lib.ABI_VERSION, _lib.ARITH_NAMES[arith], int(flags), 0, dev_plan.encode() if dev_plan else None)
         h = C.c_void_p()
         _lib.check(self.lib.conan_streams_create_opts(ctx.h, max_slots, max_frames, max_ref_frames, C.byref(opts), C.byref(h)))
         self._keep = []   # buffers of pipelined steps in flight (released by join())

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CONAN_HIP_ABI_VERSION 7
+#define CONAN_HIP_ABI_VERSION 8
 
 typedef enum conan_status {
   CONAN_OK = 0,
@@ -137,9 +137,10 @@ int conan_streams_destroy(conan_streams* s);
  * slots in a large stream-set take the f32 kernels there, exactly like the split-K factor of the f32 conv kernel follows the active
  * count.  A stream's audio therefore differs between steps with different active sets by fp32 re-association / the form of a
  * product, within the tolerance every form is held to (tests/test_gpu_configs.py: a stream inside a batch of 64 against the same
- * stream alone, 2e-5; tests/test_gpu_round5.py: both forms against the reference goldens at the plan-switch sizes 3 .. 40). */
+ * stream alone, 2e-5; tests/test_gpu_round5.py: both forms against the reference goldens at the plan-switch sizes 3 .. 40).
+ * CONAN_STREAMS_FIXED_PLAN (below) removes that dependence: the plan then follows max_slots only. */
 typedef enum conan_arith { CONAN_ARITH_AUTO = 0, CONAN_ARITH_F32 = 1, CONAN_ARITH_LIMB = 2 } conan_arith;
-/* Deployment choices of a stream-set (conan_streams_opts.flags; ABI 7 - until round 4 environment variables):
+/* Deployment choices of a stream-set (conan_streams_opts.flags):
  *   CONAN_STREAMS_FUSED_DECODER_BLOCKS  the decoder's conv blocks [LN -> k5 conv -> GELU] -> [1x1 conv + residual] as ONE operator each
  *                                       of the persistent decoder launch: 2 % less blocking latency at 64 streams, 1.4 % MORE time per
  *                                       pipelined step (every group member reads eight partial tensors) - for latency-bound serving;
@@ -147,15 +148,32 @@ typedef enum conan_arith { CONAN_ARITH_AUTO = 0, CONAN_ARITH_F32 = 1, CONAN_ARIT
  *                                       separate launches instead of the persistent launch in xcd mode (0.41 against
  *                                       0.28 ms per one-stream step) - an A/B switch, and a way out on parts whose workgroup -> XCD
  *                                       placement gives an XCD fewer than 8 workgroups of a 256-workgroup launch;
- *   CONAN_STREAMS_VOCODER_CHAIN         the vocoder step of a small stream-set (slots x frames <= 16) as one persistent launch
- *                                       (voc_chain.hip) - parity-green but measured SLOWER than the launch plans (0.40 against 0.35 ms
- *                                       at one stream), hence opt-in; f32 arithmetic only (ignored when arith = LIMB). */
-enum { CONAN_STREAMS_FUSED_DECODER_BLOCKS = 1, CONAN_STREAMS_SEPARATE_SMALL_STEPS = 2, CONAN_STREAMS_VOCODER_CHAIN = 4 };
+ *   (bit 4, CONAN_STREAMS_VOCODER_CHAIN of ABI 7, is retired: the one-launch vocoder step of small stream-sets measured slower
+ *   than the launches it replaced at every size and left the library - tools/experiments/voc_chain; the bit is rejected)
+ *   CONAN_STREAMS_FIXED_PLAN            (ABI 8) every launch-plan choice - kernel form (limb / f32), tile shape, split-K factor, merged
+ *                                       stage tails, the decoder step's single-tile or multi-tile form - is made from max_slots
+ *                                       and the step's frame count ONLY, never from the number of slots active in the step: slot k's
+ *                                       audio is bit-identical whichever other slots step with it (the reference is batch-1 and
+ *                                       deterministic per utterance, inference/Conan.py:109-113; a serving API can promise the
+ *                                       same).  Costs throughput only when few slots of a large stream-set are active (the plan is
+ *                                       the full set's); at full occupancy the plan IS the default's;
+ *   CONAN_STREAMS_SHARED_DEVICE         (ABI 8) other PROCESSES drive this GPU too: never give a launch that waits inside itself
+ *                                       (Emformer clusters) the whole chip.  Inside one process the library counts the live stream-sets
+ *                                       per device itself (over all contexts) and takes the whole-chip shape only for blocking steps
+ *                                       of the only one. */
+enum { CONAN_STREAMS_FUSED_DECODER_BLOCKS = 1, CONAN_STREAMS_SEPARATE_SMALL_STEPS = 2, CONAN_STREAMS_FIXED_PLAN = 8, CONAN_STREAMS_SHARED_DEVICE = 16 };
 typedef struct conan_streams_opts {
   int32_t abi_version;   /* must be CONAN_HIP_ABI_VERSION */
   int32_t arith;         /* conan_arith */
   int32_t flags;         /* bitwise or of CONAN_STREAMS_* (0: the defaults) */
-  int32_t reserved[5];   /* must be 0 */
+  int32_t reserved0;     /* must be 0 */
+  /* NULL in deployments.  Developer / test switches of the launch plan as "NAME=value;NAME=value" (A/B runs, the cross-checks of
+   * tests/test_gpu_round3.py: e.g. "FENCED=1", "EMF_UNFUSED=1", "DEC_MEGA=0"); unknown names are CONAN_ERR_INVALID.  Since ABI 8 the
+   * shipped library reads NO environment variable: a process's plan is a function of the arguments it passes, not of its
+   * environment (until ABI 7 these were CONAN_* environment variables; `make DEV=1` builds still accept those).  The one runtime
+   * knob that stays in the environment is HIP's own GPU_MAX_HW_QUEUES (Multi-GPU). */
+  const char* dev_plan;
+  int32_t reserved[2];   /* must be 0 */
 } conan_streams_opts;
 /* conan_streams_create with options (opts == NULL: all defaults, i.e. conan_streams_create). */
 int conan_streams_create_opts(conan_ctx* ctx, int max_slots, int max_frames, int max_ref_frames, const conan_streams_opts* opts,

@@ -99,13 +99,13 @@ def test_hifigan_long_steps_and_ragged_frames(env):
     st.close()
 
 
-def _emformer_stream_vs_oracle(env):
+def _emformer_stream_vs_oracle(env, dev_plan=None):
     from oracle import emformer as oemf
     tag, ctx, chp, vhp, sds = env
     cfg = oemf.EmformerCfg(chp)
     B, T = 3, 72
     mel = torch.from_numpy(synth.mel(T, 1234, B))
-    st = _streams(ctx, 4, max_frames=4, max_ref_frames=16)
+    st = _streams(ctx, 4, max_frames=4, max_ref_frames=16, dev_plan=dev_plan)
     slots = [3, 1, 0]
     st.reset(slots)
     state = None
@@ -126,10 +126,9 @@ def test_emformer_stream_vs_oracle(env):
     _emformer_stream_vs_oracle(env)
 
 
-def test_emformer_per_op_path_vs_oracle(env, monkeypatch):
-    """The per-op launch plan that covers shapes the fused kernel does not (CONAN_EMF_UNFUSED=1 selects it)."""
-    monkeypatch.setenv("CONAN_EMF_UNFUSED", "1")
-    _emformer_stream_vs_oracle(env)
+def test_emformer_per_op_path_vs_oracle(env):
+    """The per-op launch plan that covers shapes the fused kernel does not (conan_streams_opts.dev_plan "EMF_UNFUSED=1" selects it)."""
+    _emformer_stream_vs_oracle(env, dev_plan="EMF_UNFUSED=1")
 
 
 def test_conan_decoder_vs_oracle_and_golden(env):

@@ -81,7 +81,7 @@ def test_emformer_against_torchaudio(variant):
 
 @pytest.mark.parametrize("plan", ["fused", "per-op"])
 @pytest.mark.parametrize("M,tanh", [(4, False), (2, True)])
-def test_emformer_memory_bank_vs_oracle(M, tanh, plan, monkeypatch):
+def test_emformer_memory_bank_vs_oracle(M, tanh, plan):
     """The memory bank of torchaudio's Emformer (max_memory_size > 0: summary token, per-layer bank of the last M segment
     memories as extra attention keys, clamp / tanh on the produced memory) - BASELINE.json north_star "memory-bank
     update".  modules/Emformer/emformer.py:14-22 never enables it, so this is an extra, non-parity datapoint: the HIP
@@ -91,10 +91,7 @@ def test_emformer_memory_bank_vs_oracle(M, tanh, plan, monkeypatch):
     from oracle.common import to_torch_sd
     # plan "fused": the one-launch step (round 3: summary and memory-input rows in the 16-row tile, the bank as projected key /
     # value rows at the head of the key tables); "per-op": the separate kernels (CONAN_EMF_UNFUSED=1, read at stream-set creation)
-    if plan == "per-op":
-        monkeypatch.setenv("CONAN_EMF_UNFUSED", "1")
-    else:
-        monkeypatch.delenv("CONAN_EMF_UNFUSED", raising=False)
+    dev_plan = "EMF_UNFUSED=1" if plan == "per-op" else None
     chp = dict(configs.conan_hparams(), emformer_max_memory_size=M, emformer_tanh_on_mem=tanh)
     ctx, chp, _ = _ctx(chp, conan=False, hifigan=False)
     assert ctx.cfg.emf_max_memory_size == M
@@ -102,7 +99,7 @@ def test_emformer_memory_bank_vs_oracle(M, tanh, plan, monkeypatch):
     cfg = oemf.EmformerCfg(chp)
     B, T = 3, 80
     mel = torch.from_numpy(synth.mel(T, 33, B))
-    st = ctx.streams(4, max_frames=4, max_ref_frames=16)
+    st = ctx.streams(4, max_frames=4, max_ref_frames=16, dev_plan=dev_plan)
     slots = [3, 0, 2]
     st.reset(slots)
     state = None
@@ -128,7 +125,7 @@ def test_emformer_memory_bank_vs_oracle(M, tanh, plan, monkeypatch):
     st.close(); ctx.close()
 
 
-def test_emformer_cluster_mode_matches_single_workgroup(monkeypatch):
+def test_emformer_cluster_mode_matches_single_workgroup():
     """The fused Emformer step spread over clusters of 8 / 4 / 2 workgroups per stream group (feed-forward hidden units
     split over the cluster, one write-through exchange of partial sums per layer, emformer_fused.hip) against the same
     step with one workgroup per group, over 30 chunks (left-context ring wraps, a stream restarts half way).  Round 5: every hidden
@@ -143,9 +140,7 @@ def test_emformer_cluster_mode_matches_single_workgroup(monkeypatch):
     slots = [4, 1, 0, 3, 2]
     sets = {}
     for cs in ("1", "2", "4", "8", "8"):
-        monkeypatch.setenv("CONAN_EMF_CLUSTER", cs)
-        sets.setdefault(cs, []).append(ctx.streams(6, max_frames=4, max_ref_frames=16))
-    monkeypatch.delenv("CONAN_EMF_CLUSTER")
+        sets.setdefault(cs, []).append(ctx.streams(6, max_frames=4, max_ref_frames=16, dev_plan="EMF_CLUSTER=" + cs))
     allsets = [st for v in sets.values() for st in v]
     for st in allsets:
         st.reset(slots)
@@ -166,7 +161,7 @@ def test_emformer_cluster_mode_matches_single_workgroup(monkeypatch):
     ctx.close()
 
 
-def test_merged_branch_launches_equal_separate_branches_bitwise(monkeypatch):
+def test_merged_branch_launches_equal_separate_branches_bitwise():
     """Last dilation of a vocoder stage: the merged-branch build of the fused ResBlock pass (one workgroup runs the three
     branches of a (slot, row tile) group and stores leaky_relu(mean); 64 streams: stages C = 64 and C = 32) against
     separate branch tiles + mean_act / conv_post forming the mean - the same 64 streams, the same other kernels, so the
@@ -178,9 +173,7 @@ def test_merged_branch_launches_equal_separate_branches_bitwise(monkeypatch):
     mel = torch.from_numpy(synth.mel(4 * steps, 77, B)).cuda()                    # [B, 16, 80]
     merged = ctx.streams(B, max_frames=4, max_ref_frames=16)
     alt = ctx.streams(B, max_frames=4, max_ref_frames=16)
-    monkeypatch.setenv("CONAN_RB_NOMERGE", "1")
-    separate = ctx.streams(B, max_frames=4, max_ref_frames=16)
-    monkeypatch.delenv("CONAN_RB_NOMERGE")
+    separate = ctx.streams(B, max_frames=4, max_ref_frames=16, dev_plan="RB_NOMERGE=1")
     slots = list(range(B))
     for st in (merged, separate, alt):
         st.reset(slots)

@@ -49,7 +49,7 @@ def test_single_branch_vocoder_keeps_the_last_leaky_relu(tiny, slots):
 
 def test_fence_free_handoffs_match_the_fenced_build_under_concurrency():
     """Split-K partial tiles (conv_mfma) and the Emformer cluster exchange travel as write-through stores + a flag / ticket +
-    sc1 loads, without release / acquire fences.  Cross-check: a second stream-set created with CONAN_FENCED=1 brackets the
+    sc1 loads, without release / acquire fences.  Cross-check: a second stream-set created with dev_plan "FENCED=1" brackets the
     same hand-offs with agent-scope fences; at 1-4 streams all three pipelined stages split K / run clusters concurrently on
     their internal streams.  Every output of 120 pipelined steps must be bit-identical between the two (the split factors
     and cluster sizes are the same, so any difference is a stale read)."""
@@ -61,17 +61,8 @@ def test_fence_free_handoffs_match_the_fenced_build_under_concurrency():
     ctx.load_state_dict("hifigan", synth.hifigan_state_dict(vhp, 0))
     ctx.finalize()
     S, N = 4, 120
-    old = os.environ.get("CONAN_FENCED")
-    try:
-        os.environ["CONAN_FENCED"] = "0"
-        plain = ctx.streams(S, 4, 64)
-        os.environ["CONAN_FENCED"] = "1"
-        fenced = ctx.streams(S, 4, 64)
-    finally:
-        if old is None:
-            os.environ.pop("CONAN_FENCED", None)
-        else:
-            os.environ["CONAN_FENCED"] = old
+    plain = ctx.streams(S, 4, 64)
+    fenced = ctx.streams(S, 4, 64, dev_plan="FENCED=1")
     ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
     src = torch.from_numpy(synth.mel(4 * N + 8, 9, S)).cuda()
     hop = ctx.hop
@@ -146,21 +137,12 @@ def test_wide_stage_pairs_match_reference_goldens(arith, S):
 
 def test_wide_stage_pairs_equal_the_two_launch_plan_per_stage():
     """Same streams through a 24-slot stream-set (pair kernel in the first stage) and through a 24-slot stream-set created
-    with CONAN_RB_NOPAIR=1 (conv_mfma two-launch plan there): per-stage tensors and audio agree to fp32 re-association."""
+    with dev_plan "RB_NOPAIR=1" (conv_mfma two-launch plan there): per-stage tensors and audio agree to fp32 re-association."""
     vhp = configs.hifigan_hparams()
     ctx = _voc_ctx(vhp)
     S = 24
-    old = os.environ.get("CONAN_RB_NOPAIR")
-    try:
-        os.environ.pop("CONAN_RB_NOPAIR", None)
-        a = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32")       # (the pair kernel is the exact-f32 form of this stage)
-        os.environ["CONAN_RB_NOPAIR"] = "1"
-        b = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32")
-    finally:
-        if old is None:
-            os.environ.pop("CONAN_RB_NOPAIR", None)
-        else:
-            os.environ["CONAN_RB_NOPAIR"] = old
+    a = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32")       # (the pair kernel is the exact-f32 form of this stage)
+    b = ctx.streams(S, max_frames=4, max_ref_frames=16, arith="f32", dev_plan="RB_NOPAIR=1")
     ids = list(range(S))
     mel = torch.from_numpy(synth.mel(24, 5, S)).cuda()
     for st in (a, b):
@@ -178,7 +160,7 @@ def test_wide_stage_pairs_equal_the_two_launch_plan_per_stage():
 
 def test_decoder_megakernel_equals_the_separate_launches():
     """The decoder step as one persistent launch (decoder_mega.hip: row-tile groups, group barriers, agent-scope activation
-    accesses, fused feed-forward) against the same step as ~38 separate launches (CONAN_DEC_MEGA=0) on the same streams:
+    accesses, fused feed-forward) against the same step as ~38 separate launches (dev_plan "DEC_MEGA=0") on the same streams:
     20 steps of 4 frames at 24 streams (6 row tiles), then the ragged tail (3 frames: separate launches in both).  mel within
     fp32 re-association (the fused feed-forward sums its hidden units in a different order), and the megakernel twice gives
     the same bits (no stale reads between its operators)."""
@@ -188,17 +170,8 @@ def test_decoder_megakernel_equals_the_separate_launches():
     ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
     ctx.finalize()
     S = 24
-    old = os.environ.get("CONAN_DEC_MEGA")
-    try:
-        os.environ.pop("CONAN_DEC_MEGA", None)
-        a = ctx.streams(S, 4, 64); a2 = ctx.streams(S, 4, 64)
-        os.environ["CONAN_DEC_MEGA"] = "0"
-        b = ctx.streams(S, 4, 64)
-    finally:
-        if old is None:
-            os.environ.pop("CONAN_DEC_MEGA", None)
-        else:
-            os.environ["CONAN_DEC_MEGA"] = old
+    a = ctx.streams(S, 4, 64); a2 = ctx.streams(S, 4, 64)
+    b = ctx.streams(S, 4, 64, dev_plan="DEC_MEGA=0")
     ids = list(range(S))
     ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
     codes = torch.from_numpy(synth.codes(83, S)).int().cuda()
@@ -212,7 +185,7 @@ def test_decoder_megakernel_equals_the_separate_launches():
     a.close(); a2.close(); b.close(); ctx.close()
 
 
-@pytest.mark.parametrize("streams", [1, 12])
+@pytest.mark.parametrize("streams", [1, 4, 12])
 def test_decoder_widths_come_from_the_checkpoint(streams):
     """A checkpoint with a 64-channel uv predictor and a 512-wide aligner feed-forward (the reference hard-codes 128 / 2048 in
     its constructors; hidden_size 128 here): the host plans size their buffers and kernels from the loaded tensors.  Style
@@ -264,23 +237,9 @@ def test_decoder_widths_come_from_the_checkpoint(streams):
 
 
 def _two_stream_sets(ctx, S, *envs, arith="limb"):
-    """Stream-sets created under the developer switches of each env (they are read at creation)."""
-    keys = set().union(*envs)
-    old = {k: os.environ.get(k) for k in keys}
-    try:
-        sets = []
-        for env in envs:
-            for k in keys:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            sets.append(ctx.streams(S, max_frames=4, max_ref_frames=16, arith=arith))
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    return sets
+    """Stream-sets created with the developer switches of each env (conan_streams_opts.dev_plan; {"CONAN_X": "1"} -> "X=1")."""
+    return [ctx.streams(S, max_frames=4, max_ref_frames=16, arith=arith,
+                        dev_plan=";".join(f"{k[len('CONAN_'):]}={v}" for k, v in env.items()) or None) for env in envs]
 
 
 def _kernel_names(st, ids, mel):

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from conan_amd import configs, synth
+from conan_amd import _lib
 from tests.conftest import ARITHS, assert_arith_ran, kernels_of, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -53,14 +54,15 @@ def test_conan_golden_through_the_decoder_megakernel():
 
 
 @pytest.mark.parametrize("arith", ARITHS)
-def test_loop_golden_at_48_slots(arith):
+@pytest.mark.parametrize("S,K", [(48, 29), (64, 41), (128, 77)])
+def test_loop_golden_at_48_slots(S, K, arith):
     """tests/golden/loop_full.npz (mel / wav of the reference loop inference/Conan.py:95-156 from the imported reference modules
-    for a given code sequence) through slot 29 of a 48-slot stream-set, decoder step -> vocoder step per 4-frame chunk as the
-    fused chunk step issues them: the decoder as one megakernel launch, the vocoder in both arithmetic forms - at 48 slots the
-    limb form covers every ResBlock stage (conv_limb's grouped launches in the C = 256 stage) and ups.2 / ups.3."""
+    for a given code sequence) through slot K of an S-slot stream-set, decoder step -> vocoder step per 4-frame chunk as the
+    fused chunk step issues them: the decoder as one megakernel launch, the vocoder in both arithmetic forms - from 48 slots on the
+    limb form covers every ResBlock stage (conv_limb's grouped launches in the C = 256 stage) and ups.2 / ups.3.  S = 64 is
+    BASELINE.json configs[2]'s stream count (the headline), 128 configs[4]'s."""
     g = load_golden("loop_full.npz")
     ctx, chp, vhp = _ctx()
-    S, K = 48, 29
     st = ctx.streams(S, max_frames=4, max_ref_frames=64, arith=arith)
     assert st.arith == arith
     ids = list(range(S))
@@ -106,7 +108,10 @@ def test_arith_option_through_the_c_abi():
     assert ctx.lib.conan_streams_arith(h) == _lib.ARITH_LIMB
     ctx.lib.conan_streams_destroy(h)
     for opts, code in ((_lib.StreamsOpts(_lib.ABI_VERSION, 7), _lib.ERR_INVALID), (_lib.StreamsOpts(_lib.ABI_VERSION - 1, 0), _lib.ERR_INVALID),
-                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 0, (C.c_int32 * 5)(0, 0, 1, 0, 0)), _lib.ERR_INVALID),
+                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 0, 0, None, (C.c_int32 * 2)(0, 1)), _lib.ERR_INVALID),
+                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 0, 1), _lib.ERR_INVALID),
+                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 0, 0, b"NOT_A_SWITCH=1"), _lib.ERR_INVALID),      # (an unknown dev_plan name)
+                       (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 4), _lib.ERR_INVALID),       # (bit 4: ABI 7's VOCODER_CHAIN, retired)
                        (_lib.StreamsOpts(_lib.ABI_VERSION, 0, 64), _lib.ERR_INVALID)):      # (an unknown flag bit)
         assert ctx.lib.conan_streams_create_opts(ctx.h, 2, 4, 16, C.byref(opts), C.byref(h)) == code
     with pytest.raises(ValueError):
@@ -132,8 +137,8 @@ def test_arith_option_through_the_c_abi():
     d.close(); dec.close()
 
 
-def test_fused_conv_block_operators_equal_the_separate_launches(monkeypatch):
-    """CONAN_MEGA_BLK=1 (developer switch; off by default because it costs the pipelined step 1.4 % - DESIGN.md): the decoder's
+def test_fused_conv_block_operators_equal_the_separate_launches():
+    """CONAN_STREAMS_FUSED_DECODER_BLOCKS (off by default because it costs the pipelined step 1.4 % - DESIGN.md): the decoder's
     eight sub-layers [LN -> k5 conv -> GELU] -> [1x1 conv + residual, masks] as ONE megakernel operator each (the 16 x 512 hidden
     tile stays in LDS, the 1x1 conv's K loop is split over the group, the consumer forms x' from 8 partial tensors) against the same
     step as ~38 separate launches: 12 steps of 4 frames at 24 streams, mel within fp32 re-association; the fused program twice gives
@@ -144,11 +149,8 @@ def test_fused_conv_block_operators_equal_the_separate_launches(monkeypatch):
     ctx.load_state_dict("conan", synth.conan_state_dict(chp, 0))
     ctx.finalize()
     S = 24
-    monkeypatch.setenv("CONAN_MEGA_BLK", "1")
-    a, a2 = ctx.streams(S, 4, 64), ctx.streams(S, 4, 64)
-    monkeypatch.setenv("CONAN_DEC_MEGA", "0")
-    b = ctx.streams(S, 4, 64)
-    monkeypatch.delenv("CONAN_DEC_MEGA")
+    a, a2 = ctx.streams(S, 4, 64, flags=_lib.STREAMS_FUSED_DECODER_BLOCKS), ctx.streams(S, 4, 64, flags=_lib.STREAMS_FUSED_DECODER_BLOCKS)
+    b = ctx.streams(S, 4, 64, dev_plan="DEC_MEGA=0")
     ids = list(range(S))
     ref = torch.from_numpy(synth.mel(40, 8, S)).cuda()
     codes = torch.from_numpy(synth.codes(48, S)).int().cuda()

@@ -279,13 +279,13 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("gcc not present")
     src = tmp_path / "probe.c"
-    src.write_text('#include <stdio.h>\n#include "conan_hip.h"\nint main(void) {\n'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "conan_hip.h"\nint main(void) {\n'
                    '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(conan_cfg), sizeof(conan_mel_cfg), sizeof(conan_decoder_taps), sizeof(conan_hifigan_taps),\n'
                    '         sizeof(conan_streams_opts), sizeof(void*));\n'
                    '  printf("%d %d %d %d\\n", CONAN_HIP_ABI_VERSION, CONAN_ARITH_AUTO, CONAN_ARITH_F32, CONAN_ARITH_LIMB);\n'
                    '  printf("%d %d %d %d %d %d %d\\n", CONAN_OK, CONAN_ERR_INVALID, CONAN_ERR_MISSING, CONAN_ERR_SHAPE, CONAN_ERR_HIP, CONAN_ERR_STATE, CONAN_ERR_UNSUPPORTED);\n'
                    '  printf("%d %d %d %d\\n", CONAN_MAX_UPS, CONAN_MAX_RESBLOCKS, CONAN_MAX_DILATIONS, CONAN_MAX_DEC_BLOCKS);\n'
-                   '  printf("%d %d %d\\n", CONAN_STREAMS_FUSED_DECODER_BLOCKS, CONAN_STREAMS_SEPARATE_SMALL_STEPS, CONAN_STREAMS_VOCODER_CHAIN);\n  return 0;\n}\n')
+                   '  printf("%d %d %d %d %zu\\n", CONAN_STREAMS_FUSED_DECODER_BLOCKS, CONAN_STREAMS_SEPARATE_SMALL_STEPS, CONAN_STREAMS_FIXED_PLAN, CONAN_STREAMS_SHARED_DEVICE, offsetof(conan_streams_opts, dev_plan));\n  return 0;\n}\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.dirname(_lib.HEADER_PATH), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
@@ -294,6 +294,30 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
     assert [int(x) for x in out[1].split()] == [_lib.ABI_VERSION, _lib.ARITH_AUTO, _lib.ARITH_F32, _lib.ARITH_LIMB]
     assert [int(x) for x in out[2].split()] == [_lib.OK, _lib.ERR_INVALID, _lib.ERR_MISSING, _lib.ERR_SHAPE, _lib.ERR_HIP, _lib.ERR_STATE, _lib.ERR_UNSUPPORTED]
     assert [int(x) for x in out[3].split()] == [_lib.MAX_UPS, _lib.MAX_RESBLOCKS, _lib.MAX_DILATIONS, _lib.MAX_DEC_BLOCKS]
-    assert [int(x) for x in out[4].split()] == [_lib.STREAMS_FUSED_DECODER_BLOCKS, _lib.STREAMS_SEPARATE_SMALL_STEPS, _lib.STREAMS_VOCODER_CHAIN]
+    assert [int(x) for x in out[4].split()] == [_lib.STREAMS_FUSED_DECODER_BLOCKS, _lib.STREAMS_SEPARATE_SMALL_STEPS, _lib.STREAMS_FIXED_PLAN, _lib.STREAMS_SHARED_DEVICE, _lib.StreamsOpts.dev_plan.offset]
     # every entry point the header declares has a prototype in the binding, and the other way round
     assert sorted(_lib._PROTOS) == _lib.declared_symbols()
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """Since ABI 8 the launch plan is a function of the arguments (conan_streams_opts.flags / .dev_plan), never of the process
+    environment: the only getenv call in the library's sources is the one inside dev_getenv's `make DEV=1` branch, and the built
+    library carries none of the former CONAN_* variable names that were plan switches."""
+    import glob
+    import re
+    csrc = os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc")
+    hits = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.inc"))):
+        text = open(path).read()
+        for m in re.finditer(r"(?<![A-Za-z_])getenv\(", text):
+            line = text.count("\n", 0, m.start()) + 1
+            hits.append((os.path.basename(path), line))
+    # kernels.h: dev_getenv's body; streams.h: conan_streams::dev()'s CONAN_DEV_SWITCHES branch
+    assert sorted(set(f for f, _ in hits)) == ["kernels.h", "streams.h"], hits
+    for f, line in hits:
+        src = open(os.path.join(csrc, f)).read().split("\n")
+        window = "\n".join(src[max(0, line - 4):line])
+        assert "#ifdef CONAN_DEV_SWITCHES" in window, (f, line)
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"CONAN_EMF_UNFUSED", b"CONAN_FENCED", b"CONAN_MEGA_BLK", b"CONAN_RB_NOLIMB", b"CONAN_DEC_MEGA", b"CONAN_SKIP_STAGE"):
+        assert name not in blob, name
