@@ -475,7 +475,7 @@ bool conv_limb_supported(const ConvArgs& a) {
 // tile shape index for a group of problems (same n, T and column count), or -1: the shape with the smallest estimated
 // makespan among those that fit and give every CU a tile
 // plan_n > 0 (fixed-plan stream-sets): tile counts, the fill-the-chip thresholds and the cost model use plan_n slots instead of the
-// launch's own, and a last tile may be ragged for a single problem too - the choice must not depend on the active slots
+// launch's own, and the launch's own last tile may be ragged where the full set's is not - the choice must not depend on the active slots
 int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n) {
   static const int forced = (dev_getenv("CONAN_CL_SHAPE") && *dev_getenv("CONAN_CL_SHAPE")) ? atoi(dev_getenv("CONAN_CL_SHAPE")) : -1;      // developer switch
   int best = -1; double best_cost = 1e30;
@@ -486,7 +486,10 @@ int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n) {
     double units = 0, umax = 0;
     long long tiles = 0;
     for (int q = 0; q < nprob && ok; ++q) {
-      ok = shape_fits(s, p[q], nprob > 1 || plan_n > 0);
+      if (plan_n > 0) {      // the decision as the full stream-set would make it; the launch's own rows may then end in a ragged tile
+        ConvArgs full = p[q]; full.n = plan_n;
+        ok = shape_fits(s, full, nprob > 1) && shape_fits(s, p[q], true);
+      } else ok = shape_fits(s, p[q], nprob > 1);
       if (!ok) break;
       const int Tt = std::min(p[q].T, TM), wr = (TM / Tt) * (Tt + (p[q].ktaps - 1) * p[q].dil);
       if (wr > 32 * CL_NIT || (size_t)2 * 3 * wr * CL_LDB * 2 > 126 * 1024) { ok = false; break; }

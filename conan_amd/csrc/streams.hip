@@ -107,6 +107,17 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
       while (S > 1 && rem * S * TM * TN > sk_slab_floats) --S;
       if (S >= 2) { g.ksplit = S; g.split_from = (int)(tiles - rem); }
     }
+    // Tall tiles of a small-M x huge-K layer (ups.0 at 64 streams: M = 256 rows, K = 8192, N = 2048 - 67 MB of weights): a tile shape
+    // with few row tiles reads the weights few times (64-row tiles 4x, 32-row tiles 8x: 537 MB through the L2s per launch), but then
+    // has fewer tiles than CUs - EVERY tile is cut into S K-slices (split_from = 0) so that tiles * S fills the chip.
+    // (one factor for all tiles: a fixed-plan stream-set sizes it by max_slots)
+    const long long ptiles = (long long)((plan_n(a.n) * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
+    if (g.ksplit == 1 && ptiles * 2 <= cus_all && ptiles <= sk_max_tiles) {
+      int S = (int)std::min<long long>(8, cus_all / ptiles);
+      S = std::min(S, nks / 8);
+      while (S > 1 && ptiles * S * TM * TN > sk_slab_floats) --S;
+      if (S >= 2) { g.ksplit = S; g.split_from = 0; }
+    }
   }
   if (cnk::conv_cfg_tm(cfg) == 32) {
     // (grouped launches: one split factor for all problems, sized by the longest K loop)
