@@ -63,7 +63,10 @@ struct ConvLds {
   static constexpr int EPI_LD = 36;                 // epilogue transpose patch: 32 rows x 36 floats per compute wave
   static constexpr int PATCH = 4 * 32 * EPI_LD;
   static constexpr int RED = (WK > 1) ? (WK - 1) * TM * TN : 0;   // split-K partial tiles of waves wk > 0
-  static constexpr int TOTAL = STAGE + PATCH + RED + 4;   // + the split-K "reducer" flag
+  // (the split-K "reducer" flag lives in a padding column of the first epilogue patch - columns 32..35 of its 36-float rows are never
+  // touched: the 32 x 32 x K4 build is then 126 KB exactly, which a CU's 160 KB hold beside a 34 KB decoder workgroup)
+  static constexpr int FLAG = STAGE + 32;
+  static constexpr int TOTAL = STAGE + PATCH + RED;
 };
 
 // One output tile (rows m0.., columns n0..) of one problem.  `gbuf` is the LDS ring position of the tile's first
@@ -149,7 +152,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int m0, const
   // last-arriving block (ticket counter), in slice order, so the sum is reproducible
   const int ks_lo = SK ? (int)((long long)nks_all * kslice / nslices) : 0;
   const int nks = SK ? (int)((long long)nks_all * (kslice + 1) / nslices) - ks_lo : nks_all;
-  int* const sflag = reinterpret_cast<int*>(lds + L::STAGE + L::PATCH + L::RED);
+  int* const sflag = reinterpret_cast<int*>(lds + L::FLAG);
   auto block_barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
   };

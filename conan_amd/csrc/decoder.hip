@@ -126,6 +126,9 @@ bool conan_streams::run_mega(int n, int T, const int32_t* codes, float* mel_out,
         if (padded * mega_gs <= std::max(mega_grid, 64) && padded <= 32) e->groups = padded;
       }
       e->nops = (int)ops.size(); e->barriers = nb; e->flops = mega_rec_flops;
+      // (xcd mode, blocking steps: enough dynamic LDS that two workgroups do not share a CU - one per CU, ~32 on the elected XCD;
+      // pipelined steps launch with what the operators need, so that a vocoder workgroup fits beside a member: launch_mega)
+      e->lds_need = mega_rec_lds * 4;
       e->lds_bytes = e->xcd ? std::max(mega_rec_lds * 4, 84 * 1024) : mega_rec_lds * 4;
       // the arrival-counter barriers need every workgroup of the grid resident at once: never launch more than the device can hold
       // (a quarter of the CUs is kept as margin for what else is resident); such a step keeps its separate launches

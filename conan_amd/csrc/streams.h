@@ -256,6 +256,7 @@ struct conan_streams {
     long long key[6] = {0, 0, 0, 0, 0, 0};
     bool ok = false;
     int nops = 0, groups = 0, group_size = 0, njobs = 0, kw4 = 0, lds_bytes = 0, barriers = 0, n = 0, T = 0;
+    int lds_need = 0;                  // what the operators need (lds_bytes may be padded: xcd mode, blocking steps)
     bool xcd = false;                  // a single row tile: the launch's workgroups on ONE XCD form the group (decoder_mega.hip)
     double flops = 0.0;
     cnk::MegaOp* dev = nullptr;        // device copy (capacity kMegaMaxOps)

@@ -107,17 +107,9 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
       while (S > 1 && rem * S * TM * TN > sk_slab_floats) --S;
       if (S >= 2) { g.ksplit = S; g.split_from = (int)(tiles - rem); }
     }
-    // Tall tiles of a small-M x huge-K layer (ups.0 at 64 streams: M = 256 rows, K = 8192, N = 2048 - 67 MB of weights): a tile shape
-    // with few row tiles reads the weights few times (64-row tiles 4x, 32-row tiles 8x: 537 MB through the L2s per launch), but then
-    // has fewer tiles than CUs - EVERY tile is cut into S K-slices (split_from = 0) so that tiles * S fills the chip.
-    // (one factor for all tiles: a fixed-plan stream-set sizes it by max_slots)
-    const long long ptiles = (long long)((plan_n(a.n) * a.T + TM - 1) / TM) * ((a.Cout + TN - 1) / TN);
-    if (g.ksplit == 1 && ptiles * 2 <= cus_all && ptiles <= sk_max_tiles) {
-      int S = (int)std::min<long long>(8, cus_all / ptiles);
-      S = std::min(S, nks / 8);
-      while (S > 1 && ptiles * S * TM * TN > sk_slab_floats) --S;
-      if (S >= 2) { g.ksplit = S; g.split_from = 0; }
-    }
+    // (Tall tiles for small-M x huge-K layers - ups.0 at 64 streams as 64- or 128-row tiles with EVERY tile cut into K slices, so that
+    // the 67 MB of weights cross the L2s 4x or 2x instead of 8x - measured round 6: 91-92 us against 90-91 of the 32-row plan; the launch
+    // is bound by the f32 MFMA, not by the weight traffic.)
   }
   if (cnk::conv_cfg_tm(cfg) == 32) {
     // (grouped launches: one split factor for all problems, sized by the longest K loop)
@@ -287,7 +279,13 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   m.slots = d_slots; m.pos = pos_dec; m.n = e.n; m.T = e.T;
   m.gbar = mega_bar + 16; m.bar = mega_bar; m.bar_base = mega_bar_count; m.dbg = mega_dbg; m.guard = d_guard; m.wide_regs = rb_limb ? 1 : 0;
   m.xcd = e.xcd ? 1 : 0;
+  const bool pipelined = st_front != nullptr && st == st_front;
   if (e.xcd) {
+    // Pipelined single-tile steps: the group's members take only the LDS their operators need (34 KB), so that the small-batch vocoder's
+    // 126 KB conv_mfma workgroups find room beside them (round 5 launched 84 KB here as well: 32 blocks of every vocoder launch then
+    // waited for the decoder step to end, 0.635 against round 4's 0.52 ms per one-stream pipelined step).  Same program, same bits.
+    static const bool pad_always = ch::dev_getenv("CONAN_MEGA_XCD_PAD") != nullptr;
+    if (pipelined && !pad_always) m.lds_bytes = e.lds_need;
     mega_xseq = mega_xseq + 1u;       // (20 bits of it travel in the election word; consecutive launches differ)
     m.xs = mega_x; m.xseq = mega_xseq; m.xdec_base = mega_xdec;
     if (test_fault == 1) { m.xseq += 7u; mega_xseq += 7u; test_fault = 0; }     // test hook: the election word is not in the state this launch expects - nobody can claim
@@ -299,7 +297,13 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   mega_gseq = mega_gseq + 1u;             // (its own sequence: the xcd mode's election word tracks mega_xseq launch by launch)
   m.xs = mega_x; m.xseq = mega_gseq;      // (the flag barriers of groups that sit on one XCD count in epochs of this sequence number)
   { const bool nol2 = dev("MEGA_NOL2") != nullptr;
-    const bool mfast = dev("MEGA_LAYOUT") != nullptr && dev("MEGA_LAYOUT")[0] == 'm';
+    // Layout of the multi-tile launch's groups.  Blocking steps: group-fastest (a group on one XCD, hand-offs through its L2: 0.05 ms
+    // less latency).  PIPELINED steps: member-fastest (member s of every group on XCD s: strip s's weights stay in that XCD's L2 for
+    // all groups - 148 instead of 388 MB fetched per step; the hand-offs' extra 2-3 us are hidden behind the vocoder, the step
+    // time is the same).  Placement only: the operators and their summation orders are the same, pipelined == blocking bit for bit.
+    // MEGA_LAYOUT=m / g forces one form for both.
+    const char* lay = dev("MEGA_LAYOUT");
+    const bool mfast = lay ? lay[0] == 'm' : pipelined;
     m.xdec_base = (nol2 ? 1u : 0u) | (mfast ? 2u : 0u); }
   profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 3>" : "cnk::decoder_mega_kernel<6, 3>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);

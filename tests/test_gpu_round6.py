@@ -107,7 +107,9 @@ def test_conv_limb_ragged_tiles_with_several_slots_per_tile(S):
         assert torch.isfinite(wa).all()
         assert float((wa - wb).abs().max()) <= 2e-5, (p, float((wa - wb).abs().max()))
     names = kernels_of(a, lambda: a.hifigan_step(ids, mel[:, :2].contiguous()))
-    assert sum(n for k, n in names.items() if "conv_limb_kernel<4, 1, 1, 4>" in k) >= 6, sorted(names.items())
+    # (five of the stage's six grouped launches: the dilation-5 c1 launch's four-slot window - 4 x (16 + 50) rows - does not fit the
+    # kernel's two LDS buffers and takes conv_mfma)
+    assert sum(n for k, n in names.items() if "conv_limb_kernel<4, 1, 1, 4>" in k) >= 5, sorted(names.items())
     # the same set with only S - 1 and S - 2 slots active (other ragged remainders, entries past n that are live slots of the table)
     for n in (S - 1, S - 2):
         sub = ids[:n]
