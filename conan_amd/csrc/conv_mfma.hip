@@ -61,12 +61,13 @@ struct ConvLds {
   static constexpr int LDA = KS;
   static constexpr int STAGE = NBUF * (TM * LDA + KS * TN);
   static constexpr int EPI_LD = 36;                 // epilogue transpose patch: 32 rows x 36 floats per compute wave
-  static constexpr int PATCH = 4 * 32 * EPI_LD;
+  // (only the compute waves with wk == 0 run the epilogue - waves 0 .. 4 / WK - 1: the K-split builds need a patch per such wave, not
+  // per compute wave; the 32 x 32 x K4 build went from 126 to 112.5 KB, which leaves room for a single-tile decoder workgroup - 36.5 KB -
+  // on the same CU: small-batch pipelined steps)
+  static constexpr int PATCH = (4 / WK) * 32 * EPI_LD;
   static constexpr int RED = (WK > 1) ? (WK - 1) * TM * TN : 0;   // split-K partial tiles of waves wk > 0
-  // (the split-K "reducer" flag lives in a padding column of the first epilogue patch - columns 32..35 of its 36-float rows are never
-  // touched: the 32 x 32 x K4 build is then 126 KB exactly, which a CU's 160 KB hold beside a 34 KB decoder workgroup)
-  static constexpr int FLAG = STAGE + 32;
-  static constexpr int TOTAL = STAGE + PATCH + RED;
+  static constexpr int FLAG = STAGE + PATCH + RED;        // the split-K "reducer" flag
+  static constexpr int TOTAL = STAGE + PATCH + RED + 4;
 };
 
 // One output tile (rows m0.., columns n0..) of one problem.  `gbuf` is the LDS ring position of the tile's first

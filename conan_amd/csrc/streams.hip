@@ -303,7 +303,9 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
     // time is the same).  Placement only: the operators and their summation orders are the same, pipelined == blocking bit for bit.
     // MEGA_LAYOUT=m / g forces one form for both.
     const char* lay = dev("MEGA_LAYOUT");
-    const bool mfast = lay ? lay[0] == 'm' : pipelined;
+    // (from 8 row tiles - 32 streams - on: below that the decoder step is not hidden behind the vocoder's and its latency is the step's;
+    // 8 streams measured 0.634 against 0.553 ms per pipelined step with the member-fastest layout)
+    const bool mfast = lay ? lay[0] == 'm' : (pipelined && e.njobs >= 8);
     m.xdec_base = (nol2 ? 1u : 0u) | (mfast ? 2u : 0u); }
   profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 3>" : "cnk::decoder_mega_kernel<6, 3>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);

@@ -89,7 +89,7 @@ def test_fixed_plan_at_full_occupancy_runs_the_default_kernels():
     a.close(); b.close(); ctx.close()
 
 
-@pytest.mark.parametrize("S", [30, 17, 18, 33])
+@pytest.mark.parametrize("S", [30, 17, 33, 34, 45])
 def test_conv_limb_ragged_tiles_with_several_slots_per_tile(S):
     """40 ms chunks: 2 frames per step = 16 rows per slot in the C = 256 stage, so conv_limb's 64-row tiles hold FOUR slots and a
     ragged last tile stages up to three slots past the active count (the slot table carried one copy of the last
@@ -107,13 +107,18 @@ def test_conv_limb_ragged_tiles_with_several_slots_per_tile(S):
         assert torch.isfinite(wa).all()
         assert float((wa - wb).abs().max()) <= 2e-5, (p, float((wa - wb).abs().max()))
     names = kernels_of(a, lambda: a.hifigan_step(ids, mel[:, :2].contiguous()))
+    b.hifigan_step(ids, mel[:, :2].contiguous())            # (the same step for the other set: the two stay in the same state)
     # (five of the stage's six grouped launches: the dilation-5 c1 launch's four-slot window - 4 x (16 + 50) rows - does not fit the
     # kernel's two LDS buffers and takes conv_mfma)
-    assert sum(n for k, n in names.items() if "conv_limb_kernel<4, 1, 1, 4>" in k) >= 5, sorted(names.items())
+    # (17 / 18 slots of 16 rows are too few tiles for a third of the CUs: those sizes take conv_mfma here and are kept as the f32-plan
+    # cross-check of the same slot tables)
+    if S >= 30:
+        assert sum(n for k, n in names.items() if "conv_limb_kernel<4, 1, 1, 4>" in k) >= 5, sorted(names.items())
     # the same set with only S - 1 and S - 2 slots active (other ragged remainders, entries past n that are live slots of the table)
     for n in (S - 1, S - 2):
         sub = ids[:n]
-        wa, wb = a.hifigan_step(sub, mel[:n, :2].contiguous()), b.hifigan_step(sub, mel[:n, :2].contiguous())
+        x = mel[:n, :2].contiguous()
+        wa, wb = a.hifigan_step(sub, x), b.hifigan_step(sub, x)
         assert float((wa - wb).abs().max()) <= 2e-5
     a.close(); b.close(); ctx.close()
 
