@@ -6,7 +6,7 @@
 # the library's default arithmetic, workload_<arith> for an explicit one (the name bench.py looks its PMC summary up under).
 W=${1:-b64}
 A=${2:-auto}
-R=${ROUND:-r5}
+R=${ROUND:-r6}
 STEPS=${STEPS:-4}
 TAG=$W; if [ "$A" != "auto" ]; then TAG=${W}_$A; fi
 cd /tmp && export TMPDIR=/tmp

@@ -1,18 +1,19 @@
 # Round-end evidence on a MI355X box (run from the repo root through gpurun): GPU test log, the default bench line, one
 # bench line per BASELINE workload, then the rocprofv3 kernel stats + PMC passes of the default workload in both arithmetic
 # forms (tools/collect_profiles.sh).  Everything lands in gpurun_out/profiles_<round>/ with the names profiles/ uses.
-R=${R:-r5}; export ROUND=$R
+R=${R:-r6}; export ROUND=$R
 O=gpurun_out/profiles_$R; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q -rs 2>&1 | grep -v "amdgpu.ids" | tail -12 > $O/${R}_pytest_gpu.txt
 # the float64 error tables of both arithmetic forms (tests/test_gpu_arith.py prints them)
 timeout 900 python -m pytest tests/test_gpu_arith.py -q -s 2>&1 | grep -v "amdgpu.ids" > $O/${R}_arith_vs_f64.txt
-# per-operator stamps of the decoder megakernel alone, the stages alone against the pipelined step
-timeout 300 python tools/mega_probe.py 64 2>&1 | grep -v "amdgpu.ids" > $O/${R}_decoder_mega_stamps.txt
-# ... and of single-tile steps (xcd mode) at one and four streams, with the separate launches beside them
-for n in 1 4; do CONAN_MEGA_STAMPS=1 timeout 300 python tools/xcd_check.py $n 2>&1 | grep -v "amdgpu.ids" >> $O/${R}_decoder_xcd_stamps.txt; done
-# the one-launch vocoder step (opt-in) against the launch plans
-for n in 1 4; do timeout 300 python tools/chain_check.py $n 4 2>&1 | grep "slots" >> $O/${R}_voc_chain.txt; done
-bash tools/ab_round5.sh > $O/${R}_ab_l2_groups.txt 2>&1
+# (the per-operator stamps of the decoder megakernel - tools/mega_probe.py, tools/xcd_check.py - and the l2 / layout A/Bs of round 5 read
+# developer switches from the environment: `make DEV=1` builds only since ABI 8)
+# the default configuration at 1 .. 128 streams per GPU
+bash tools/stream_sweep.sh > $O/${R}_stream_sweep.txt 2>/dev/null
+# what CONAN_STREAMS_FIXED_PLAN costs at 64 of 64 slots active (alternating runs)
+for i in 1 2 3; do for F in "" "--fixed-plan"; do
+  timeout 600 python bench.py --no-cpu-baseline --no-other --no-b1 $F 2>/dev/null | grep '^{' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('fixed_plan=%s ms/step %.4f p50 %.3f vocoder alone %.3f' % (d['config']['fixed_plan'], d['ms_per_step'], d['p50_latency_ms'], d['roofline']['vocoder_alone_ms']))"
+done; done > $O/${R}_fixed_plan_cost.txt
 timeout 300 python tools/stage_times.py 64 2>&1 | grep -v "amdgpu.ids" | grep -v "^  op\|decoder_mega\]" > $O/${R}_stage_times.txt
 bash tools/collect_profiles.sh b64 auto > $O/collect_b64.log 2>&1       # first: the bench lines below read profiles/${R}_b64_pmc.json
 bash tools/collect_profiles.sh b64 f32 > $O/collect_b64_f32.log 2>&1
