@@ -99,9 +99,10 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     for (int it = 0; it < g.assign_per; ++it) {
       const int tile = __builtin_amdgcn_readfirstlane(*(gci)(mine + it));
       if (tile < 0) break;
-      const int q = tile_word(tile, 0), mt = tile_word(tile, 1);
+      const int q = tile_word(tile, 0), mt = tile_word(tile, 1), tw3 = tile_word(tile, 3);
       const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
       const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil, S = TM / Tt, wr = S * wrs;
+      const int ks = tw3 & 255, ns = (tw3 >> 8) & 255;            // K slice of a split tile: channel blocks [cb0, cb1)
       const int m0 = mt * TM, i0 = m0 / T, ta = m0 - i0 * T;
       const bool ring = CL_SEL(q, x.mode) == 0;
       const float* xb = CL_SEL(q, x.base);
@@ -129,19 +130,20 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
           loff[u] = w * CL_RS + c4 * 4;
         }
       }
-      const int nblk = Cin / 32;
+      const int nblk_all = Cin / 32;
+      const int cb0 = ns > 1 ? (nblk_all * ks) / ns : 0, cb1 = ns > 1 ? (nblk_all * (ks + 1)) / ns : nblk_all;
       // Software-pipelined: the loads of slice cb + 1 are issued BEFORE the barrier that publishes slice cb and land while the
       // matrix waves compute; behind the barrier the helper only converts and stores registers.  (Loading, converting and
       // storing a slice between two barriers put a global round trip - 2 us - on every channel block: 3-tap tiles ran as
       // long as 11-tap ones.)
       f32x4 v[CL_NIT];
 #ifdef CL_ABL_STAGE      // developer ablation: the helpers only keep the barriers
-      for (int cb = 0; cb < nblk; ++cb) { bar(); ++gslice; }
+      for (int cb = cb0; cb < cb1; ++cb) { bar(); ++gslice; }
       continue;
 #endif
 #pragma unroll
-      for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u]);
-      for (int cb = 0; cb < nblk; ++cb) {
+      for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + cb0 * 32);
+      for (int cb = cb0; cb < cb1; ++cb) {
         u16* dstb = lds + (gslice & 1) * 3 * plane;
 #pragma unroll
         for (int u = 0; u < CL_NIT; ++u) {
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
             *reinterpret_cast<uint2*>(d + 2 * PO) = make_uint2(l[0], l[1]);
           }
         }
-        if (cb + 1 < nblk) {
+        if (cb + 1 < cb1) {
 #pragma unroll
           for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + (cb + 1) * 32);
         }
@@ -181,14 +183,17 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
   for (int it = 0; it < g.assign_per; ++it) {
     const int tile = __builtin_amdgcn_readfirstlane(*(gci)(mine + it));
     if (tile < 0) break;
-    const int q = tile_word(tile, 0), mt = tile_word(tile, 1), nt = tile_word(tile, 2);
+    const int q = tile_word(tile, 0), mt = tile_word(tile, 1), nt = tile_word(tile, 2), tw3 = tile_word(tile, 3);
     const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
     const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil;
     const int m0 = mt * TM, n0 = nt * TN;
-    const int nblk = Cin / 32, NB = nblk * k;
+    const int ks = tw3 & 255, ns = (tw3 >> 8) & 255, split_idx = tw3 >> 16;      // K slice of a split tile (ns <= 1: the whole K range)
+    const int nblk_all = Cin / 32;
+    const int cb0 = ns > 1 ? (nblk_all * ks) / ns : 0, cb1 = ns > 1 ? (nblk_all * (ks + 1)) / ns : nblk_all;
+    const int NB = (cb1 - cb0) * k;
     const int ct0 = n0 / 16 + wc * NCW;
-    const long long ct_stride = (long long)NB * 1536;            // elements per column tile
-    const u16* wl = CL_SEL(q, wl) + (long long)ct0 * ct_stride + lane * 8;
+    const long long ct_stride = (long long)nblk_all * k * 1536;  // elements per column tile
+    const u16* wl = CL_SEL(q, wl) + (long long)ct0 * ct_stride + (long long)cb0 * k * 1536 + lane * 8;
     // this lane's row of each of the wave's row tiles: window row of tap 0
     int abase[NRW];
 #pragma unroll
@@ -343,8 +348,49 @@ __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g
     (void)st_bar0;
     const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
+    // ---------------- split-K tail: the slices' partial tiles meet in memory.  No workgroup barrier (the helper waves are already
+    // staging the next tile behind the K loop's barriers): every matrix wave hands over ITS sub-tile on its own - agent-scope
+    // write-through stores, s_waitcnt, a ticket per (split tile, wave); the wave that draws the last ticket loads all slices' partials
+    // of that sub-tile with sc1 loads, sums them IN SLICE ORDER (its own from memory too: bit-reproducible whoever is last) and runs the
+    // epilogue.  The protocol of conv_mfma's split-K hand-off, per wave; no fence, nothing invalidates an L2.
+    bool run_epi = true;
+    if (ns > 1) {
+      float* const part = g.slab + (long long)split_idx * ns * (TM * TN) + (long long)wave * (NRW * NCW * 256);
+      float* const mine = part + (long long)ks * (TM * TN);
+#pragma unroll
+      for (int r = 0; r < NRW; ++r)
+#pragma unroll
+        for (int c = 0; c < NCW; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) __hip_atomic_store(mine + ((r * NCW + c) * 4 + e) * 64 + lane, acc[r][c][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int* const ctr = g.counters + split_idx * 4 + wave;
+      int ticket = 0;
+      if (lane == 0) ticket = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      run_epi = ticket == ns - 1;
+      if (run_epi) {
+        if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+#pragma unroll
+        for (int r = 0; r < NRW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < ns; ++s2) {
+          const float* src = part + (long long)s2 * (TM * TN);
+          float pv[NRW * NCW * 4];
+#pragma unroll
+          for (int f = 0; f < NRW * NCW * 4; ++f) pv[f] = __hip_atomic_load(src + f * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int r = 0; r < NRW; ++r)
+#pragma unroll
+            for (int c = 0; c < NCW; ++c)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[r][c][e] += pv[(r * NCW + c) * 4 + e];
+        }
+      }
+    }
     // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
-    {
+    if (run_epi) {
 
       const int oact = CL_SEL(q, out_act);
       const float oslope = CL_SEL(q, out_slope);
@@ -472,11 +518,25 @@ bool conv_limb_supported(const ConvArgs& a) {
   return true;
 }
 
+// Split-K tail of a single problem: with tiles = q * CUs + rem (rem > 0, q >= 1) the last rem tiles are cut into S K slices over
+// their channel blocks, rem * S <= CUs, so that every CU gets q + 1 / S tiles of MFMA work instead of rem CUs getting one tile more
+// (ups.1 at 64 streams: 320 tiles of 64 x 64 on 256 CUs - two rounds for 1.25 rounds of work).  -> S (1: no split)
+static int tail_slices(const ConvArgs& a, const CLShape& s, int num_cu) {
+  const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
+  const long long tiles = (((long long)a.n * a.T + TM - 1) / TM) * ((((a.Cout + 15) / 16) * 16) / TN);
+  const long long rem = tiles % num_cu;
+  if (tiles <= num_cu || rem == 0) return 1;
+  int S = (int)std::min<long long>(8, num_cu / rem);
+  S = std::min(S, a.Cin / 32);                                   // at least one channel block per slice
+  return S < 2 ? 1 : S;
+}
+int conv_limb_tail_slices(const ConvArgs& a, int shape, int num_cu) { return shape >= 0 && shape < kNumShapes ? tail_slices(a, kShapes[shape], num_cu) : 1; }
+
 // tile shape index for a group of problems (same n, T and column count), or -1: the shape with the smallest estimated
 // makespan among those that fit and give every CU a tile
 // plan_n > 0 (fixed-plan stream-sets): tile counts, the fill-the-chip thresholds and the cost model use plan_n slots instead of the
 // launch's own, and the launch's own last tile may be ragged where the full set's is not - the choice must not depend on the active slots
-int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n) {
+int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n, bool tail_split) {
   static const int forced = (dev_getenv("CONAN_CL_SHAPE") && *dev_getenv("CONAN_CL_SHAPE")) ? atoi(dev_getenv("CONAN_CL_SHAPE")) : -1;      // developer switch
   int best = -1; double best_cost = 1e30;
   for (int si = 0; si < kNumShapes; ++si) {
@@ -504,11 +564,13 @@ int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n) {
     if (!ok || tiles * (nprob > 1 ? 3 : 2) < num_cu) continue;
     // (a single problem in 64-row tiles - ups.1: 320 tiles, two rounds - measured slower than conv_mfma's f32 pass with its
     // split-K tail, 78 against 72 us; groups of problems are list-scheduled and take them)
-    if (nprob == 1 && TM < 80 && forced < 0) continue;
+    // ... unless the launch may split the K range of its tail tiles (round 6): 1.25 rounds then cost 1 + 1 / S
+    const int tailS = (nprob == 1 && tail_split && plan_n == 0) ? tail_slices(p[0], s, num_cu) : 1;
+    if (nprob == 1 && TM < 80 && forced < 0 && tailS < 2) continue;
     if (forced >= 0) { if (si == forced) return si; continue; }
     // equal tiles run in rounds; tiles of several costs are list-scheduled (at least the largest one, at least the average)
     const double rounds = std::ceil((double)tiles / num_cu);
-    const double makespan = nprob == 1 ? rounds * umax : std::max(units / num_cu, umax);
+    const double makespan = nprob == 1 ? (tailS >= 2 ? (double)(tiles / num_cu) + 1.0 / tailS + 0.1 : rounds) * umax : std::max(units / num_cu, umax);
     const double cost = makespan * (s.CW == 4 ? 1.0 : 1.05);     // shared column tiles: redundant weight loads
     if (cost < best_cost) { best_cost = cost; best = si; }
   }
@@ -528,8 +590,8 @@ size_t conv_limb_lds_bytes(const ConvArgs* p, int nprob, int shape, int* wr_max_
 }
 
 // Balanced tile lists per launch shape, cached in device memory (a handful per model and device, never freed).
-static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) {
-  struct Key { int v[16]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
+static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out, int tailS) {
+  struct Key { int v[17]; bool operator<(const Key& o) const { return memcmp(v, o.v, sizeof(v)) < 0; } };
   struct Val { const int* tiles; const int* assign; int per, grid; };
   static std::map<Key, Val> cache;
   static std::mutex mu;
@@ -537,22 +599,50 @@ static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) 
   int dev = 0;
   (void)hipGetDevice(&dev);
   Key key; memset(&key, 0, sizeof(key));
-  key.v[0] = shape; key.v[1] = num_cu; key.v[2] = dev; key.v[3] = g.nprob;
+  key.v[0] = shape; key.v[1] = num_cu; key.v[2] = dev; key.v[3] = g.nprob; key.v[16] = tailS;
   for (int q = 0; q < g.nprob; ++q) { key.v[4 + 4 * q] = g.p[q].n; key.v[5 + 4 * q] = g.p[q].T; key.v[6 + 4 * q] = g.p[q].Cout; key.v[7 + 4 * q] = g.p[q].ktaps * 4096 + g.p[q].Cin; }
   auto it = cache.find(key);
   if (it == cache.end()) {
     const CLShape& s = kShapes[shape];
     const int TM = 16 * s.NRW * s.RW, TN = 16 * s.NCW * s.CW;
-    struct Tl { int q, mt, nt; double cost; };
+    struct Tl { int q, mt, nt, w3; double cost; };
     std::vector<Tl> tl;
     for (int q = 0; q < g.nprob; ++q) {
       const int mts = (int)(((long long)g.p[q].n * g.p[q].T + TM - 1) / TM), nts = (((g.p[q].Cout + 15) / 16) * 16) / TN;
       // n-tile outermost: workgroups that run at the same time then share their weight columns' rows ... the m tiles of one
       // n tile are adjacent in the list
+      // (split tail - a single problem: the last tiles % CUs tiles of this order are items of tailS K slices each)
+      const long long total = (long long)mts * nts, first_split = tailS >= 2 ? total - total % num_cu : total;
+      long long idx = 0;
       for (int nt = 0; nt < nts; ++nt)
-        for (int mt = 0; mt < mts; ++mt) tl.push_back({q, mt, nt, (double)g.p[q].ktaps * g.p[q].Cin});
+        for (int mt = 0; mt < mts; ++mt, ++idx) {
+          const double cost = (double)g.p[q].ktaps * g.p[q].Cin;
+          if (idx < first_split) tl.push_back({q, mt, nt, 0, cost});
+          else for (int ks = 0; ks < tailS; ++ks) tl.push_back({q, mt, nt, ks | (tailS << 8) | ((int)(idx - first_split) << 16), cost / tailS + 0.02 * cost});
+        }
     }
-    std::stable_sort(tl.begin(), tl.end(), [](const Tl& a, const Tl& b) { return a.cost > b.cost; });
+    // XCD of every item.  With a multiple of 8 n tiles (or fewer than 8) the rule below keeps an n tile's m tiles on one XCD (or on
+    // 8 / nts of them).  Otherwise - ups.1: 10 n tiles - "n tile % 8" gives two XCDs twice the work of the others (two rounds for 1.25
+    // rounds of tiles, and a split tail that lands on those two XCDs again): the items, in (n tile, m tile) order, are cut into eight
+    // runs of equal cost instead - an n tile's weight columns are then shared by one or two XCDs.
+    std::vector<int> xcd_of(tl.size(), -1);
+    {
+      bool by_cost = tailS >= 2;
+      for (int q = 0; q < g.nprob; ++q) { const int nts = (((g.p[q].Cout + 15) / 16) * 16) / TN; by_cost = by_cost || (nts > 8 && nts % 8 != 0); }
+      if (by_cost) {
+        double total = 0, cum = 0;
+        for (auto& t : tl) total += t.cost;
+        for (size_t e = 0; e < tl.size(); ++e) { xcd_of[e] = std::min(7, (int)(cum * 8.0 / total)); cum += tl[e].cost; }
+      }
+    }
+    {      // (sort items by cost, longest first, carrying their XCD along)
+      std::vector<size_t> ord(tl.size());
+      for (size_t e = 0; e < ord.size(); ++e) ord[e] = e;
+      std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return tl[a].cost > tl[b].cost; });
+      std::vector<Tl> tl2(tl.size()); std::vector<int> x2(tl.size());
+      for (size_t e = 0; e < ord.size(); ++e) { tl2[e] = tl[ord[e]]; x2[e] = xcd_of[ord[e]]; }
+      tl.swap(tl2); xcd_of.swap(x2);
+    }
     const int grid = (int)std::min<size_t>(tl.size(), (size_t)num_cu);
     std::vector<std::vector<int>> per(grid);
     std::vector<double> load(grid, 0.0);
@@ -563,6 +653,7 @@ static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) 
       const int nts = (((g.p[tl[e].q].Cout + 15) / 16) * 16) / TN;
       int x = tl[e].nt % 8;
       if (nts < 8) { const int share = 8 / nts; x = (tl[e].nt + nts * (tl[e].mt % share)) % 8; }
+      if (xcd_of[e] >= 0) x = xcd_of[e];
       if (grid < 8) x = 0;
       int b = -1;
       for (int c = x; c < grid; c += (grid < 8 ? 1 : 8)) if (b < 0 || load[c] < load[b]) b = c;
@@ -573,7 +664,7 @@ static bool cl_schedule(ConvLimbGroup& g, int shape, int num_cu, int* grid_out) 
     for (auto& v : per) mx = std::max(mx, v.size());
     const int ap = (int)mx + 1;
     std::vector<int> flat(tl.size() * 4), asg((size_t)grid * ap, -1);
-    for (size_t e = 0; e < tl.size(); ++e) { flat[e * 4] = tl[e].q; flat[e * 4 + 1] = tl[e].mt; flat[e * 4 + 2] = tl[e].nt; flat[e * 4 + 3] = 0; }
+    for (size_t e = 0; e < tl.size(); ++e) { flat[e * 4] = tl[e].q; flat[e * 4 + 1] = tl[e].mt; flat[e * 4 + 2] = tl[e].nt; flat[e * 4 + 3] = tl[e].w3; }
     for (int b = 0; b < grid; ++b) for (size_t i2 = 0; i2 < per[b].size(); ++i2) asg[(size_t)b * ap + i2] = per[b][i2];
     int *dt = nullptr, *da = nullptr;
     if (hipMalloc(&dt, flat.size() * sizeof(int)) != hipSuccess || hipMalloc(&da, asg.size() * sizeof(int)) != hipSuccess) return false;
@@ -591,7 +682,15 @@ bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream
   if (shape < 0 || shape >= kNumShapes || g.nprob < 1 || g.nprob > 3) return false;
   const size_t lds = conv_limb_lds_bytes(g.p, g.nprob, shape, &g.wr_max);
   int grid = 0;
-  if (!cl_schedule(g, shape, num_cu, &grid) || grid <= 0) return false;
+  // the split tail: where the caller gave the launch a slab and tickets, and they are large enough
+  int tailS = (g.nprob == 1 && g.slab && g.counters) ? tail_slices(g.p[0], kShapes[shape], num_cu) : 1;
+  if (tailS >= 2) {
+    const int TM = 16 * kShapes[shape].NRW * kShapes[shape].RW, TN = 16 * kShapes[shape].NCW * kShapes[shape].CW;
+    const long long tiles = (((long long)g.p[0].n * g.p[0].T + TM - 1) / TM) * ((((g.p[0].Cout + 15) / 16) * 16) / TN), rem = tiles % num_cu;
+    if (rem * tailS * TM * TN > g.slab_floats || rem * 4 > g.max_counters || rem >= 65536) tailS = 1;
+  }
+  if (tailS < 2) { g.slab = nullptr; g.counters = nullptr; }
+  if (!cl_schedule(g, shape, num_cu, &grid, tailS) || grid <= 0) return false;
   switch (shape) {
     case 0: launch_cl<4, 1, 1, 4>(g, grid, lds, st); break;
     case 1: launch_cl<5, 1, 1, 4>(g, grid, lds, st); break;

@@ -162,14 +162,20 @@ void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num
 struct ConvLimbGroup {
   ConvArgs p[3];        // problems with the same n, T and column count (different taps / dilations / tensors)
   int nprob;
-  const int* tiles;     // filled by launch_conv_limb: [ntiles] {problem, m tile, n tile, 0}
-  const int* assign;    // [grid][assign_per] tile indices per block, -1 terminated
+  const int* tiles;     // filled by launch_conv_limb: [items] {problem, m tile, n tile, K slice | slices << 8 | split-tile index << 16}
+  const int* assign;    // [grid][assign_per] item indices per block, -1 terminated
   int assign_per;
   int wr_max;           // window rows of the largest problem's tile
+  // split-K tail (a single problem whose tile count is not a multiple of the CU count - ups.1: 320 tiles on 256 CUs): the last
+  // tiles % CUs tiles are cut into K slices over their channel blocks; partial tiles meet in `slab` ([split tile][slice][TM x TN]),
+  // one ticket per (split tile, matrix wave) in `counters` (zero before and after every launch); nullptr: no split
+  float* slab; int* counters;
+  long long slab_floats; int max_counters;
 };
 bool conv_limb_supported(const ConvArgs& a);
-int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n = 0);      // tile shape for these problems, -1: none fits (plan_n: conv_limb.hip)
+int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n = 0, bool tail_split = false);      // tile shape for these problems, -1: none fits (plan_n: conv_limb.hip)
 bool launch_conv_limb(const ConvLimbGroup& g, int shape, int num_cu, hipStream_t st);
+int conv_limb_tail_slices(const ConvArgs& a, int shape, int num_cu);      // K slices of the split tail this launch would run with (1: none)
 const char* conv_limb_name(int shape);
 
 // One ResBlock1 unit (hifigan_causal.py:230-238) as ONE tile pass (resblock_fused.hip):

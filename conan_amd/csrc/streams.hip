@@ -63,11 +63,17 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
     bool ok = true;
     for (int p = 0; p < nprob; ++p) ok = ok && cnk::conv_limb_supported(gin.p[p]) && gin.p[p].n == gin.p[0].n && gin.p[p].T == gin.p[0].T && gin.p[p].Cout == gin.p[0].Cout;
     const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
-    const int shape = ok ? cnk::conv_limb_shape(gin.p, nprob, cus, fixed_plan ? plan_n(gin.p[0].n) : 0) : -1;
+    // (a single problem may split the K range of its tail tiles - conv_limb.hip; not in a fixed-plan stream-set: which tiles are the
+    // tail follows a slot's position in the active list)
+    const int shape = ok ? cnk::conv_limb_shape(gin.p, nprob, cus, fixed_plan ? plan_n(gin.p[0].n) : 0, !fixed_plan) : -1;
     if (shape >= 0) {
       cnk::ConvLimbGroup lg; memset(&lg, 0, sizeof(lg));
       for (int p = 0; p < nprob; ++p) lg.p[p] = gin.p[p];
       lg.nprob = nprob;
+      if (!fixed_plan && nprob == 1) {
+        const int wsi = ws_index(st);
+        lg.slab = sk_slab[wsi]; lg.counters = sk_counters[wsi]; lg.slab_floats = sk_slab_floats; lg.max_counters = sk_max_tiles;
+      }
       double fl = 0.0;
       for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)lg.p[p].n * lg.p[p].T * lg.p[p].Cout * lg.p[p].ktaps * lg.p[p].Cin;
       profiled(cnk::conv_limb_name(shape), fl, st, [&] {
