@@ -303,15 +303,16 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   mega_gseq = mega_gseq + 1u;             // (its own sequence: the xcd mode's election word tracks mega_xseq launch by launch)
   m.xs = mega_x; m.xseq = mega_gseq;      // (the flag barriers of groups that sit on one XCD count in epochs of this sequence number)
   { const bool nol2 = dev("MEGA_NOL2") != nullptr;
-    // Layout of the multi-tile launch's groups.  Blocking steps: group-fastest (a group on one XCD, hand-offs through its L2: 0.05 ms
-    // less latency).  PIPELINED steps: member-fastest (member s of every group on XCD s: strip s's weights stay in that XCD's L2 for
-    // all groups - 148 instead of 388 MB fetched per step; the hand-offs' extra 2-3 us are hidden behind the vocoder, the step
-    // time is the same).  Placement only: the operators and their summation orders are the same, pipelined == blocking bit for bit.
-    // MEGA_LAYOUT=m / g forces one form for both.
+    // Layout of the multi-tile launch's groups: group-fastest (a group on one XCD, hand-offs through its L2) for every step.
+    // Member-fastest (member s of every group on XCD s: strip s's weights stay in that XCD's L2 for all groups - 159 instead of
+    // 387 MB fetched per step, profiles/r6_*) for PIPELINED steps was tried in round 6 as VERDICT round 5 asked: the step time is the
+    // same (1.3958 against 1.3984 ms, three alternating runs), the bits are the same - and with two stream-sets overlapping on the
+    // device (tests/test_gpu_stress.py, 128 streams, f32) the pair kernel's bounded partner wait gave up in 3 of 8 runs and one run
+    // ended in a GPU memory fault, against 0 of 16 with this layout (tools/stress_repro.py; profiles/r6_stress_layout.txt).  The
+    // bytes are not worth a launch shape whose forward progress beside other waiting launches is not understood: MEGA_LAYOUT=m
+    // stays a developer switch.
     const char* lay = dev("MEGA_LAYOUT");
-    // (from 8 row tiles - 32 streams - on: below that the decoder step is not hidden behind the vocoder's and its latency is the step's;
-    // 8 streams measured 0.634 against 0.553 ms per pipelined step with the member-fastest layout)
-    const bool mfast = lay ? lay[0] == 'm' : (pipelined && e.njobs >= 8);
+    const bool mfast = lay && lay[0] == 'm';
     m.xdec_base = (nol2 ? 1u : 0u) | (mfast ? 2u : 0u); }
   profiled(rb_limb ? "cnk::decoder_mega_kernel<4, 3>" : "cnk::decoder_mega_kernel<6, 3>", e.flops, st, [&] { cnk::launch_decoder_mega(m, st); });
   mega_bar_count += (unsigned)(e.groups * e.group_size);
