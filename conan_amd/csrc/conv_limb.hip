@@ -77,380 +77,17 @@ __device__ unsigned long long cl_dbg2[256 * 4];      // {cycles before the first
 
 #define CL_SEL(q_, f) ((q_) == 0 ? g.p[0].f : ((q_) == 1 ? g.p[1].f : g.p[2].f))
 
+// SK: the build with the split-K tail (conv_limb_sk_kernel; the hand-over costs the <5,1,1,4> shape two registers over its 192-register
+// budget beside the decoder, so the launches without a tail run the build without it)
 template <int NRW, int NCW, int RW, int CW>
 __global__ __launch_bounds__(512, 2) void conv_limb_kernel(const ConvLimbGroup g) {
-  static_assert(RW * CW == 4, "four matrix waves");
-  constexpr int TM = 16 * NRW * RW, TN = 16 * NCW * CW;
-  extern __shared__ __attribute__((aligned(16))) u16 lds[];      // [2 buffers][wr_max][3 planes][CL_LDB]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int plane = g.wr_max * CL_LDB;                           // elements per buffer / 3
-  constexpr int PO = CL_LDB;                                     // plane offset inside a row
-  auto bar = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  auto tile_word = [&](int idx, int w) __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*(gci)(g.tiles + (long long)idx * 4 + w)); };
-  // this block's tiles: assign[b * per + i] until -1 (host-balanced)
-  const int* mine = g.assign + (long long)blockIdx.x * g.assign_per;
-  int gslice = 0;                                                // slices staged / consumed so far (buffer = parity)
-
-  if (wave >= 4) {
-    // ============================================================ helper waves: window slices
-    const int ht = tid - 256;
-    __builtin_amdgcn_s_setprio(3);
-    for (int it = 0; it < g.assign_per; ++it) {
-      const int tile = __builtin_amdgcn_readfirstlane(*(gci)(mine + it));
-      if (tile < 0) break;
-      const int q = tile_word(tile, 0), mt = tile_word(tile, 1), tw3 = tile_word(tile, 3);
-      const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
-      const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil, S = TM / Tt, wr = S * wrs;
-      const int ks = tw3 & 255, ns = (tw3 >> 8) & 255;            // K slice of a split tile: channel blocks [cb0, cb1)
-      const int m0 = mt * TM, i0 = m0 / T, ta = m0 - i0 * T;
-      const bool ring = CL_SEL(q, x.mode) == 0;
-      const float* xb = CL_SEL(q, x.base);
-      const int xC = CL_SEL(q, x.C), xmask = ring ? CL_SEL(q, x.lmask) : -1, xrate = CL_SEL(q, x.rate), xoff = CL_SEL(q, x.off) - CL_SEL(q, pad_left);
-      const long long xss = CL_SEL(q, x.slot_stride);
-      const int* slots = CL_SEL(q, slots);
-      const int* pos = CL_SEL(q, pos);
-      const bool act = CL_SEL(q, in_act) == ACT_LRELU;
-      const float slope = CL_SEL(q, in_slope);
-      const float act_slope = act ? slope : 1.f;
-      // per thread: the rows it stages (window row w = idx / 8, 4-channel group idx % 8), as float offsets from xb
-      int roff[CL_NIT], loff[CL_NIT];
-      const int total = wr * 8;
-#pragma unroll
-      for (int u = 0; u < CL_NIT; ++u) {
-        const int idx = ht + 256 * u;
-        roff[u] = -1; loff[u] = 0;
-        if (idx < total) {
-          const int w = idx >> 3, c4 = idx & 7, s = w / wrs, o = w - s * wrs;
-          // (a last tile with fewer slots than it has room for reads slot-table entries n .. n + TM / T - 2: the host keeps
-          // kSlotTablePad copies of the last slot there, conan_streams::set_slots)
-          const int i = i0 + s, slot = slots ? *(gci)(slots + i) : i, pv = (ring && pos) ? *(gci)(pos + slot) : 0;
-          const int row = ((ring ? pv * xrate : 0) + xoff + ta + o) & xmask;
-          roff[u] = (int)((long long)(ring ? slot : i) * xss) + row * xC + c4 * 4;
-          loff[u] = w * CL_RS + c4 * 4;
-        }
-      }
-      const int nblk_all = Cin / 32;
-      const int cb0 = ns > 1 ? (nblk_all * ks) / ns : 0, cb1 = ns > 1 ? (nblk_all * (ks + 1)) / ns : nblk_all;
-      // Software-pipelined: the loads of slice cb + 1 are issued BEFORE the barrier that publishes slice cb and land while the
-      // matrix waves compute; behind the barrier the helper only converts and stores registers.  (Loading, converting and
-      // storing a slice between two barriers put a global round trip - 2 us - on every channel block: 3-tap tiles ran as
-      // long as 11-tap ones.)
-      f32x4 v[CL_NIT];
-#ifdef CL_ABL_STAGE      // developer ablation: the helpers only keep the barriers
-      for (int cb = cb0; cb < cb1; ++cb) { bar(); ++gslice; }
-      continue;
-#endif
-#pragma unroll
-      for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + cb0 * 32);
-      for (int cb = cb0; cb < cb1; ++cb) {
-        u16* dstb = lds + (gslice & 1) * 3 * plane;
-#pragma unroll
-        for (int u = 0; u < CL_NIT; ++u) {
-          if (roff[u] >= 0) {
-            unsigned h[2], m[2], l[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              f32x2 s = {v[u][2 * e], v[u][2 * e + 1]};
-              // (LeakyReLU with 0 < slope < 1 as max(x, slope * x): the same bits as x > 0 ? x : x * slope; act_slope is 1 without it)
-              const f32x2 sx = s * act_slope;
-              s = (f32x2){__builtin_fmaxf(s[0], sx[0]), __builtin_fmaxf(s[1], sx[1])};
-              cl_split2(s, h[e], m[e], l[e]);
-            }
-            u16* d = dstb + loff[u];
-            *reinterpret_cast<uint2*>(d) = make_uint2(h[0], h[1]);
-            *reinterpret_cast<uint2*>(d + PO) = make_uint2(m[0], m[1]);
-            *reinterpret_cast<uint2*>(d + 2 * PO) = make_uint2(l[0], l[1]);
-          }
-        }
-        if (cb + 1 < cb1) {
-#pragma unroll
-          for (int u = 0; u < CL_NIT; ++u) if (roff[u] >= 0) v[u] = cl_gload(xb + roff[u] + (cb + 1) * 32);
-        }
-        bar();                                                   // slice staged (and the matrix waves are done with the other buffer)
-        ++gslice;
-      }
-    }
-    return;
-  }
-
-  // ============================================================== matrix waves
-#ifdef CL_STAMPS
-  unsigned long long st_bar = 0, st_loop = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime(), st_pro = 0, st_epi = 0, st_fb = 0, st_tiles = 0;
-#endif
-  const int wr_ = wave / CW, wc = wave % CW;
-  const int lr = lane & 15, lg = lane >> 4;
-  for (int it = 0; it < g.assign_per; ++it) {
-    const int tile = __builtin_amdgcn_readfirstlane(*(gci)(mine + it));
-    if (tile < 0) break;
-    const int q = tile_word(tile, 0), mt = tile_word(tile, 1), nt = tile_word(tile, 2), tw3 = tile_word(tile, 3);
-    const int T = CL_SEL(q, T), k = CL_SEL(q, ktaps), dil = CL_SEL(q, dil), Cin = CL_SEL(q, Cin);
-    const int Tt = T < TM ? T : TM, wrs = Tt + (k - 1) * dil;
-    const int m0 = mt * TM, n0 = nt * TN;
-    const int ks = tw3 & 255, ns = (tw3 >> 8) & 255, split_idx = tw3 >> 16;      // K slice of a split tile (ns <= 1: the whole K range)
-    const int nblk_all = Cin / 32;
-    const int cb0 = ns > 1 ? (nblk_all * ks) / ns : 0, cb1 = ns > 1 ? (nblk_all * (ks + 1)) / ns : nblk_all;
-    const int NB = (cb1 - cb0) * k;
-    const int ct0 = n0 / 16 + wc * NCW;
-    const long long ct_stride = (long long)nblk_all * k * 1536;  // elements per column tile
-    const u16* wl = CL_SEL(q, wl) + (long long)ct0 * ct_stride + (long long)cb0 * k * 1536 + lane * 8;
-    // this lane's row of each of the wave's row tiles: window row of tap 0
-    int abase[NRW];
-#pragma unroll
-    for (int r = 0; r < NRW; ++r) {
-      const int row = (wr_ * NRW + r) * 16 + lr, s = row / Tt, tl = row - s * Tt;
-      abase[r] = (s * wrs + tl) * CL_RS + 8 * lg;
-    }
-    f32x4 acc[NRW][NCW];
-#pragma unroll
-    for (int r = 0; r < NRW; ++r)
-#pragma unroll
-      for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the epilogue's rows: slot and frame counter of this lane's row of every row tile - two dependent loads, issued now so that
-    // they are long back when the K loop ends (in the epilogue they were 2 us per tile with nothing to overlap them)
-    int eslot[NRW], epos[NRW];
-    {
-      const int* slots = CL_SEL(q, slots);
-      const int* pos = CL_SEL(q, pos);
-#pragma unroll
-      for (int r = 0; r < NRW; ++r) {
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T;      // (rows past the launch's last slot - slot-table entry n, a copy of the last one: computed, never stored)
-        eslot[r] = slots ? *(gci)(slots + i) : i;
-      }
-#pragma unroll
-      for (int r = 0; r < NRW; ++r) {
-        // (a row past the launch's last slot - a ragged last tile - carries the sign bit in its frame counter: ring rows are masked, so
-        // every address formed from it stays in bounds, and the epilogue stores nothing for it.  No register of its own: this build is
-        // at its 192-register budget beside the decoder megakernel.)
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr;
-        epos[r] = (pos ? *(gci)(pos + eslot[r]) : 0) | (m / T < CL_SEL(q, n) ? 0 : (int)0x80000000);
-      }
-    }
-    // weight blocks in flight: four with one column tile per wave (a block is 6 * NRW MFMAs = 0.2 us of work there - two blocks
-    // ahead is less than an L2 round trip under load), two with two
-    constexpr int RING = NCW == 1 ? CL_RING1 : 2;
-    f32x4 bw[RING][NCW][3];
-#pragma unroll
-    for (int s = 0; s < RING; ++s)
-#pragma unroll
-      for (int c = 0; c < NCW; ++c)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bw[s][c][p] = cl_gload(wl + (s < NB ? s : 0) * 1536 + c * ct_stride + p * 512);
-    f32x4 af[NRW][3];
-    int j = 0;                                                   // tap of block gb
-    const u16* buf = lds;
-    const int dstep = dil * CL_RS;
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-    auto step = [&](const int gb, auto slot_c) __attribute__((always_inline)) {
-      constexpr int SL = decltype(slot_c)::value;
-      if (j == 0) {                                              // first tap of a channel block: its window slice
-#ifdef CL_STAMPS
-        { const unsigned long long q0 = __builtin_amdgcn_s_memtime(); bar(); st_bar += __builtin_amdgcn_s_memtime() - q0; }
-#else
-        bar();
-#endif
-        buf = lds + (gslice & 1) * 3 * plane;
-        ++gslice;
-#pragma unroll
-        for (int r = 0; r < NRW; ++r)
-#pragma unroll
-          for (int p = 0; p < 3; ++p) af[r][p] = *reinterpret_cast<const f32x4*>(buf + abase[r] + p * PO);
-      }
-      const bool more = j + 1 < k;                               // the next tap reads the same slice, dil rows further
-      const u16* anext = buf + (more ? (j + 1) * dstep : 0);
-#pragma unroll
-      for (int s = 0; s < 6; ++s)
-#pragma unroll
-        for (int r = 0; r < NRW; ++r) {
-#pragma unroll
-          for (int c = 0; c < NCW; ++c)
-            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[SL][c][PB[s]]), __builtin_bit_cast(bf16x8, af[r][PA[s]]), acc[r][c], 0, 0, 0);
-#ifndef CL_ABL_A      // (developer ablation: no A re-reads)
-          if (s == 0) af[r][2] = *reinterpret_cast<const f32x4*>(anext + abase[r] + 2 * PO);
-          if (s == 3) af[r][1] = *reinterpret_cast<const f32x4*>(anext + abase[r] + PO);
-          if (s == 5) af[r][0] = *reinterpret_cast<const f32x4*>(anext + abase[r]);
-#endif
-        }
-#ifdef CL_ABL_W
-      const int gn = 0;                                          // developer ablation: every weight block from the stream's start (L1 hits)
-#else
-      const int gn = gb + RING < NB ? gb + RING : 0;             // (past the last block: block 0 again, unused)
-#endif
-#pragma unroll
-      for (int c = 0; c < NCW; ++c)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) bw[SL][c][p] = cl_gload(wl + (long long)gn * 1536 + c * ct_stride + p * 512);
-#pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        if (s == 0 || s == 3 || s == 5) {
-#pragma unroll
-          for (int r = 0; r < NRW; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NCW, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, NRW * NCW, 0);
-        }
-      }
-      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NCW, 0);
-      j = more ? j + 1 : 0;
-    };
-#ifdef CL_STAMPS
-    const unsigned long long st_l0 = __builtin_amdgcn_s_memtime();
-    if (st_tiles == 0) st_pro = st_l0 - st_t0;
-    const unsigned long long st_bar0 = st_bar;
-    ++st_tiles;
-#endif
-    // The epilogue's operands - bias and, for c2, the residual rows - are requested here, a whole K loop before their use (loaded in
-    // the epilogue, their round trip - 1-2 k cycles - stood at the end of every tile: 43.2 / 45.1 -> 40.5 / 42.2 us per launch of the
-    // C = 256 c2 convs; issued behind the first blocks of the loop instead - vmcnt is in-order: the loop's counted waits for weight
-    // blocks then also wait for these - 42.4 / 43.7).  Only in the builds whose register budget
-    // has room for them (16 + 4 registers with four row tiles and one column tile per wave).
-    constexpr bool PRE = NRW * NCW <= 4;      // the residual rows too; the bias in every build
-    f32x4 pre_b[NCW], pre_r[PRE ? NRW : 1][PRE ? NCW : 1];
-    auto pre_issue = [&]() __attribute__((always_inline)) {
-     if constexpr (!PRE) {
-      const float* bias = CL_SEL(q, bias);
-      const int Cout = CL_SEL(q, Cout);
-#pragma unroll
-      for (int c = 0; c < NCW; ++c) {
-        const int cc = (ct0 + c) * 16 + 4 * lg;
-        pre_b[c] = (bias && cc < Cout) ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-     } else {
-      const float* bias = CL_SEL(q, bias);
-      const int Cout = CL_SEL(q, Cout);
-      const bool hres = CL_SEL(q, has_res) != 0;
-      const bool rring = CL_SEL(q, res.mode) == 0;
-      const float* rb = CL_SEL(q, res.base);
-      const int rC = CL_SEL(q, res.C), rmask = rring ? CL_SEL(q, res.lmask) : -1, rrate = CL_SEL(q, res.rate), roffs = CL_SEL(q, res.off);
-      const long long rss = CL_SEL(q, res.slot_stride);
-#pragma unroll
-      for (int c = 0; c < NCW; ++c) {
-        const int cc = (ct0 + c) * 16 + 4 * lg;
-        pre_b[c] = (bias && cc < Cout) ? cl_gload(bias + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < NRW; ++r) {
-          const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
-          const int rrow = ((rring ? epos[r] * rrate : 0) + roffs + t) & rmask;
-          pre_r[r][c] = (hres && cc < Cout) ? cl_gload(rb + (long long)(rring ? eslot[r] : i) * rss + (long long)rrow * rC + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-    }
-    };
-    int gb = 0;
-    pre_issue();
-    for (; gb + RING <= NB; gb += RING) cl_static_for<0, RING>([&](auto sl) __attribute__((always_inline)) { step(gb + decltype(sl)::value, sl); });
-    cl_static_for<0, RING - 1>([&](auto sl) __attribute__((always_inline)) { if (gb + decltype(sl)::value < NB) step(gb + decltype(sl)::value, sl); });
-#ifdef CL_STAMPS
-    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
-    st_loop += __builtin_amdgcn_s_memtime() - st_l0;
-    (void)st_bar0;
-    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---------------- split-K tail: the slices' partial tiles meet in memory.  No workgroup barrier (the helper waves are already
-    // staging the next tile behind the K loop's barriers): every matrix wave hands over ITS sub-tile on its own - agent-scope
-    // write-through stores, s_waitcnt, a ticket per (split tile, wave); the wave that draws the last ticket loads all slices' partials
-    // of that sub-tile with sc1 loads, sums them IN SLICE ORDER (its own from memory too: bit-reproducible whoever is last) and runs the
-    // epilogue.  The protocol of conv_mfma's split-K hand-off, per wave; no fence, nothing invalidates an L2.
-    bool run_epi = true;
-    if (ns > 1) {
-      float* const part = g.slab + (long long)split_idx * ns * (TM * TN) + (long long)wave * (NRW * NCW * 256);
-      float* const mine = part + (long long)ks * (TM * TN);
-#pragma unroll
-      for (int r = 0; r < NRW; ++r)
-#pragma unroll
-        for (int c = 0; c < NCW; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) __hip_atomic_store(mine + ((r * NCW + c) * 4 + e) * 64 + lane, acc[r][c][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int* const ctr = g.counters + split_idx * 4 + wave;
-      int ticket = 0;
-      if (lane == 0) ticket = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ticket = __builtin_amdgcn_readfirstlane(ticket);
-      run_epi = ticket == ns - 1;
-      if (run_epi) {
-        if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-#pragma unroll
-        for (int r = 0; r < NRW; ++r)
-#pragma unroll
-          for (int c = 0; c < NCW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s2 = 0; s2 < ns; ++s2) {
-          const float* src = part + (long long)s2 * (TM * TN);
-          float pv[NRW * NCW * 4];
-#pragma unroll
-          for (int f = 0; f < NRW * NCW * 4; ++f) pv[f] = __hip_atomic_load(src + f * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-          for (int r = 0; r < NRW; ++r)
-#pragma unroll
-            for (int c = 0; c < NCW; ++c)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc[r][c][e] += pv[(r * NCW + c) * 4 + e];
-        }
-      }
-    }
-    // ---------------- epilogue: bias -> activation -> + residual -> (pixel-shuffled) store, 4 packed columns per lane
-    if (run_epi) {
-
-      const int oact = CL_SEL(q, out_act);
-      const float oslope = CL_SEL(q, out_slope);
-      const int shuf = CL_SEL(q, shuffle_r), Cout = CL_SEL(q, Cout), Cq = Cout / shuf;
-      const bool yring = CL_SEL(q, y.mode) == 0;
-      float* yb = CL_SEL(q, y.base);
-      const int yC = CL_SEL(q, y.C), ymask = yring ? CL_SEL(q, y.lmask) : -1, yrate = CL_SEL(q, y.rate), yoff = CL_SEL(q, y.off);
-      const long long yss = CL_SEL(q, y.slot_stride);
-      const bool hres = CL_SEL(q, has_res) != 0;
-      const bool rring = CL_SEL(q, res.mode) == 0;
-      const float* rb = CL_SEL(q, res.base);
-      const int rC = CL_SEL(q, res.C), rmask = rring ? CL_SEL(q, res.lmask) : -1, rrate = CL_SEL(q, res.rate), roffs = CL_SEL(q, res.off);
-      const long long rss = CL_SEL(q, res.slot_stride);
-      float* y2b = CL_SEL(q, y2_base);
-      const float y2s = CL_SEL(q, y2_slope);
-#pragma unroll
-      for (int r = 0; r < NRW; ++r) {
-        const int m = m0 + (wr_ * NRW + r) * 16 + lr, i = m / T, t = m - i * T;
-        const int slot = eslot[r], pv = epos[r];
-#pragma unroll
-        for (int c = 0; c < NCW; ++c) {
-          const int cc = (ct0 + c) * 16 + 4 * lg;                // first of this lane's 4 packed columns
-          if (cc < Cout && pv >= 0) {
-            f32x4 o = acc[r][c] + pre_b[c];
-            if (oact == ACT_LRELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * oslope;
-            }
-            if constexpr (PRE) { if (hres) o += pre_r[r][c]; }
-            else if (hres) {
-              const int rrow = ((rring ? pv * rrate : 0) + roffs + t) & rmask;
-              o += cl_gload(rb + (long long)(rring ? slot : i) * rss + (long long)rrow * rC + cc);
-            }
-            int jj = 0, oc = cc;
-            if (shuf > 1) { jj = cc / Cq; oc = cc - jj * Cq; }
-            const int yrow = ((yring ? pv * yrate : 0) + yoff + t * shuf + jj) & ymask;
-            const long long yo = (long long)(yring ? slot : i) * yss + (long long)yrow * yC + oc;
-            cl_gstore(yb + yo, o);
-            if (y2b) {
-              f32x4 o2;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o2[e] = o[e] > 0.f ? o[e] : o[e] * y2s;
-              cl_gstore(y2b + yo, o2);
-            }
-          }
-        }
-      }
-    }
-#ifdef CL_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st_epi += __builtin_amdgcn_s_memtime() - st_e0;
-#endif
-  }
-#ifdef CL_STAMPS
-  if (tid == 0 && blockIdx.x < 256) { cl_dbg2[blockIdx.x * 4] = st_pro; cl_dbg2[blockIdx.x * 4 + 1] = st_epi; cl_dbg2[blockIdx.x * 4 + 2] = st_fb; cl_dbg2[blockIdx.x * 4 + 3] = st_tiles; }
-  if (tid == 0 && blockIdx.x < 256) {
-    cl_dbg[blockIdx.x * 4] = st_loop; cl_dbg[blockIdx.x * 4 + 1] = st_bar;
-    cl_dbg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - st_t0; cl_dbg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime() - st_r0;
-  }
-#endif
+  constexpr bool SK = false;
+#include "conv_limb_body.inc"
+}
+template <int NRW, int NCW, int RW, int CW>
+__global__ __launch_bounds__(512, 2) void conv_limb_sk_kernel(const ConvLimbGroup g) {
+  constexpr bool SK = true;
+#include "conv_limb_body.inc"
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -489,6 +126,18 @@ void launch_cl(const ConvLimbGroup& g, int grid, size_t lds_bytes, hipStream_t s
     attr_devs.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((conv_limb_kernel<NRW, NCW, RW, CW>), dim3(grid), dim3(512), lds_bytes, st, g);
+}
+template <int NRW, int NCW, int RW, int CW>
+void launch_cl_sk(const ConvLimbGroup& g, int grid, size_t lds_bytes, hipStream_t st) {
+  static std::atomic<unsigned long long> attr_devs{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)conv_limb_sk_kernel<NRW, NCW, RW, CW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_devs.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((conv_limb_sk_kernel<NRW, NCW, RW, CW>), dim3(grid), dim3(512), lds_bytes, st, g);
 }
 
 bool shape_fits(const CLShape& s, const ConvArgs& a, bool ragged_ok) {
@@ -565,7 +214,7 @@ int conv_limb_shape(const ConvArgs* p, int nprob, int num_cu, int plan_n, bool t
     // (a single problem in 64-row tiles - ups.1: 320 tiles, two rounds - measured slower than conv_mfma's f32 pass with its
     // split-K tail, 78 against 72 us; groups of problems are list-scheduled and take them)
     // ... unless the launch may split the K range of its tail tiles (round 6): 1.25 rounds then cost 1 + 1 / S
-    const int tailS = (nprob == 1 && tail_split && plan_n == 0) ? tail_slices(p[0], s, num_cu) : 1;
+    const int tailS = (nprob == 1 && tail_split && plan_n == 0 && si == 0) ? tail_slices(p[0], s, num_cu) : 1;
     if (nprob == 1 && TM < 80 && forced < 0 && tailS < 2) continue;
     if (forced >= 0) { if (si == forced) return si; continue; }
     // equal tiles run in rounds; tiles of several costs are list-scheduled (at least the largest one, at least the average)
@@ -683,7 +332,7 @@ bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream
   const size_t lds = conv_limb_lds_bytes(g.p, g.nprob, shape, &g.wr_max);
   int grid = 0;
   // the split tail: where the caller gave the launch a slab and tickets, and they are large enough
-  int tailS = (g.nprob == 1 && g.slab && g.counters) ? tail_slices(g.p[0], kShapes[shape], num_cu) : 1;
+  int tailS = (g.nprob == 1 && g.slab && g.counters && shape == 0) ? tail_slices(g.p[0], kShapes[shape], num_cu) : 1;
   if (tailS >= 2) {
     const int TM = 16 * kShapes[shape].NRW * kShapes[shape].RW, TN = 16 * kShapes[shape].NCW * kShapes[shape].CW;
     const long long tiles = (((long long)g.p[0].n * g.p[0].T + TM - 1) / TM) * ((((g.p[0].Cout + 15) / 16) * 16) / TN), rem = tiles % num_cu;
@@ -691,7 +340,9 @@ bool launch_conv_limb(const ConvLimbGroup& gin, int shape, int num_cu, hipStream
   }
   if (tailS < 2) { g.slab = nullptr; g.counters = nullptr; }
   if (!cl_schedule(g, shape, num_cu, &grid, tailS) || grid <= 0) return false;
-  switch (shape) {
+  if (tailS >= 2 && shape != 0) return false;       // (the split-tail build exists for the 64 x 64 shape only)
+  if (tailS >= 2) launch_cl_sk<4, 1, 1, 4>(g, grid, lds, st);
+  else switch (shape) {
     case 0: launch_cl<4, 1, 1, 4>(g, grid, lds, st); break;
     case 1: launch_cl<5, 1, 1, 4>(g, grid, lds, st); break;
     case 2: launch_cl<5, 2, 2, 2>(g, grid, lds, st); break;

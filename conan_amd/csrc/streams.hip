@@ -76,7 +76,8 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
       }
       double fl = 0.0;
       for (int p = 0; p < nprob; ++p) fl += 2.0 * (double)lg.p[p].n * lg.p[p].T * lg.p[p].Cout * lg.p[p].ktaps * lg.p[p].Cin;
-      profiled(cnk::conv_limb_name(shape), fl, st, [&] {
+      const bool tail = lg.slab && shape == 0 && cnk::conv_limb_tail_slices(lg.p[0], shape, cus) >= 2;
+      profiled(tail ? "cnk::conv_limb_sk_kernel<4, 1, 1, 4>" : cnk::conv_limb_name(shape), fl, st, [&] {
         if (!cnk::launch_conv_limb(lg, shape, cus, st)) throw Error(CONAN_ERR_HIP, "conv_limb launch failed");
       });
       return;

@@ -163,7 +163,8 @@ def _check_kernels(ran):
     assert any("resblock_pair_kernel" in k for k in f) and any("resblock_fused_kernel<128" in k for k in f)
     for c in (128, 64, 32):
         assert any(("resblock_limb_kernel<%d," % c) in k for k in l), sorted(l)
-    assert sum(n for k, n in l.items() if "conv_limb_kernel" in k) == 9, sorted(l)         # 6 grouped ResBlock-conv launches of the C = 256 stage + ups.1 (split-K tail) + ups.2 + ups.3
+    assert sum(n for k, n in l.items() if "conv_limb_kernel" in k) == 8, sorted(l)         # 6 grouped ResBlock-conv launches of the C = 256 stage + ups.2 + ups.3
+    assert l.get("cnk::conv_limb_sk_kernel<4, 1, 1, 4>") == 1, sorted(l)                    # ups.1: the build with the split-K tail
     assert not any("resblock_fused_kernel" in k or "resblock_pair_kernel" in k for k in l), sorted(l)
 
 

@@ -283,9 +283,10 @@ def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, other):
     assert any("resblock_limb_kernel<128" in k for k in na) and any("resblock_limb_kernel<64" in k for k in na) and any("resblock_limb_kernel<32" in k for k in na)
     # three upsamplers (ups.1 with its split-K tail since round 6: 320 tiles of 64 x 64 on 256 CUs) + 3 dilations x (c1, c2) grouped
     # launches, no pair kernel
-    assert sum(n for k, n in na.items() if "conv_limb_kernel" in k) == 9 and not any("resblock_pair_kernel" in k for k in na)
+    assert sum(n for k, n in na.items() if "conv_limb_kernel" in k or "conv_limb_sk_kernel" in k) == 9 and not any("resblock_pair_kernel" in k for k in na)
+    assert na.get("cnk::conv_limb_sk_kernel<4, 1, 1, 4>") == 1
     if other == "pair":
-        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k) == 3 and any("resblock_pair_kernel" in k for k in nb)
+        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k or "conv_limb_sk_kernel" in k) == 3 and any("resblock_pair_kernel" in k for k in nb)
         assert any("resblock_limb_kernel<128" in k for k in nb)
     else:
         assert not any("limb" in k for k in nb) and any("resblock_pair_kernel" in k for k in nb)

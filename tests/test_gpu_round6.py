@@ -86,9 +86,9 @@ def test_fixed_plan_at_full_occupancy_runs_the_default_kernels():
     assert float((wa - wb).abs().max()) <= 2e-5
     na = kernels_of(a, lambda: a.hifigan_step(ids, mel[:, 4:].contiguous()))
     nb = kernels_of(b, lambda: b.hifigan_step(ids, mel[:, 4:].contiguous()))
-    assert na.get("cnk::conv_limb_kernel<4, 1, 1, 4>") == 7 and nb.get("cnk::conv_limb_kernel<4, 1, 1, 4>") == 6, (sorted(na.items()), sorted(nb.items()))
+    assert na.get("cnk::conv_limb_sk_kernel<4, 1, 1, 4>") == 1 and "cnk::conv_limb_sk_kernel<4, 1, 1, 4>" not in nb, (sorted(na.items()), sorted(nb.items()))
     assert nb.get("cnk::conv_mfma_kernel<64, 64, 2, 2, 1, 32>") == 1 and "cnk::conv_mfma_kernel<64, 64, 2, 2, 1, 32>" not in na
-    rest = lambda d: {k: v for k, v in d.items() if "conv_limb_kernel<4, 1, 1, 4>" not in k and "conv_mfma_kernel<64, 64" not in k}
+    rest = lambda d: {k: v for k, v in d.items() if "conv_limb_sk_kernel" not in k and "conv_mfma_kernel<64, 64" not in k}
     assert rest(na) == rest(nb), (sorted(na.items()), sorted(nb.items()))
     a.close(); b.close(); ctx.close()
 
