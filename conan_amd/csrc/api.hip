@@ -421,6 +421,12 @@ int conan_step_async(conan_streams* s, const int32_t* slots, int n, int emit, co
     // issued back to back the stages work on consecutive chunks at the same time (Emformer of chunk t+2 beside the decoder
     // of t+1 beside the vocoder of t): the decoder's ~50 latency-bound launches no longer queue behind the Emformer's
     // one long launch, and their tail no longer leaves the vocoder stream idle.
+    // An EMPTY pipeline (the first step, or every earlier step has completed - e.g. behind the caller's join + synchronize): nothing of
+    // this stream-set can overlap this step's Emformer launch, which the decoder and vocoder of the same chunk wait for - it may take
+    // the blocking steps' launch shape (one workgroup per CU where the stream-set is alone on the device: 136 instead of 190 us on
+    // the first chunk's critical path; the feed-forward's sum does not depend on the cluster size, so the bits are the same).
+    s->pipe_idle = t == 0 || (hipEventQuery(s->ev_emf[pl]) == hipSuccess && hipEventQuery(s->ev_front[pl]) == hipSuccess && hipEventQuery(s->ev_voc[pl]) == hipSuccess);
+    (void)hipGetLastError();      // (hipErrorNotReady from a query is an answer, not an error)
     // inputs are ready in the caller's stream order
     HIP_CHECK(hipEventRecord(s->ev_in[p], (hipStream_t)stream));
     HIP_CHECK(hipStreamWaitEvent(s->st_emf, s->ev_in[p], 0));

@@ -76,6 +76,7 @@ struct conan_streams {
   // (the per-utterance style pass of a fixed-plan stream-set runs one slot at a time: its plan follows the slot's own reference length)
   bool in_style_pass = false;
   int plan_n(int n) const { return (fixed_plan && !in_style_pass) ? max_slots : n; }
+  bool pipe_idle = false;                      // set by conan_step_async: no earlier pipelined step of this stream-set is still in flight
   bool shared_device = false;                  // CONAN_STREAMS_SHARED_DEVICE: other processes drive this GPU too - never take whole-chip launch shapes
   int max_slots = 0, max_frames = 0, max_ref = 0, S_max = 0;
   std::vector<void*> allocs;

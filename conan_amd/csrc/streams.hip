@@ -742,7 +742,7 @@ void conan_streams::emformer_step(int n, const float* chunk, float* out, float* 
       // device (counted over all contexts of the process; CONAN_STREAMS_SHARED_DEVICE when other processes use the GPU): its launches are serialised on one stream.  The feed-forward's sum is formed chunk by chunk in chunk order whatever the
       // cluster size (emformer_fused.hip), so the step styles and both policies produce the same bits.)
       const bool pipelined = st_emf != nullptr && st == st_emf;       // (the internal stream exists only once a pipelined step has run; a caller's null stream is not it)
-      const bool alone = !pipelined && !shared_device && live && live->load() == 1;
+      const bool alone = (!pipelined || pipe_idle) && !shared_device && live && live->load() == 1;      // (pipe_idle: a pipelined step into an EMPTY pipeline, conan_step_async)
       const int cap = (emf_cluster > 0 || alone) ? ctx->num_cu : 64;
       a.cs = emf_cluster > 0 ? std::min(emf_cluster, (int)cnk::EMF_MAX_CLUSTER) : cnk::EMF_MAX_CLUSTER;
       while (a.cs & (a.cs - 1)) a.cs &= a.cs - 1;             // a power of two

@@ -1,7 +1,7 @@
 """Regenerate DESIGN.md's round table (between the round-table markers) from tools/design_round_table.tpl and the committed profiles
 (profiles/<round>_*): run after tools/collect_round.sh's output has been copied into profiles/.   python tools/fill_design.py [round]"""
 import json, re, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r5"
+R = sys.argv[1] if len(sys.argv) > 1 else "r6"
 P = "profiles/%s_" % R
 
 
@@ -14,6 +14,9 @@ b1 = J("b1"); b1w = J("b1win"); b128 = J("b128s2"); b128w = J("b128s2win"); m4 =
 pmc = json.load(open(P + "b64_pmc.json"))
 st = dict(re.findall(r"(emformer|decoder|vocoder|pipelined)\D+([0-9.]+) ms", open(P + "stage_times.txt").read()))
 tests = open(P + "pytest_gpu.txt").read().strip().splitlines()[-1]
+k20 = json.load(open(P + "b64_bench_k20.json"))
+fp = re.findall(r"fixed_plan=(True|False) ms/step ([0-9.]+) p50 ([0-9.]+) vocoder alone ([0-9.]+)", open(P + "fixed_plan_cost.txt").read())
+fpm = lambda flag, i: sum(float(x[i]) for x in fp if x[0] == flag) / max(1, sum(1 for x in fp if x[0] == flag))
 cpu = d["cpu_baseline"]
 
 
@@ -41,7 +44,9 @@ fill = {
     "DECF": "%.0f" % (dec["fetch"] / dec["dispatches_per_step"] / 1e6) if dec else "?",
     "B1WIN": "%.3f" % b1w["ms_per_step"], "B128MS": "%.3f" % b128["ms_per_step"], "B128V": "%.1f" % (b128["value"] / 1e3),
     "B128P50": "%.2f" % b128["p50_latency_ms"], "B128WIN": "%.2f" % b128w["ms_per_step"], "MEM4": "%.3f" % m4["ms_per_step"],
-    "COMM": "%.3f" % comm["ms_per_step"], "CPU": "%.1f" % cpu["value"], "CPUS": "%.1f" % cpu["stateful_value"], "TESTS": tests.strip("= "),
+    "COMM": "%.3f" % comm["ms_per_step"], "K20": "%.3f" % k20["ms_per_step"], "VOCA": "%.3f" % r["vocoder_alone_ms"],
+    "FPD": "%.4f" % fpm("False", 1), "FPF": "%.4f" % fpm("True", 1), "FPPD": "%.3f" % fpm("False", 2), "FPPF": "%.3f" % fpm("True", 2),
+    "FPVD": "%.3f" % fpm("False", 3), "FPVF": "%.3f" % fpm("True", 3), "CPU": "%.1f" % cpu["value"], "CPUS": "%.1f" % cpu["stateful_value"], "TESTS": tests.strip("= "),
 }
 t = open("tools/design_round_table.tpl").read()
 for k, v in fill.items():
