@@ -113,6 +113,44 @@ class EmformerDistillModel(_tree.ParamTree):
         return self._streams
 
     @torch.inference_mode()
+    def inference_rtf(self, mel_input, verbose=False):
+        """emformer.py:99-156: `inference` with a clock around every streaming step.  Returns what the reference returns:
+        (proj(features), latency_list, rtf_list), or (proj1(features), proj2(features), latency_list) when mode == 'both'; latencies in
+        seconds per chunk step (host submit -> the step's outputs complete on the device: the reference reads time.time() around an
+        asynchronous CUDA call, i.e. the submit time - here the device is synchronised so that the figure is the step's latency),
+        rtf = latency / (segment_length * 20 ms)."""
+        import time
+        B, T, F = mel_input.shape
+        seg, rc = self.segment_length, self.right_context_len
+        pos, state, outs, logits, lat, rtf = 0, None, [], [], [], []
+        while pos < T:
+            emit = min(seg, T - pos)
+            look = min(rc, T - (pos + emit))
+            real = emit + look
+            chunk = mel_input[:, pos:pos + real, :]
+            need = (seg + rc) - real
+            if need > 0:
+                chunk = torch.cat([chunk, chunk[:, -1:, :].expand(B, need, F)], dim=1)
+            lengths = torch.full((B,), chunk.size(1), dtype=torch.long, device=mel_input.device)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out, _, state = self.emformer.infer(chunk, lengths, state)
+            torch.cuda.synchronize()
+            lat.append(time.time() - t0)
+            rtf.append(lat[-1] / (seg * 0.02))
+            if verbose:
+                print("latency: {:.4f}, rtf: {:.4f}".format(lat[-1], rtf[-1]))
+            outs.append(out[:, :emit, :])
+            logits.append(self._last[1][:, :emit, :])
+            pos += emit
+        first = torch.cat(logits, dim=1)
+        if self.mode == "both":
+            return first, self.proj2(torch.cat(outs, dim=1)), lat
+        if "proj" not in self._modules or not hasattr(self._modules["proj"], "weight"):
+            return torch.cat(outs, dim=1), lat, rtf
+        return first, lat, rtf
+
+    @torch.inference_mode()
     def inference(self, mel_input):
         """emformer.py:48-98: chunked streaming over mel_input[B, T, F] -> proj(features) [B, T, out_dim], or the tuple
         (proj1(features), proj2(features)) when mode == 'both' (emformer.py:95-97)."""

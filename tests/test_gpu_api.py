@@ -68,6 +68,12 @@ def test_emformer_module_streaming_api():
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits.numpy(), atol=2e-4, rtol=1e-4)
     with pytest.raises(ValueError):        # torchaudio raises ValueError for a wrong chunk length
         e.emformer.infer(mel[:, :5].cuda(), torch.tensor([5, 5]).cuda(), None)
+    # inference_rtf (modules/Emformer/emformer.py:99-156): the same logits + one latency and one real-time factor per chunk step
+    out, lat, rtf = e.inference_rtf(mel.cuda())
+    assert torch.equal(out, logits)
+    n_steps = -(-30 // e.segment_length)
+    assert len(lat) == n_steps and len(rtf) == n_steps and all(0 < x < 1.0 for x in lat)
+    assert all(abs(r - l / (e.segment_length * 0.02)) < 1e-12 for r, l in zip(rtf, lat))
 
 
 def test_streaming_voice_conversion_infer_once():
