@@ -288,9 +288,10 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
   m.xcd = e.xcd ? 1 : 0;
   const bool pipelined = st_front != nullptr && st == st_front;
   if (e.xcd) {
-    // Pipelined single-tile steps: the group's members take only the LDS their operators need (34 KB), so that the small-batch vocoder's
-    // 126 KB conv_mfma workgroups find room beside them (round 5 launched 84 KB here as well: 32 blocks of every vocoder launch then
-    // waited for the decoder step to end, 0.635 against round 4's 0.52 ms per one-stream pipelined step).  Same program, same bits.
+    // Pipelined single-tile steps: the group's members take only the LDS their operators need (36.5 KB), so that the small-batch
+    // vocoder's conv_mfma workgroups (112.5 KB since round 6) find room beside them (round 5 launched 84 KB here as well: 32 blocks of
+    // every vocoder launch then waited for the decoder step to end - 0.635 ms per one-stream pipelined step, 0.40 now).  Same program,
+    // same bits.
     static const bool pad_always = ch::dev_getenv("CONAN_MEGA_XCD_PAD") != nullptr;
     if (pipelined && !pad_always) m.lds_bytes = e.lds_need;
     mega_xseq = mega_xseq + 1u;       // (20 bits of it travel in the election word; consecutive launches differ)
@@ -323,7 +324,7 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
 void conan_streams::parse_dev_plan(const char* text) {
   static const char* known[] = {"RESERVE_CUS", "ROWCONV", "RB_NOMERGE", "RB_NOLIMB", "FENCED", "DEC_MEGA", "MEGA_GRID", "FRONT_CUSTRIDE", "EMF_CUSTRIDE", "MEGA_GS",
                                 "MEGA_NARROW", "MEGA_NOL2", "MEGA_LAYOUT", "FRONT_PRIO", "RB_UNFUSED", "RB_FUSED", "RB_PAIR", "RB_NOPAIR", "RP_MIN_SLOTS",
-                                "UPS_CFG", "EMF_CLUSTER", "EMF_UNFUSED", "UPS_F32", "C256_SHAPE"};
+                                "UPS_CFG", "EMF_CLUSTER", "EMF_UNFUSED"};
   dev_plan.clear();
   if (!text) return;
   const std::string t(text);
