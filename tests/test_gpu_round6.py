@@ -70,6 +70,37 @@ def test_fixed_plan_stream_bits_do_not_depend_on_the_active_slots(arith):
     ctx.close()
 
 
+def test_fixed_plan_with_40ms_chunks_and_ragged_tiles():
+    """The same promise at BASELINE configs[4]'s chunk size (40 ms: 2 frames per step, 16 rows per slot in the C = 256 stage - four
+    slots per conv_limb tile): slot 17 of a 32-slot fixed-plan stream-set with 32, 9 and 1 active slots (9 and 1 end in ragged tiles
+    where the full set's tiles are whole: the shape is chosen as the full set would, the launch's own last tile may be ragged) - codes,
+    mel and audio bit-identical over 16 steps."""
+    chp = dict(configs.conan_hparams(), chunk_size=40)
+    ctx, chp, _ = _ctx(chp=chp)
+    S, K, steps, seg = 32, 17, 16, 2
+    src = torch.from_numpy(synth.mel(seg * steps + 2, 77, S)).cuda()
+    ref = torch.from_numpy(synth.mel(36, 78, S)).cuda()
+    actives = [list(range(S)), [3, 5, 8, K, 20, 21, 22, 30, 31], [K]]
+    outs = []
+    for act in actives:
+        st = ctx.streams(S, max_frames=seg, max_ref_frames=64, flags=_lib.STREAMS_FIXED_PLAN)
+        st.reset(act)
+        idx = torch.tensor(act, device="cuda")
+        st.set_reference(act, ref[idx].contiguous())
+        k = act.index(K)
+        c, m, w = [], [], []
+        for t in range(steps):
+            cc, mm, ww = st.step(act, src[idx, seg * t:seg * t + seg + 2].contiguous())
+            c.append(cc[k].clone()); m.append(mm[k].clone()); w.append(ww[k].clone())
+        outs.append((torch.cat(c), torch.cat(m), torch.cat(w)))
+        st.close()
+    for o in outs[1:]:
+        for x, y in zip(o, outs[0]):
+            assert torch.equal(x, y), float((x.float() - y.float()).abs().max())
+    assert torch.isfinite(outs[0][2]).all()
+    ctx.close()
+
+
 def test_fixed_plan_at_full_occupancy_runs_the_default_kernels():
     """At 64 of 64 slots active the fixed plan is the default's except for ups.1: its split-K tail (which tiles are split follows a
     slot's position in the active list) is what lets it run on the limb MFMA; a fixed-plan stream-set keeps it on conv_mfma without a
