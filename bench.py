@@ -397,7 +397,9 @@ def launcher_command(gpus, argv, env=None, port=None):
     127.0.0.1), or None when this process IS a rank already (WORLD_SIZE / RANK set by a launcher: no recursion) or N = 1.
     BASELINE.json configs[3] (512 streams over 8 GPUs) is this path."""
     env = os.environ if env is None else env
-    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+    if "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+        return None
+    if gpus <= 1 and env.get("CONAN_BENCH_FORCE_SPAWN") != "1":      # (test hook: the child-process path with one rank, on a 1-GPU box)
         return None
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
             "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)

@@ -224,3 +224,24 @@ def test_option_block_abi8():
     names = kernels_of(per_op, lambda: per_op.emformer_step([0, 1], chunk))
     assert not any("emformer_fused_kernel" in k for k in names), sorted(names)
     st.close(); per_op.close(); ctx.close()
+
+
+def test_bench_launcher_child_process_path_with_one_rank():
+    """bench.py's own launcher (task 1) on real hardware as far as a 1-GPU box allows: CONAN_BENCH_FORCE_SPAWN=1 makes
+    `python bench.py --gpus 1` take the path `--gpus 8` takes on an 8-GPU node - torch.distributed.run started as a CHILD process on
+    127.0.0.1, the rank's JSON line relayed, its exit code returned - with one rank (the ranks' RCCL side is covered by the world-1
+    test of tests/test_gpu_round5.py and the gloo tests)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CONAN_BENCH_FORCE_SPAWN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--prime", "0", "--latency-steps", "2",
+                        "--no-cpu-baseline", "--no-other", "--no-b1", "--streams", "8"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["ranks"]["rccl_world"] == 1
