@@ -1,4 +1,4 @@
-**Measured (round 6, 1×MI355X, `profiles/r6_*`; the box of the collection - the pool's boxes differ by ±2-4 %: THIS box's vocoder-alone step is @VOCA@ ms, round 5's collection box ran the same launches in 1.199; `profiles/r6_voc_kernels.txt` has the round's kernels on a fast box).**
+**Measured (round 6, 1×MI355X, `profiles/r6_*`; the box of the collection - the pool's boxes differ by ±2-4 %: THIS box's vocoder-alone step is @VOCA@ ms; round 5's collection box: 1.199 with round 5's library; `profiles/r6_voc_kernels.txt` has the round's kernels on a fast box).**
 
 | | bf16-limb (default, headline) | exact-f32 MFMA (`--arith f32`) |
 |---|---|---|
@@ -12,7 +12,7 @@
 | HBM bytes per step (PMC, gfx950-corrected) | **@HBM@ GB** (fetch @FETCH@ + write @WRITE@): decoder launch @DECF@ MB (group-fastest layout, §4.2; 159 MB member-fastest: measured, not shipped - §4.6), Emformer 78 MB | — |
 | other BASELINE configs | b1win @B1WIN@ ms per blocking windowed step; b128s2 (40 ms chunks, B = 128) **@B128MS@ ms per step = @B128V@ k chunks/s**, p50 @B128P50@; b128s2win @B128WIN@ ms; b128s2mem4 @MEM4@ ms | — |
 | gather choreography on one rank (`CONAN_BENCH_COMM=1`) | @COMM@ ms per step | — |
-| `CONAN_STREAMS_FIXED_PLAN` at 64 of 64 slots active (`profiles/r6_fixed_plan_cost.txt`, three alternating runs) | @FPD@ ms per step default against @FPF@ fixed (ups.1 without its split tail, on the f32 MFMA; vocoder alone @FPVD@ against @FPVF@; blocking p50 @FPPD@ against @FPPF@) | — |
+| `CONAN_STREAMS_FIXED_PLAN` at 64 of 64 slots active (`profiles/r6_fixed_plan_cost.txt`, three alternating runs, medians) | @FPD@ ms per step default against @FPF@ fixed (ups.1 without its split tail, on the f32 MFMA; vocoder alone @FPVD@ against @FPVF@; blocking p50 @FPPD@ against @FPPF@) | — |
 | CPU baseline (oracle, AMD EPYC 9575F host, 16 threads chosen by probe) | reference-semantics loop @CPU@ chunks/s, stateful @CPUS@ | — |
 | GPU tests | @TESTS@ | — |
 

@@ -16,7 +16,7 @@ st = dict(re.findall(r"(emformer|decoder|vocoder|pipelined)\D+([0-9.]+) ms", ope
 tests = open(P + "pytest_gpu.txt").read().strip().splitlines()[-1]
 k20 = json.load(open(P + "b64_bench_k20.json"))
 fp = re.findall(r"fixed_plan=(True|False) ms/step ([0-9.]+) p50 ([0-9.]+) vocoder alone ([0-9.]+)", open(P + "fixed_plan_cost.txt").read())
-fpm = lambda flag, i: sum(float(x[i]) for x in fp if x[0] == flag) / max(1, sum(1 for x in fp if x[0] == flag))
+fpm = lambda flag, i: sorted(float(x[i]) for x in fp if x[0] == flag)[sum(1 for x in fp if x[0] == flag) // 2]      # median of the runs
 cpu = d["cpu_baseline"]
 
 
