@@ -57,7 +57,7 @@ PEAK_LIMB_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 def kernel_peak(name):
     """(peak in algorithmic TFLOP/s, what it is) of a matrix kernel by its name."""
-    if "resblock_limb" in name or "conv_limb" in name:      # (conv_limb_kernel and conv_limb_sk_kernel, its build with the split-K tail)
+    if "resblock_limb" in name or "conv_limb" in name or "conv_tall" in name:      # (conv_limb_kernel and conv_limb_sk_kernel, its build with the split-K tail)
         return PEAK_LIMB_TFLOPS, "bf16 MFMA dense / 6 limb products per fp32 product"
     return PEAK_F32_MFMA_TFLOPS, "f32 MFMA dense"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)

@@ -157,6 +157,19 @@ int conv_cfg_tm(int cfg);
 int conv_cfg_tn(int cfg);
 void launch_conv(const ConvGroup& g, int nprob, int cfg, hipStream_t st, int num_cu = 256);
 
+// A convolution with few rows per slot and a long K (ups.0) as a split-K GEMM in the limb arithmetic (conv_tall.hip): tiles of 128 rows
+// of any slots x 128 columns, items = (tile, K slice), the slices' partial tiles summed in slice order by the last arrival.
+struct ConvTallArgs {
+  ConvArgs p;
+  int S, nbps;            // K slices per tile, (tap, 32-channel) blocks per slice (even)
+  int mtiles, ntiles;
+  float* slab;            // [tile][slice][128 x 128] partial tiles
+  int* counters;          // [tile][4 matrix waves] tickets, zero before and after every launch
+};
+bool conv_tall_supported(const ConvArgs& a);
+bool conv_tall_plan(const ConvArgs& a, int num_cu, int plan_n, ConvTallArgs* out, long long slab_floats, int max_counters, int max_T = 32);
+void launch_conv_tall(const ConvTallArgs& g, hipStream_t st);
+
 // The same convolution with every fp32 product as six bf16 limb products on the bf16 MFMA (conv_limb.hip); covers the
 // subset of ConvArgs that conv_limb_supported() accepts.
 struct ConvLimbGroup {

@@ -58,6 +58,18 @@ void conan_streams::launch_group(const ConvGroup& gin, int nprob, int cfg, hipSt
       throw Error(CONAN_ERR_UNSUPPORTED, "activation tensor of 4 GiB or more: lower max_slots");
     if (a.y2_base && ((a.Cout & 3) || (a.y.C & 3) || ((a.Cout / a.shuffle_r) & 3))) throw Error(CONAN_ERR_UNSUPPORTED, "activated twin output needs channel counts that are multiples of 4");
   }
+  // few rows per slot and a long K (ups.0: 4 rows per stream, K = 8192): the split-K limb GEMM of conv_tall.hip
+  if (rb_limb && nprob == 1 && dev("NO_TALL") == nullptr) {
+    const int cus = std::max(8, ctx->num_cu - (ws_index(st) == 1 ? reserve_cus : 0));
+    const int wsi = ws_index(st);
+    cnk::ConvTallArgs ta;
+    if (cnk::conv_tall_plan(gin.p[0], cus, fixed_plan ? plan_n(gin.p[0].n) : 0, &ta, sk_slab_floats, sk_max_tiles, dev("TALL_MAXT") ? atoi(dev("TALL_MAXT")) : 32)) {
+      ta.slab = sk_slab[wsi]; ta.counters = sk_counters[wsi];
+      const ConvArgs& a = gin.p[0];
+      profiled("cnk::conv_tall_kernel", 2.0 * (double)a.n * a.T * a.Cout * a.ktaps * a.Cin, st, [&] { cnk::launch_conv_tall(ta, st); });
+      return;
+    }
+  }
   // the bf16-limb form (conv_limb.hip) where the weights were packed for it and a tile shape fits all problems of the group
   if (rb_limb && nprob >= 1 && nprob <= 3) {
     bool ok = true;
@@ -324,7 +336,7 @@ void conan_streams::launch_mega(MegaProgram& e, hipStream_t st) {
 void conan_streams::parse_dev_plan(const char* text) {
   static const char* known[] = {"RESERVE_CUS", "ROWCONV", "RB_NOMERGE", "RB_NOLIMB", "FENCED", "DEC_MEGA", "MEGA_GRID", "FRONT_CUSTRIDE", "EMF_CUSTRIDE", "MEGA_GS",
                                 "MEGA_NARROW", "MEGA_NOL2", "MEGA_LAYOUT", "FRONT_PRIO", "RB_UNFUSED", "RB_FUSED", "RB_PAIR", "RB_NOPAIR", "RP_MIN_SLOTS",
-                                "UPS_CFG", "EMF_CLUSTER", "EMF_UNFUSED"};
+                                "UPS_CFG", "EMF_CLUSTER", "EMF_UNFUSED", "NO_TALL", "TALL_MAXT"};
   dev_plan.clear();
   if (!text) return;
   const std::string t(text);

@@ -7,7 +7,7 @@
 Both are fp32 convolutions of the SAME fp32 inputs and weights, so the yardstick for either is the same convolution evaluated
 in float64 (oracle/hifigan.py restates hifigan_causal.py:217-244 ResBlock1 and :191-212 the pixel-shuffle upsampler; run on
 float64 tensors it is that evaluation).  Per kernel - the MRF stage C = 256 (conv_limb's grouped launches at >= 16 slots), the
-fused ResBlock passes C = 128 / 64 / 32 (resblock_limb) and the upsamplers ups.1 / ups.2 / ups.3 (conv_limb) - the test takes the tensor
+fused ResBlock passes C = 128 / 64 / 32 (resblock_limb) and the upsamplers ups.0 / ups.1 (conv_tall), ups.2 / ups.3 (conv_limb) - the test takes the tensor
 the kernel read and the tensor it wrote through conan_hifigan_step_taps, evaluates the float64 reference on the tensor read,
 and asserts
 
@@ -98,9 +98,10 @@ def _run(ctx, arith, mel):
     parts = [st.hifigan_step_taps(ids, x[:, p:p + FRAMES].contiguous(), stage_out=True) for p in range(0, STEPS * FRAMES, FRAMES)]
     ups = [torch.cat([p[3][i][list(CHECK)] for p in parts], 1).cpu() for i in range(len(parts[0][3]))]
     outs = [torch.cat([p[4][i][list(CHECK)] for p in parts], 1).cpu() for i in range(len(parts[0][4]))]
+    cpre = torch.cat([p[2][list(CHECK)] for p in parts], 1).cpu()       # conv_pre's activated output: what ups.0 reads
     names = kernels_of(st, lambda: st.hifigan_step(ids, x[:, :FRAMES].contiguous()))
     st.close()
-    return ups, outs, names
+    return cpre, ups, outs, names
 
 
 def _errors(got, want):
@@ -134,8 +135,13 @@ def _measure(case):
     nb = len(vhp["resblock_kernel_sizes"])
     res, ran = {}, {}
     for arith in ("f32", "limb"):
-        ups, outs, names = _run(ctx, arith, mel)
+        cpre, ups, outs, names = _run(ctx, arith, mel)
         ran[arith] = names
+        with torch.no_grad():      # ups.0: conv + pixel shuffle in float64 on the tensor it read (conv_pre's output, already activated)
+            y0 = ohifi._cconv(sd64, "ups.0.conv.conv", cpre.double().transpose(1, 2))
+            want0 = ohifi.pixel_shuffle_1d(y0, vhp["upsample_rates"][0]).transpose(1, 2)
+        res.setdefault("ups.0", {})[arith] = _errors(ups[0], want0)
+        res["ups.0"]["ref_rms"] = float(want0.pow(2).mean().sqrt())
         for i in range(len(ups)):
             # the MRF stage: leaky_relu(mean_j ResBlock1_j(up)) in float64 on the tensor the stage's kernels read
             up64 = ups[i].double().transpose(1, 2)
@@ -164,13 +170,12 @@ def _check_kernels(ran):
     for c in (128, 64, 32):
         assert any(("resblock_limb_kernel<%d," % c) in k for k in l), sorted(l)
     assert sum(n for k, n in l.items() if "conv_limb_kernel" in k) == 8, sorted(l)         # 6 grouped ResBlock-conv launches of the C = 256 stage + ups.2 + ups.3
-    assert l.get("cnk::conv_limb_sk_kernel<4, 1, 1, 4>") == 1, sorted(l)                    # ups.1: the build with the split-K tail
+    assert l.get("cnk::conv_tall_kernel") == 2, sorted(l)                                   # ups.0 and ups.1: the split-K limb GEMM (conv_tall.hip)
     assert not any("resblock_fused_kernel" in k or "resblock_pair_kernel" in k for k in l), sorted(l)
 
 
-# (ups.1 is a limb kernel since round 6: conv_limb with a split-K tail - the partial tiles of its last 64 tiles are summed in slice
-# order; ups.0 - 4 rows per stream, K = 8192 - stays on the f32 MFMA in both stream-sets)
-LIMB_KERNELS = ("stage.0", "stage.1", "stage.2", "stage.3", "ups.1", "ups.2", "ups.3")
+# (ups.0 and ups.1 are limb kernels since round 6: conv_tall.hip, a split-K GEMM whose partial tiles are summed in slice order)
+LIMB_KERNELS = ("stage.0", "stage.1", "stage.2", "stage.3", "ups.0", "ups.1", "ups.2", "ups.3")
 
 
 @pytest.mark.parametrize("case", ["normal", "scales", "mantissas", "tiny60", "tiny110"])

@@ -281,12 +281,11 @@ def test_bf16_limb_kernels_equal_the_f32_mfma_kernels(env, other):
     # the kernels that ran (a silent fall-back to the f32 kernels would pass the comparison above)
     na, nb = _kernel_names(a, ids, mel[:, :4].contiguous()), _kernel_names(b, ids, mel[:, :4].contiguous())
     assert any("resblock_limb_kernel<128" in k for k in na) and any("resblock_limb_kernel<64" in k for k in na) and any("resblock_limb_kernel<32" in k for k in na)
-    # three upsamplers (ups.1 with its split-K tail since round 6: 320 tiles of 64 x 64 on 256 CUs) + 3 dilations x (c1, c2) grouped
-    # launches, no pair kernel
-    assert sum(n for k, n in na.items() if "conv_limb_kernel" in k or "conv_limb_sk_kernel" in k) == 9 and not any("resblock_pair_kernel" in k for k in na)
-    assert na.get("cnk::conv_limb_sk_kernel<4, 1, 1, 4>") == 1
+    # ups.2 / ups.3 + 3 dilations x (c1, c2) grouped launches on conv_limb, no pair kernel
+    assert sum(n for k, n in na.items() if "conv_limb_kernel" in k) == 8 and not any("resblock_pair_kernel" in k for k in na)
+    assert na.get("cnk::conv_tall_kernel") == 2       # ups.0 and ups.1 (round 6: the split-K limb GEMM of conv_tall.hip)
     if other == "pair":
-        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k or "conv_limb_sk_kernel" in k) == 3 and any("resblock_pair_kernel" in k for k in nb)
+        assert sum(n for k, n in nb.items() if "conv_limb_kernel" in k) == 2 and nb.get("cnk::conv_tall_kernel") == 2 and any("resblock_pair_kernel" in k for k in nb)
         assert any("resblock_limb_kernel<128" in k for k in nb)
     else:
         assert not any("limb" in k for k in nb) and any("resblock_pair_kernel" in k for k in nb)

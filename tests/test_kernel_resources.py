@@ -102,6 +102,9 @@ def test_co_residency_budgets(tmp_path):
         # per wave) leave the 128-register decoder build its place
         if "ILi4ELi1ELi1ELi4E" in k or "ILi5ELi1ELi1ELi4E" in k:
             assert 2 * gran(f["vgpr"] + f["agpr"]) + 128 <= 512, (k, f)
+    # conv_tall.hip (ups.0 / ups.1 from 24-32 streams on): 112 KB of dynamic LDS and at most 192 registers - beside the 128-register decoder
+    tall = _find(ks, "conv_tall_kernel")
+    assert tall["spill"] == 0 and tall["scratch"] == 0 and tall["lds"] == 0 and 2 * gran(tall["vgpr"] + tall["agpr"]) + 128 <= 512, tall
     # conv_mfma's shapes that run at serving sizes beside the 128-register decoder build (ups.0: <32,64,1,2,2,64>, ups.1: <64,64,2,2,1,32>,
     # two waves per SIMD each): round 5 briefly gave the 32-row shapes a 64-register split-K batch and an operand prefetch - 231
     # registers, the decoder's workgroups no longer fitted beside ups.0's and the pipelined step lost 4 % (1.355 -> 1.40 ms); they are
